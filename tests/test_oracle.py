@@ -1,0 +1,133 @@
+"""Pins the CPU oracle (oracle/dfft_oracle.c).
+
+The reference has no golden vectors (inputs are clock()-seeded, tests/src/pencil/base.cu:49),
+so the oracle is pinned by: a long-double O(N^2) DFT, numpy's pocketfft (independent), the
+committed fixtures in tests/golden/ and the three properties the reference's own tests
+check: testcase 1 (distributed == single device, tests/src/pencil/random_dist_3D.cu:386-403),
+testcase 3 (round trip, :641-666) and testcase 4 (analytic Laplacian, :73-121, :748-793).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel_linf(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 8, 12, 15, 16, 30, 64, 100, 128, 256, 1024, 2048])
+@pytest.mark.parametrize("sign", [-1, 1])
+def test_fft1d_vs_naive_long_double(n, sign):
+    rng = np.random.default_rng(n * 7 + sign)
+    x = (rng.uniform(0, 255, n) + 1j * rng.uniform(0, 255, n))
+    want = orc.dft_naive(x, sign)
+    got = orc.fft1d(x[None, :], sign)[0]
+    assert rel_linf(got, want) < 2e-14
+    ref = np.fft.fft(x) if sign < 0 else np.fft.ifft(x) * n
+    assert rel_linf(got, ref) < 2e-14
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 8), (16, 4, 32), (12, 10, 14), (9, 7, 10), (32, 32, 32)])
+def test_fft3d_vs_numpy(shape):
+    rng = np.random.default_rng(sum(shape))
+    x = rng.uniform(0, 255, shape) + 1j * rng.uniform(0, 255, shape)
+    assert rel_linf(orc.fft3d_c2c(x, -1), np.fft.fftn(x)) < 1e-13
+    assert rel_linf(orc.fft3d_c2c(x, +1), np.fft.ifftn(x) * x.size) < 1e-13
+    r = rng.uniform(0, 255, shape)
+    X = orc.fft3d_r2c(r)
+    assert rel_linf(X, np.fft.rfftn(r)) < 1e-13
+    back = orc.fft3d_c2r(X, shape[2])
+    # unnormalised: C2R(R2C(x)) = Nx*Ny*Nz*x (reference subtracts N^3*in, random_dist_3D.cu:650)
+    assert rel_linf(back / r.size, r) < 1e-13
+
+
+DECOMPS = [((8, 8, 8), 1, 1), ((8, 8, 8), 2, 2), ((16, 16, 16), 2, 4), ((12, 10, 14), 2, 4),
+           ((9, 7, 10), 3, 2), ((16, 8, 8), 4, 1), ((10, 9, 12), 3, 1), ((10, 9, 12), 1, 3),
+           ((16, 16, 16), 8, 1)]
+
+
+@pytest.mark.parametrize("shape,P1,P2", DECOMPS)
+@pytest.mark.parametrize("c2c", [False, True])
+def test_testcase1_distributed_equals_single(shape, P1, P2, c2c):
+    """Reference testcase 1: gather of the distributed outputs == one-device 3-D transform."""
+    g = orc.fill_block(shape, (0, 0, 0), shape, 2 if c2c else 1, seed=11)
+    pl = orc.PencilPlan(*shape, P1, P2, c2c)
+    outs = pl.forward(pl.scatter(g))
+    G = pl.gather_out(outs)
+    single = orc.fft3d_c2c(g, -1) if c2c else orc.fft3d_r2c(g)
+    # same 1-D routine on the same lines in the same z,y,x order: bit-identical
+    assert np.array_equal(G, single)
+    assert rel_linf(G, np.fft.fftn(g) if c2c else np.fft.rfftn(g)) < 1e-13
+
+
+@pytest.mark.parametrize("shape,P1,P2", DECOMPS)
+@pytest.mark.parametrize("c2c", [False, True])
+def test_testcase3_round_trip(shape, P1, P2, c2c):
+    g = orc.fill_block(shape, (0, 0, 0), shape, 2 if c2c else 1, seed=3)
+    pl = orc.PencilPlan(*shape, P1, P2, c2c)
+    ins = pl.scatter(g)
+    back = pl.inverse(pl.forward(ins))
+    n3 = float(np.prod(shape))
+    for r in range(pl.P):
+        assert rel_linf(back[r] / n3, ins[r]) < 1e-13
+
+
+@pytest.mark.parametrize("shape,P1,P2", [((16, 16, 16), 2, 4), ((32, 16, 8), 2, 2), ((16, 16, 16), 1, 1)])
+def test_testcase4_laplacian(shape, P1, P2):
+    """u = sin sin sin; forward, multiply by -(k1^2+k2^2+k3^2)/sqrt(N^3) on the distributed
+    output layout, inverse; compare with -3*sqrt(N^3)*u (random_dist_3D.cu:748-778)."""
+    Nx, Ny, Nz = shape
+    x, y, z = np.meshgrid(np.arange(Nx), np.arange(Ny), np.arange(Nz), indexing="ij")
+    u = np.sin(2 * np.pi * x / Nx) * np.sin(2 * np.pi * y / Ny) * np.sin(2 * np.pi * z / Nz)
+    pl = orc.PencilPlan(Nx, Ny, Nz, P1, P2, False)
+    ins = pl.scatter(u)
+    outs = pl.forward(ins)
+    for r in range(pl.P):
+        s, o = pl.out_block(r)
+        n = s[0] * s[1] * s[2]
+        blk = np.ascontiguousarray(outs[r][:n].reshape(s))
+        orc.derivative_coefficients(blk, shape, o[2], o[1], half=True)
+        outs[r][:n] = blk.ravel()
+    back = pl.inverse(outs)
+    n3 = float(Nx * Ny * Nz)
+    for r in range(pl.P):
+        want = -3.0 * np.sqrt(n3) * ins[r]
+        assert np.max(np.abs(back[r] - want)) < 1e-9 * np.sqrt(n3)
+
+
+def test_exchange_tables_match_reference_formulas():
+    """mpicufft_pencil_opt1.cpp:269-273 and :315-319 spelled out for C4 (1024^3, 2x4, R2C)."""
+    pl = orc.PencilPlan(1024, 1024, 1024, 2, 4, False)
+    assert [pl.out_block(r)[0][2] for r in range(4)] == [129, 128, 128, 128]  # 513 split
+    sc, sd, rc, rd = pl.exchange_tables(5, 1)      # rank (1,1)
+    assert sc == [129 * 256 * 512, 128 * 256 * 512, 128 * 256 * 512, 128 * 256 * 512]
+    assert sd == [0, 129 * 256 * 512, 257 * 256 * 512, 385 * 256 * 512]
+    assert rc == [512 * 256 * 128] * 4 and rd == [512 * 256 * p * 128 for p in range(4)]
+    sc, sd, rc, rd = pl.exchange_tables(5, 2)
+    assert sc == [512 * 128 * 512] * 2 and sd == [0, 512 * 128 * 512]
+    assert rc == [512 * 512 * 128] * 2 and rd == [0, 512 * 512 * 128]
+
+
+def test_fill_is_decomposition_independent():
+    g = orc.fill_block((6, 5, 4), (0, 0, 0), (6, 5, 4), 1, seed=9)
+    b = orc.fill_block((6, 5, 4), (2, 1, 0), (3, 2, 4), 1, seed=9)
+    assert np.array_equal(b, g[2:5, 1:3, :])
+    assert g.min() >= 0 and g.max() < 255
+
+
+def test_golden_fixtures():
+    """Committed fixtures (tests/golden/make_golden.py): numpy.fft outputs of seeded grids."""
+    d = np.load(os.path.join(GOLD, "fft3d_small.npz"))
+    for key in ("c2c_8x8x8", "c2c_12x10x14"):
+        shape = tuple(int(v) for v in key.split("_")[1].split("x"))
+        g = orc.fill_block(shape, (0, 0, 0), shape, 2, seed=int(d["seed"]))
+        assert rel_linf(orc.fft3d_c2c(g, -1), d[key]) < 1e-13
+    for key in ("r2c_8x8x8", "r2c_12x10x14"):
+        shape = tuple(int(v) for v in key.split("_")[1].split("x"))
+        g = orc.fill_block(shape, (0, 0, 0), shape, 1, seed=int(d["seed"]))
+        assert rel_linf(orc.fft3d_r2c(g), d[key]) < 1e-13
