@@ -1,0 +1,274 @@
+"""Host-side mirror of the reference's plan/execute interface for the hot path.
+
+Same names, argument meaning and error behaviour as the reference's C++ classes
+(paths relative to the reference repository):
+
+    GlobalSize, Partition, Slab_Partition, Pencil_Partition, Configurations
+                                                         include/params.hpp:24-93
+    MPIcuFFT<T> (abstract)                               include/mpicufft.hpp:55-105
+    MPIcuFFT_Slab / MPIcuFFT_Slab_Opt1                   include/mpicufft_slab.hpp, _slab_opt1.hpp
+    MPIcuFFT_Pencil / MPIcuFFT_Pencil_Opt1               include/mpicufft_pencil.hpp, _pencil_opt1.hpp
+
+Everything here is plumbing over the C ABI (include/dfft_c.h): device pointers in, device
+pointers out.  torch is used only to own device memory and for torch.distributed.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+from . import _lib
+from ._lib import Config, DfftError, check, lib
+
+# include/params.hpp:83-84
+Peer2Peer, All2All = 0, 1
+Sync, Streams, MPI_Type = 0, 1, 2
+FORWARD, INVERSE = -1, 1
+
+
+class GlobalSize:
+    """include/params.hpp:24-37"""
+
+    def __init__(self, Nx, Ny, Nz):
+        self.Nx, self.Ny, self.Nz = int(Nx), int(Ny), int(Nz)
+        self.Nz_out = self.Nz // 2 + 1
+
+
+class Partition:
+    """include/params.hpp:39-42"""
+
+    def __init__(self, P1=1, P2=1):
+        self.P1, self.P2 = int(P1), int(P2)
+
+
+class Slab_Partition(Partition):
+    """include/params.hpp:44-49"""
+
+    def __init__(self, P1):
+        super().__init__(P1, 1)
+
+
+class Pencil_Partition(Partition):
+    """include/params.hpp:51-56"""
+
+    def __init__(self, P1, P2):
+        super().__init__(P1, P2)
+
+
+@dataclass
+class Configurations:
+    """include/params.hpp:85-93"""
+    cuda_aware: bool = True
+    warmup_rounds: int = 0
+    comm_method: int = All2All
+    send_method: int = Sync
+    benchmark_dir: str = "../benchmarks"
+    comm_method2: int = All2All
+    send_method2: int = Sync
+
+    def _c(self):
+        return Config(int(self.cuda_aware), self.warmup_rounds, self.comm_method, self.send_method,
+                      self.comm_method2, self.send_method2)
+
+
+def _ptr(x):
+    """device pointer of a torch tensor / int / None"""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    raise TypeError(f"expected a device tensor or an integer address, got {type(x)}")
+
+
+class Comm:
+    """Communicator handed to the plans in place of MPI_Comm (src/mpicufft.cpp:42-51)."""
+
+    def __init__(self, handle, nranks, rank=None, keep=None):
+        self._h, self.nranks, self.rank, self._keep = handle, nranks, rank, keep
+
+    @classmethod
+    def local(cls, nranks):
+        """nranks virtual ranks in this process on the current device (one host thread each)."""
+        h = C.c_void_p()
+        check(lib().dfft_comm_create_local(nranks, C.byref(h)))
+        return cls(h, nranks)
+
+    @classmethod
+    def rccl(cls, unique_id, nranks, rank):
+        """one process per GPU over RCCL/xGMI; unique_id = bytes from rccl_unique_id() of rank 0"""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        h = C.c_void_p()
+        check(lib().dfft_comm_create_rccl(buf, nranks, rank, C.byref(h)))
+        return cls(h, nranks, rank)
+
+    @classmethod
+    def callback(cls, nranks, rank, fn):
+        """fn(send_ptr, scounts, sdispls, recv_ptr, rcounts, rdispls, group, me, stream) -> None"""
+
+        def tramp(user, send, sc, sd, recv, rc, rd, group, ng, me, stream):
+            try:
+                fn(send, [sc[i] for i in range(ng)], [sd[i] for i in range(ng)], recv,
+                   [rc[i] for i in range(ng)], [rd[i] for i in range(ng)], [group[i] for i in range(ng)], me,
+                   stream)
+                return 0
+            except Exception:  # surfaced as a library error with the traceback printed
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        cfn = _lib.ALLTOALLV_FN(tramp)
+        h = C.c_void_p()
+        check(lib().dfft_comm_create_callback(nranks, rank, cfn, None, C.byref(h)))
+        return cls(h, nranks, rank, keep=cfn)
+
+    @staticmethod
+    def rccl_unique_id():
+        buf = C.create_string_buffer(128)
+        check(lib().dfft_rccl_unique_id(buf))
+        return buf.raw
+
+    def destroy(self):
+        if self._h:
+            lib().dfft_comm_destroy(self._h)
+            self._h = None
+
+
+class MPIcuFFT:
+    """include/mpicufft.hpp:55-105.  precision: 'double' | 'float' (the template argument T)."""
+    _kind = 3
+
+    def __init__(self, config=None, comm=None, max_world_size=-1, precision="double", rank=0):
+        self.config = config or Configurations()
+        self.comm = comm
+        self.precision = {"double": 1, "float": 0, "f64": 1, "f32": 0}[precision]
+        cfg = self.config._c()
+        self._h = C.c_void_p()
+        check(lib().dfft_plan_create(C.byref(self._h), self._kind, self.precision, C.byref(cfg),
+                                     comm._h if comm else None,
+                                     rank if (comm is None or comm.rank is None) else comm.rank, max_world_size))
+        self.c2c = False
+        self._work = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                lib().dfft_plan_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # -- plan ---------------------------------------------------------------------------
+    def initFFT(self, global_size, partition=None, allocate=True, c2c=False):
+        """initFFT(GlobalSize*, Partition*, bool allocate).  c2c=True plans a complex
+        transform (Nz_out = Nz) for execC2C instead of R2C/C2R."""
+        if global_size is None:
+            raise DfftError("GlobalSize or Partition not initialized!")
+        if partition is None:
+            partition = Partition(lib().dfft_world_size(self._h), 1)
+        self.global_size, self.partition, self.c2c = global_size, partition, bool(c2c)
+        check(lib().dfft_init(self._h, global_size.Nx, global_size.Ny, global_size.Nz, partition.P1,
+                              partition.P2, int(c2c), int(allocate)))
+
+    def setWorkArea(self, device=None, host=None):
+        self._work = device
+        check(lib().dfft_set_work_area(self._h, _ptr(device), _ptr(host)))
+
+    def setStream(self, stream):
+        """HIP stream (int handle, e.g. torch.cuda.current_stream().cuda_stream)"""
+        check(lib().dfft_set_stream(self._h, C.c_void_p(int(stream))))
+
+    # -- execute ------------------------------------------------------------------------
+    def execR2C(self, out, in_):
+        check(lib().dfft_exec_r2c(self._h, _ptr(out), _ptr(in_)))
+
+    def execC2R(self, out, in_):
+        check(lib().dfft_exec_c2r(self._h, _ptr(out), _ptr(in_)))
+
+    def execC2C(self, out, in_, direction=FORWARD, sync=True):
+        f = lib().dfft_exec_c2c if sync else lib().dfft_enqueue_c2c
+        check(f(self._h, _ptr(out), _ptr(in_), direction))
+
+    # -- getters ------------------------------------------------------------------------
+    def _get3(self, fn):
+        a = (C.c_size_t * 3)()
+        check(fn(self._h, a))
+        return tuple(a)
+
+    def getInSize(self):
+        return self._get3(lib().dfft_get_in_size)
+
+    def getInStart(self):
+        return self._get3(lib().dfft_get_in_start)
+
+    def getOutSize(self):
+        return self._get3(lib().dfft_get_out_size)
+
+    def getOutStart(self):
+        return self._get3(lib().dfft_get_out_start)
+
+    def getDomainSize(self):
+        return lib().dfft_domain_size(self._h)
+
+    def getWorkSizeDevice(self):
+        return lib().dfft_work_size_device(self._h)
+
+    def getWorkSizeHost(self):
+        return lib().dfft_work_size_host(self._h)
+
+    def getWorkAreaDevice(self):
+        return lib().dfft_work_area_device(self._h)
+
+    def getRank(self):
+        return lib().dfft_rank(self._h)
+
+    def getWorldSize(self):
+        return lib().dfft_world_size(self._h)
+
+    def getExchangeTables(self, which):
+        n = self.partition.P2 if which == 1 else self.partition.P1
+        arrs = [(C.c_size_t * n)() for _ in range(4)]
+        check(lib().dfft_get_exchange_tables(self._h, which, *arrs))
+        return [list(a) for a in arrs]
+
+    def getTileLines(self):
+        return lib().dfft_tile_lines(self._h)
+
+    def enablePhaseTiming(self, on=True):
+        check(lib().dfft_enable_phase_timing(self._h, int(on)))
+
+    def getPhaseTimes(self, direction=FORWARD):
+        ms = (C.c_float * 8)()
+        n = lib().dfft_get_phase_times(self._h, ms, 8)
+        return [(lib().dfft_phase_name(i, direction).decode(), ms[i]) for i in range(n)]
+
+
+class MPIcuFFT_Slab(MPIcuFFT):
+    _kind = 0
+
+
+class MPIcuFFT_Slab_Opt1(MPIcuFFT):
+    _kind = 1
+
+
+class MPIcuFFT_Pencil(MPIcuFFT):
+    _kind = 2
+
+
+class MPIcuFFT_Pencil_Opt1(MPIcuFFT):
+    _kind = 3
+
+
+def fft1d_batched(out, in_, N, batch, direction=FORWARD, precision="double", stream=0):
+    """one axis pass on natural lines [batch][N] (kernel-level entry point)"""
+    prec = {"double": 1, "float": 0}[precision]
+    check(lib().dfft_fft1d_batched(prec, N, batch, _ptr(out), _ptr(in_), direction, C.c_void_p(int(stream))))
+
+
+def kernel_info(N, precision="double"):
+    prec = {"double": 1, "float": 0}[precision]
+    vals = [C.c_int() for _ in range(4)]
+    rc = lib().dfft_kernel_info(prec, N, *[C.byref(v) for v in vals])
+    if rc != 0:
+        return None
+    return dict(zip(("threads", "lds_bytes", "points_per_thread", "lines_per_workgroup"), (v.value for v in vals)))

@@ -1,0 +1,242 @@
+// comm.hip -- the three exchange transports (see comm.hpp).
+#include "comm.hpp"
+#include "dfft_internal.hpp"
+#include "../../include/dfft_c.h"
+
+#include <dlfcn.h>
+#include <string.h>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace dfft {
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+            return (int)e_;                                                                    \
+        }                                                                                      \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// LocalWorld: P virtual ranks in one process on one device, one host thread per rank.
+// The all-to-all is "pull": every rank publishes its send buffer + an event recorded after
+// its producer kernel, ranks meet in a host barrier, then each rank enqueues one D2D copy per
+// peer on its own stream.  Stands in for MPI ranks sharing a GPU
+// (tests/src/pencil/random_dist_3D.cu:175-177, cudaSetDevice(rank % dev_count)).
+// ------------------------------------------------------------------------------------------
+struct LocalWorld : dfft_comm {
+    struct Slot {
+        const char *send = nullptr;
+        const size_t *sdispl = nullptr;
+        const int *group = nullptr;
+        int ngroup = 0;
+        hipEvent_t ready = nullptr, done = nullptr;
+    };
+    std::vector<Slot> slots;
+    std::mutex mu;
+    std::condition_variable cv;
+    int waiting = 0;
+    unsigned long generation = 0;
+
+    explicit LocalWorld(int n) : slots(n) { nranks = n; }
+    ~LocalWorld() override
+    {
+        for (auto &s : slots) {
+            if (s.ready) (void)hipEventDestroy(s.ready);
+            if (s.done) (void)hipEventDestroy(s.done);
+        }
+    }
+    void barrier(int) override
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        unsigned long gen = generation;
+        if (++waiting == nranks) {
+            waiting = 0;
+            generation++;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return generation != gen; });
+        }
+    }
+    int alltoallv(int myrank, const void *send, const size_t *scount, const size_t *sdispl, void *recv,
+                  const size_t *rcount, const size_t *rdispl, const int *group, int ngroup, int me,
+                  hipStream_t stream) override
+    {
+        (void)scount;
+        Slot &mine = slots[myrank];
+        if (!mine.ready) {
+            HIP_TRY(hipEventCreateWithFlags(&mine.ready, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&mine.done, hipEventDisableTiming));
+        }
+        mine.send = static_cast<const char *>(send);
+        mine.sdispl = sdispl;
+        mine.group = group;
+        mine.ngroup = ngroup;
+        HIP_TRY(hipEventRecord(mine.ready, stream));
+        barrier(myrank);   // everyone has published
+        for (int q = 0; q < ngroup; q++) {
+            const Slot &peer = slots[group[q]];
+            if (group[q] != myrank) HIP_TRY(hipStreamWaitEvent(stream, peer.ready, 0));
+            if (rcount[q])
+                HIP_TRY(hipMemcpyAsync(static_cast<char *>(recv) + rdispl[q], peer.send + peer.sdispl[me],
+                                       rcount[q], hipMemcpyDeviceToDevice, stream));
+        }
+        HIP_TRY(hipEventRecord(mine.done, stream));
+        barrier(myrank);   // everyone has enqueued its pulls
+        // my send buffer may be overwritten by my next kernel only after all peers pulled it
+        for (int q = 0; q < ngroup; q++)
+            if (group[q] != myrank) HIP_TRY(hipStreamWaitEvent(stream, slots[group[q]].done, 0));
+        return 0;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// RCCL over xGMI: one process per GPU.  librccl is dlopen'ed so that the library loads (and
+// every CPU-side test runs) on hosts without it.  One grouped ncclSend/ncclRecv batch per
+// exchange on the plan's stream = the reference's All2All-Sync mode with cuda_aware = true.
+// ------------------------------------------------------------------------------------------
+struct Id128 { char b[128]; };
+struct RcclApi {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, /*ncclUniqueId by value: 128 bytes*/ Id128, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+static RcclApi *rccl()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char *n : names) {
+            api.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (api.h) break;
+        }
+        if (!api.h) return;
+        api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.h, "ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.h, "ncclCommInitRank");
+        api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.h, "ncclCommDestroy");
+        api.Send = (decltype(api.Send))dlsym(api.h, "ncclSend");
+        api.Recv = (decltype(api.Recv))dlsym(api.h, "ncclRecv");
+        api.GroupStart = (decltype(api.GroupStart))dlsym(api.h, "ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.h, "ncclGroupEnd");
+        api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.h, "ncclGetErrorString");
+    });
+    if (!api.h || !api.GetUniqueId || !api.CommInitRank || !api.Send || !api.Recv || !api.GroupStart ||
+        !api.GroupEnd)
+        return nullptr;
+    return &api;
+}
+
+#define NCCL_TRY(expr)                                                                         \
+    do {                                                                                       \
+        int r_ = (expr);                                                                       \
+        if (r_ != 0) {                                                                         \
+            set_error(std::string(#expr) + ": " + (R->GetErrorString ? R->GetErrorString(r_) : "rccl error")); \
+            return 1000 + r_;                                                                  \
+        }                                                                                      \
+    } while (0)
+
+struct RcclComm : dfft_comm {
+    void *comm = nullptr;
+    int rank = 0;
+    int fixed_rank() const override { return rank; }
+    ~RcclComm() override
+    {
+        RcclApi *R = rccl();
+        if (R && comm && R->CommDestroy) R->CommDestroy(comm);
+    }
+    int alltoallv(int myrank, const void *send, const size_t *scount, const size_t *sdispl, void *recv,
+                  const size_t *rcount, const size_t *rdispl, const int *group, int ngroup, int me,
+                  hipStream_t stream) override
+    {
+        RcclApi *R = rccl();
+        if (!R) { set_error("librccl not available"); return 1; }
+        const char *s = static_cast<const char *>(send);
+        char *r = static_cast<char *>(recv);
+        // self block: plain device copy, never goes through RCCL
+        // (the reference skips self in its send tables, src/pencil/mpicufft_pencil.cpp:282-289)
+        if (rcount[me])
+            HIP_TRY(hipMemcpyAsync(r + rdispl[me], s + sdispl[me], rcount[me], hipMemcpyDeviceToDevice, stream));
+        NCCL_TRY(R->GroupStart());
+        for (int i = 1; i < ngroup; i++) {
+            // ring order (me+i)%P like the reference's comm_order (mpicufft_pencil_opt1.cpp:107-113)
+            const int to = (me + i) % ngroup, from = (me - i + ngroup) % ngroup;
+            if (scount[to]) NCCL_TRY(R->Send(s + sdispl[to], scount[to], /*ncclInt8*/ 0, group[to], comm, stream));
+            if (rcount[from]) NCCL_TRY(R->Recv(r + rdispl[from], rcount[from], 0, group[from], comm, stream));
+        }
+        NCCL_TRY(R->GroupEnd());
+        (void)myrank;
+        return 0;
+    }
+};
+
+int rccl_unique_id(void *id128)
+{
+    RcclApi *R = rccl();
+    if (!R) { set_error("librccl not available"); return 1; }
+    NCCL_TRY(R->GetUniqueId(id128));
+    return 0;
+}
+
+dfft_comm *make_rccl_comm(const void *id128, int nranks, int rank)
+{
+    RcclApi *R = rccl();
+    if (!R) { set_error("librccl not available"); return nullptr; }
+    RcclComm *c = new RcclComm;
+    c->nranks = nranks;
+    c->rank = rank;
+    Id128 id;
+    memcpy(id.b, id128, 128);
+    int r = R->CommInitRank(&c->comm, nranks, id, rank);
+    if (r != 0) {
+        set_error(std::string("ncclCommInitRank: ") + (R->GetErrorString ? R->GetErrorString(r) : "error"));
+        c->comm = nullptr;
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------
+// Callback transport: the caller owns the exchange (torch.distributed.all_to_all_single over
+// RCCL in bench.py, gloo in the CPU tests, MPI_Alltoallv in an MPI host).
+// ------------------------------------------------------------------------------------------
+struct CallbackComm : dfft_comm {
+    dfft_alltoallv_fn fn = nullptr;
+    void *user = nullptr;
+    int rank = 0;
+    int fixed_rank() const override { return rank; }
+    int alltoallv(int myrank, const void *send, const size_t *scount, const size_t *sdispl, void *recv,
+                  const size_t *rcount, const size_t *rdispl, const int *group, int ngroup, int me,
+                  hipStream_t stream) override
+    {
+        (void)myrank;
+        int r = fn(user, send, scount, sdispl, recv, rcount, rdispl, group, ngroup, me, (void *)stream);
+        if (r != 0) set_error("all-to-all callback failed with code " + std::to_string(r));
+        return r;
+    }
+};
+
+dfft_comm *make_local_world(int nranks) { return new LocalWorld(nranks); }
+dfft_comm *make_callback_comm(int nranks, int rank, void *fn, void *user)
+{
+    CallbackComm *c = new CallbackComm;
+    c->nranks = nranks;
+    c->rank = rank;
+    c->fn = (dfft_alltoallv_fn)fn;
+    c->user = user;
+    return c;
+}
+
+}  // namespace dfft

@@ -1,0 +1,30 @@
+// comm.hpp -- exchange transports behind dfft_comm.
+//
+// Replaces the reference's MPI layer for the hot path: MPI_Comm_split into row/column
+// communicators (src/pencil/mpicufft_pencil_opt1.cpp:103-104) and MPI_Alltoallv on device
+// pointers (:784-785, :1297-1298).  A transport only has to provide an all-to-all-v among an
+// explicit list of ranks on a HIP stream; sub-communicators are expressed as rank lists of
+// the parent, so no split is needed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+struct dfft_comm {
+    int nranks = 1;
+    virtual ~dfft_comm() {}
+    // rank of the caller if the transport knows it (RCCL, callback), -1 for a local world
+    virtual int fixed_rank() const { return -1; }
+    // counts/displacements in bytes; group = global ranks, me = my index in group
+    virtual int alltoallv(int myrank, const void *send, const size_t *scount, const size_t *sdispl,
+                          void *recv, const size_t *rcount, const size_t *rdispl, const int *group,
+                          int ngroup, int me, hipStream_t stream) = 0;
+    // host-side rendezvous of all ranks (used around timing); no-op by default
+    virtual void barrier(int /*myrank*/) {}
+};
+
+namespace dfft {
+dfft_comm *make_local_world(int nranks);
+dfft_comm *make_rccl_comm(const void *id128, int nranks, int rank);
+dfft_comm *make_callback_comm(int nranks, int rank, void *fn, void *user);
+int rccl_unique_id(void *id128);
+}  // namespace dfft

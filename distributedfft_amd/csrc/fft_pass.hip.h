@@ -1,0 +1,385 @@
+// fft_pass.hip.h -- the one hot kernel of the library: a batched 1-D complex FFT "axis pass"
+// for gfx950 (MI355X / CDNA4) with the layout change of the distributed algorithm fused into
+// its load and store sides.
+//
+// Replaces, per axis pass, one cuFFT plan of the reference plus the cudaMemcpy2D/3D pack or
+// unpack next to it:
+//   cufftMakePlanMany64 z/y/x plans  src/pencil/mpicufft_pencil_opt1.cpp:165-197
+//   unpack after exchange 1 / 2      src/pencil/mpicufft_pencil_opt1.cpp:788-800, 1301-1312
+//   pack before inverse exchanges    src/pencil/mpicufft_pencil_opt1.cpp:813-824, 1325-1336
+//
+// Design (see DESIGN.md for the full story):
+//  * One workgroup transforms TW = TL*G lines of length N.  A line is owned by N/E threads,
+//    each holding E complex points in VGPRs.  The transform is a Stockham autosort chain of
+//    up to four radix-R passes (R <= E, all powers of two); butterflies run entirely in
+//    registers, data moves between passes through LDS (re/im planes, 8-/4-byte accesses).
+//  * Thread <-> data mapping is "line fastest": lane = line + TW * t.  Every global access
+//    of a wave then covers TL adjacent lines x 8 adjacent points, which is what makes the
+//    line-interleaved intermediate layouts below coalesce.
+//  * Intermediate (send/recv) buffers use a tiled layout [a][tile][n][l]: TL lines that are
+//    adjacent along the *next* pass's line-set axis are interleaved point by point, so the
+//    consumer reads one fully contiguous chunk per workgroup and the producer writes
+//    TL x TL (1 KiB) or TL (128 B) contiguous runs.  Per-peer blocks stay contiguous and have
+//    exactly the reference's all-to-all byte counts/displacements
+//    (mpicufft_pencil_opt1.cpp:269-273, 315-319) -- only the order inside a block differs.
+//  * The inverse transform reuses the forward butterflies via the re<->im swap identity.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+namespace dfft {
+
+constexpr int MAXSEG = 16;   // max peers in one exchange group
+
+enum LoadKind : int {
+    LOAD_LINES = 0,    // natural lines:        (a*LB + b*TL + l)*N + n
+    LOAD_TILED = 1,    // tiled, segmented by source peer: base[s] + a*len[s]*LB + b*TL*len[s] + (n-start[s])*tw + l
+    LOAD_KMAJOR = 2    // point-major:          n*KS + a*LB + b*TL + l
+};
+enum StoreKind : int {
+    STORE_LINES = 0,           // (a*LB + b*TL + l)*N + k
+    STORE_KMAJOR = 1,          // k*KS + a*LB + b*TL + l
+    STORE_TILED_SAME = 2,      // base[p] + (k-start[p])*LB*LA + b*TL*LA + a*tw + l
+    STORE_TILED_TRANSPOSE = 3  // base[p] + a*len[p]*LB + kt*T2*LB + (b*TL+l)*tw2 + kr
+};
+
+struct SegTable {
+    int32_t nseg;
+    uint32_t start[MAXSEG];   // first point index of the segment
+    uint32_t len[MAXSEG];     // points in the segment
+    uint64_t base[MAXSEG];    // element offset of the peer block in the buffer
+};
+
+struct PassArgs {
+    const void *in;
+    void *out;
+    const void *tw;        // twiddle table, N complex entries exp(-2*pi*i*j/N)
+    uint32_t na;           // extent of the outer line-set axis
+    uint32_t LB;           // extent of the inner (tiled) line-set axis
+    uint32_t nb;           // tiles along LB = ceil(LB / TL)
+    uint32_t ntiles;       // na * nb
+    int32_t load_kind, store_kind;
+    int32_t swap;          // 1 = inverse transform (swap re/im on load and on store)
+    uint32_t LA;           // STORE_TILED_SAME: extent of the a axis
+    uint32_t T2shift;      // STORE_TILED_TRANSPOSE: log2 of the consumer's tile size
+    uint64_t KS_in;        // LOAD_KMAJOR point stride
+    uint64_t KS_out;       // STORE_KMAJOR point stride
+    SegTable lseg, sseg;
+};
+
+// ------------------------------------------------------------------------------------------
+template <typename R> struct Vec2;
+template <> struct Vec2<double> { using type = double2; };
+template <> struct Vec2<float> { using type = float2; };
+
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
+constexpr int brev(int m, int R)
+{
+    int r = 0;
+    for (int b = 1; b < R; b <<= 1) { r = (r << 1) | (m & 1); m >>= 1; }
+    return r;
+}
+
+// cos/sin(2*pi*j/32), j = 0..8 (one octant + 1); everything else by symmetry
+__device__ constexpr double kCos32[9] = {1.0,
+                                         0.98078528040323044913,
+                                         0.92387953251128675613,
+                                         0.83146961230254523708,
+                                         0.70710678118654752440,
+                                         0.55557023301960222474,
+                                         0.38268343236508977173,
+                                         0.19509032201612826785,
+                                         0.0};
+constexpr double cos32(int j)
+{
+    // j in [0, 32)
+    j &= 31;
+    if (j > 16) j = 32 - j;           // cos even about 16
+    if (j > 8) return -kCos32[16 - j];
+    return kCos32[j];
+}
+constexpr double sin32(int j) { return cos32((j + 24) & 31); }   // sin(x) = cos(x - pi/2)
+
+// multiply by exp(-2*pi*i*J/R) (forward kernel), compile-time J, trivial cases folded
+template <int R, int J, typename C> __device__ __forceinline__ C mul_w(C d)
+{
+    using T = decltype(d.x);
+    constexpr int j32 = (J * (32 / R)) & 31;
+    if constexpr (j32 == 0) return d;
+    else if constexpr (j32 == 8) { C r; r.x = d.y; r.y = -d.x; return r; }           // * -i
+    else if constexpr (j32 == 16) { C r; r.x = -d.x; r.y = -d.y; return r; }
+    else if constexpr (j32 == 24) { C r; r.x = -d.y; r.y = d.x; return r; }          // * +i
+    else if constexpr (j32 == 4) { constexpr T s = (T)0.70710678118654752440; C r; r.x = (d.x + d.y) * s; r.y = (d.y - d.x) * s; return r; }
+    else if constexpr (j32 == 12) { constexpr T s = (T)0.70710678118654752440; C r; r.x = (d.y - d.x) * s; r.y = -(d.x + d.y) * s; return r; }
+    else {
+        constexpr T c = (T)cos32(j32), s = (T)sin32(j32);   // w = c - i s
+        C r;
+        r.x = d.x * c + d.y * s;
+        r.y = d.y * c - d.x * s;
+        return r;
+    }
+}
+
+// radix-R decimation-in-frequency FFT on registers v[OFF + m*STRIDE], m = 0..R-1.
+// On return slot m holds X[brev(m, R)].
+template <int R, int OFF, int STRIDE, typename C> struct Dif {
+    static __device__ __forceinline__ void run(C *v)
+    {
+        if constexpr (R >= 2) {
+            constexpr int H = R / 2;
+            static_for<0, H>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                C a = v[OFF + j * STRIDE], b = v[OFF + (j + H) * STRIDE];
+                C s, d;
+                s.x = a.x + b.x; s.y = a.y + b.y;
+                d.x = a.x - b.x; d.y = a.y - b.y;
+                v[OFF + j * STRIDE] = s;
+                v[OFF + (j + H) * STRIDE] = mul_w<R, j>(d);
+            });
+            Dif<H, OFF, STRIDE, C>::run(v);
+            Dif<H, OFF + H * STRIDE, STRIDE, C>::run(v);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+template <typename R, int N, int E, int TL, int G, int R1, int R2, int R3, int R4, int PLANES>
+struct PassCfg {
+    using real = R;
+    using C = typename Vec2<R>::type;
+    static constexpr int kN = N, kE = E, kTL = TL, kG = G;
+    static constexpr int r1 = R1, r2 = R2, r3 = R3, r4 = R4, kPLANES = PLANES;
+    static constexpr int RLAST = R4 > 1 ? R4 : (R3 > 1 ? R3 : (R2 > 1 ? R2 : R1));
+    static constexpr int NT = N / E;                 // threads per line
+    static constexpr int TW = TL * G;                // lines per workgroup
+    static constexpr int THREADS = NT * TW;
+    static constexpr int NPASS = (R1 > 1) + (R2 > 1) + (R3 > 1) + (R4 > 1);
+    static constexpr int PS = ilog2(R1 * TW);        // pad once per first-pass scatter stride ...
+    static constexpr int PWS = ilog2(TW) > 4 ? 4 : ilog2(TW);   // ... by min(TW,16) slots
+    static constexpr int SLOTS = N * TW;
+    static constexpr int PLANE_SLOTS = SLOTS + ((SLOTS >> PS) << PWS);
+    static constexpr size_t LDS_BYTES = NPASS > 1 ? (size_t)PLANES * PLANE_SLOTS * sizeof(R) : 0;
+    static_assert((R1 > 1 ? R1 : 1) * (R2 > 1 ? R2 : 1) * (R3 > 1 ? R3 : 1) * (R4 > 1 ? R4 : 1) == N, "radices must multiply to N");
+    static_assert(E % R1 == 0 && (R2 <= 1 || E % R2 == 0) && (R3 <= 1 || E % R3 == 0) && (R4 <= 1 || E % R4 == 0), "radix must divide E");
+    static_assert(THREADS <= 1024, "workgroup too large");
+};
+
+template <typename Cfg> __device__ __forceinline__ int lds_pad(int idx)
+{
+    return idx + ((idx >> Cfg::PS) << Cfg::PWS);
+}
+
+// twiddle + butterflies of one Stockham pass: radix RP, previous sub-transform length NS
+template <typename Cfg, int RP, int NS>
+__device__ __forceinline__ void pass_compute(typename Cfg::C *v, int t, const typename Cfg::C *__restrict__ W)
+{
+    using C = typename Cfg::C;
+    constexpr int S = Cfg::kE / RP;     // butterflies per thread == register stride
+    constexpr int N = Cfg::kN;
+    static_for<0, S>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (NS > 1) {
+            const int j = t + Cfg::NT * i;
+            const int k = j & (NS - 1);
+            constexpr int step = N / (NS * RP);
+            static_for<1, RP>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                const C w = W[(m * k) * step];
+                C x = v[i + m * S], r;
+                r.x = x.x * w.x - x.y * w.y;
+                r.y = x.x * w.y + x.y * w.x;
+                v[i + m * S] = r;
+            });
+        }
+        Dif<RP, i, S, C>::run(v);
+    });
+}
+
+// scatter the outputs of pass (RP, NS) to LDS plane, Stockham output index
+template <typename Cfg, int RP, int NS, int COMP>
+__device__ __forceinline__ void lds_scatter(const typename Cfg::C *v, typename Cfg::real *plane, int t, int lw)
+{
+    constexpr int S = Cfg::kE / RP;
+    static_for<0, S>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int j = t + Cfg::NT * i;
+        const int k = j & (NS - 1);
+        const int nbase = (j - k) * RP + k;       // (j/NS)*NS*RP + k
+        static_for<0, RP>([&](auto mc) {
+            constexpr int mr = decltype(mc)::value;          // register slot
+            constexpr int m = brev(mr, RP);                  // output index of that slot
+            const int idx = lds_pad<Cfg>((nbase + m * NS) * Cfg::TW + lw);
+            plane[idx] = COMP == 0 ? v[i + mr * S].x : v[i + mr * S].y;
+        });
+    });
+}
+template <typename Cfg, int COMP>
+__device__ __forceinline__ void lds_gather(typename Cfg::C *v, const typename Cfg::real *plane, int tid)
+{
+    static_for<0, Cfg::kE>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        const int idx = lds_pad<Cfg>(tid + Cfg::NT * Cfg::TW * c);   // (t + NT*c)*TW + lw
+        if (COMP == 0) v[c].x = plane[idx]; else v[c].y = plane[idx];
+    });
+}
+
+template <typename Cfg, int RP, int NS>
+__device__ __forceinline__ void exchange(typename Cfg::C *v, typename Cfg::real *lds, int t, int lw, int tid, bool first)
+{
+    using R = typename Cfg::real;
+    if constexpr (Cfg::kPLANES == 2) {
+        R *p0 = lds, *p1 = lds + Cfg::PLANE_SLOTS;
+        if (!first) __syncthreads();
+        lds_scatter<Cfg, RP, NS, 0>(v, p0, t, lw);
+        lds_scatter<Cfg, RP, NS, 1>(v, p1, t, lw);
+        __syncthreads();
+        lds_gather<Cfg, 0>(v, p0, tid);
+        lds_gather<Cfg, 1>(v, p1, tid);
+    } else {
+        if (!first) __syncthreads();
+        lds_scatter<Cfg, RP, NS, 0>(v, lds, t, lw);     // old re -> LDS
+        __syncthreads();
+        lds_gather<Cfg, 0>(v, lds, tid);                // new re (old im still live in v[].y)
+        __syncthreads();
+        lds_scatter<Cfg, RP, NS, 1>(v, lds, t, lw);
+        __syncthreads();
+        lds_gather<Cfg, 1>(v, lds, tid);
+    }
+}
+
+// the whole Stockham chain on the registers of one thread
+template <typename Cfg>
+__device__ __forceinline__ void transform(typename Cfg::C *v, typename Cfg::real *lds,
+                                          const typename Cfg::C *__restrict__ W, int t, int lw, int tid)
+{
+    constexpr int R1 = Cfg::r1, R2 = Cfg::r2, R3 = Cfg::r3, R4 = Cfg::r4;
+    pass_compute<Cfg, R1, 1>(v, t, W);
+    if constexpr (R2 > 1) {
+        exchange<Cfg, R1, 1>(v, lds, t, lw, tid, true);
+        pass_compute<Cfg, R2, R1>(v, t, W);
+    }
+    if constexpr (R3 > 1) {
+        exchange<Cfg, R2, R1>(v, lds, t, lw, tid, false);
+        pass_compute<Cfg, R3, R1 * R2>(v, t, W);
+    }
+    if constexpr (R4 > 1) {
+        exchange<Cfg, R3, R1 * R2>(v, lds, t, lw, tid, false);
+        pass_compute<Cfg, R4, R1 * R2 * R3>(v, t, W);
+    }
+}
+
+template <typename Cfg>
+__global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A)
+{
+    using C = typename Cfg::C;
+    using R = typename Cfg::real;
+    constexpr int N = Cfg::kN, E = Cfg::kE, TL = Cfg::kTL, NT = Cfg::NT, TW = Cfg::TW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    R *lds = reinterpret_cast<R *>(smem);
+
+    const int tid = threadIdx.x;
+    const int lw = tid % TW;          // line within the workgroup
+    const int t = tid / TW;           // thread within the line
+    const int g = lw / TL, l = lw % TL;
+
+    const uint32_t w = blockIdx.x * Cfg::kG + g;            // tile index, b fastest
+    const bool tile_ok = w < A.ntiles;
+    const uint32_t a = tile_ok ? w / A.nb : 0, b = tile_ok ? w % A.nb : 0;
+    const uint32_t rem = A.LB - b * TL;
+    const uint32_t tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;   // valid lines of this tile
+    const bool active = tile_ok && (uint32_t)l < tw;
+
+    const C *__restrict__ in = reinterpret_cast<const C *>(A.in);
+    C *__restrict__ out = reinterpret_cast<C *>(A.out);
+    const C *__restrict__ W = reinterpret_cast<const C *>(A.tw);
+
+    C v[E];
+    // ------------------------------------------------------------------ load
+    if (active) {
+        if (A.load_kind == LOAD_LINES) {
+            const C *p = in + ((uint64_t)a * A.LB + (uint64_t)b * TL + l) * N + t;
+            static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = p[NT * c]; });
+        } else if (A.load_kind == LOAD_KMAJOR) {
+            const C *p = in + (uint64_t)a * A.LB + (uint64_t)b * TL + l + (uint64_t)t * A.KS_in;
+            static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = p[(uint64_t)(NT * c) * A.KS_in]; });
+        } else {
+            if (A.lseg.nseg == 1) {
+                const uint64_t len = A.lseg.len[0];
+                const C *p = in + A.lseg.base[0] + (uint64_t)a * len * A.LB + (uint64_t)b * TL * len + l + (uint64_t)t * tw;
+                static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = p[(uint64_t)(NT * c) * tw]; });
+            } else {
+                static_for<0, E>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    const uint32_t n = t + NT * c;
+                    uint32_t s0 = A.lseg.start[0], ln = A.lseg.len[0];
+                    uint64_t bs = A.lseg.base[0];
+                    for (int s = 1; s < A.lseg.nseg; s++)
+                        if (n >= A.lseg.start[s]) { s0 = A.lseg.start[s]; ln = A.lseg.len[s]; bs = A.lseg.base[s]; }
+                    v[c] = in[bs + (uint64_t)a * ln * A.LB + (uint64_t)b * TL * ln + (uint64_t)(n - s0) * tw + l];
+                });
+            }
+        }
+    } else {
+        static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].x = 0; v[c].y = 0; });
+    }
+    if (A.swap) static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; R tmp = v[c].x; v[c].x = v[c].y; v[c].y = tmp; });
+
+    // ------------------------------------------------------------------ passes
+    transform<Cfg>(v, lds, W, t, lw, tid);
+
+    if (A.swap) static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; R tmp = v[c].x; v[c].x = v[c].y; v[c].y = tmp; });
+
+    // ------------------------------------------------------------------ store
+    if (!active) return;
+    constexpr int RL = Cfg::RLAST;     // radix of the last pass
+    constexpr int S = E / RL;
+    // register c = i + mr*S holds output k = t + NT*i + brev(mr)*(N/RL)
+    if (A.store_kind == STORE_LINES) {
+        C *p = out + ((uint64_t)a * A.LB + (uint64_t)b * TL + l) * N + t;
+        static_for<0, E>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
+            p[k0] = v[c];
+        });
+    } else if (A.store_kind == STORE_KMAJOR) {
+        C *p = out + (uint64_t)a * A.LB + (uint64_t)b * TL + l + (uint64_t)t * A.KS_out;
+        static_for<0, E>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
+            p[(uint64_t)k0 * A.KS_out] = v[c];
+        });
+    } else {
+        static_for<0, E>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
+            const uint32_t k = t + k0;
+            uint32_t s0 = A.sseg.start[0], ln = A.sseg.len[0];
+            uint64_t bs = A.sseg.base[0];
+            for (int s = 1; s < A.sseg.nseg; s++)
+                if (k >= A.sseg.start[s]) { s0 = A.sseg.start[s]; ln = A.sseg.len[s]; bs = A.sseg.base[s]; }
+            const uint32_t kl = k - s0;
+            uint64_t off;
+            if (A.store_kind == STORE_TILED_SAME) {
+                off = bs + (uint64_t)kl * A.LB * A.LA + (uint64_t)b * TL * A.LA + (uint64_t)a * tw + l;
+            } else {
+                const uint32_t T2 = 1u << A.T2shift;
+                const uint32_t kt = kl >> A.T2shift, kr = kl & (T2 - 1);
+                const uint32_t r2 = ln - kt * T2;
+                const uint32_t tw2 = r2 < T2 ? r2 : T2;
+                off = bs + (uint64_t)a * ln * A.LB + (uint64_t)kt * T2 * A.LB + ((uint64_t)b * TL + l) * tw2 + kr;
+            }
+            out[off] = v[c];
+        });
+    }
+}
+
+}  // namespace dfft

@@ -1,0 +1,38 @@
+// fp32 instantiations of the axis-pass kernel (TL = 16 lines per tile: 16 x 8 B = 128 B runs)
+#include "kernels.hip.inc"
+
+namespace dfft {
+using F32_2    = PassCfg<float, 2,    2, 16, 16, 2, 1, 1, 1,   1>;
+using F32_4    = PassCfg<float, 4,    4, 16, 16, 4, 1, 1, 1,   1>;
+using F32_8    = PassCfg<float, 8,    8, 16, 16, 8, 1, 1, 1,   1>;
+using F32_16   = PassCfg<float, 16,  16, 16, 16, 16, 1, 1, 1,  1>;
+using F32_32   = PassCfg<float, 32,   8, 16, 4,  8, 4, 1, 1,   2>;
+using F32_64   = PassCfg<float, 64,   8, 16, 2,  8, 8, 1, 1,   2>;
+using F32_128  = PassCfg<float, 128, 16, 16, 2,  16, 8, 1, 1,  2>;
+using F32_256  = PassCfg<float, 256, 16, 16, 1,  16, 16, 1, 1, 2>;
+using F32_512  = PassCfg<float, 512, 16, 16, 1,  8, 8, 8, 1,   2>;
+using F32_1024 = PassCfg<float, 1024, 16, 16, 1, 16, 16, 4, 1, 1>;
+using F32_2048 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1,  1>;
+
+#define DFFT_F32_LIST(X) X(2, F32_2) X(4, F32_4) X(8, F32_8) X(16, F32_16) X(32, F32_32) X(64, F32_64) \
+    X(128, F32_128) X(256, F32_256) X(512, F32_512) X(1024, F32_1024) X(2048, F32_2048)
+
+int launch_pass_f32(int N, const PassArgs &A, hipStream_t stream)
+{
+    switch (N) {
+#define X(n, cfg) case n: return launch_cfg<cfg>(A, stream);
+        DFFT_F32_LIST(X)
+#undef X
+    }
+    return -1;
+}
+bool pass_info_f32(int N, PassInfo *pi)
+{
+    switch (N) {
+#define X(n, cfg) case n: info_cfg<cfg>(pi); return true;
+        DFFT_F32_LIST(X)
+#undef X
+    }
+    return false;
+}
+}  // namespace dfft

@@ -1,0 +1,160 @@
+/*
+ * dfft_c.h -- C ABI of libdfft_amd.so, the MI355X-native replacement for the hot path of
+ * eggersn/DistributedFFT: "plan once, then execR2C / execC2R / (new) execC2C on device buffers".
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference repository).  The boundary is the abstract class
+ *     template<typename T> class MPIcuFFT            include/mpicufft.hpp:55-105
+ * and its concrete decompositions
+ *     MPIcuFFT_Slab / _Slab_Opt1                      include/mpicufft_slab.hpp:99-125
+ *     MPIcuFFT_Pencil / _Pencil_Opt1                  include/mpicufft_pencil.hpp:88-122
+ * Differences by design: plain C, int return codes instead of printf+exit(EXIT_FAILURE)
+ * (src/pencil/mpicufft_pencil_opt1.cpp:27-33), the communicator is an explicit dfft_comm
+ * (RCCL over xGMI, in-process virtual ranks, or a caller-supplied all-to-all) instead of an
+ * MPI_Comm, and complex-to-complex execution is added next to R2C/C2R.
+ *
+ * Memory layout contract (identical to the reference, README.md:247,
+ * include/mpicufft_pencil.hpp:94-122): row-major [x][y][z], z contiguous.
+ *   input  block of rank (i,j): [Nx/P1][Ny/P2][Nz]        (real for R2C, complex for C2C)
+ *   output block of rank (i,j): [Nx][Ny/P1][Nzc/P2]       (complex; Nzc = Nz/2+1 or Nz)
+ * Remainders of uneven divisions go to the lowest ranks.  rank = i*P2 + j.  Slab = P2 == 1.
+ * Transforms are unnormalised, forward kernel exp(-2*pi*i*jk/N) (cuFFT convention).
+ *
+ * All functions return 0 on success; on failure a non-zero code and dfft_last_error() holds
+ * a message (thread local).
+ */
+#ifndef DFFT_C_H
+#define DFFT_C_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dfft_plan dfft_plan;
+typedef struct dfft_comm dfft_comm;
+
+/* which reference class the plan stands in for (all four share one engine: the "realigned"
+ * opt1 data flow with pack/unpack fused into the FFT kernels; the value is kept for callers
+ * that select by name and for the timer/CSV naming) */
+enum dfft_kind {
+    DFFT_SLAB = 0,         /* MPIcuFFT_Slab       include/mpicufft_slab.hpp          */
+    DFFT_SLAB_OPT1 = 1,    /* MPIcuFFT_Slab_Opt1  include/mpicufft_slab_opt1.hpp     */
+    DFFT_PENCIL = 2,       /* MPIcuFFT_Pencil     include/mpicufft_pencil.hpp        */
+    DFFT_PENCIL_OPT1 = 3   /* MPIcuFFT_Pencil_Opt1 include/mpicufft_pencil_opt1.hpp  */
+};
+enum dfft_precision { DFFT_F32 = 0, DFFT_F64 = 1 };   /* template parameter T = float|double */
+enum dfft_direction { DFFT_FORWARD = -1, DFFT_INVERSE = 1 };
+
+/* struct Configurations, include/params.hpp:83-93.  comm/send method enums are accepted and
+ * recorded; the device exchange always runs as one grouped all-to-all per exchange. */
+typedef struct dfft_config {
+    int cuda_aware;        /* kept for source compatibility; device buffers are always used */
+    int warmup_rounds;
+    int comm_method;       /* 0 Peer2Peer, 1 All2All   (params.hpp:83) */
+    int send_method;       /* 0 Sync, 1 Streams, 2 MPI_Type (params.hpp:84) */
+    int comm_method2;
+    int send_method2;
+} dfft_config;
+
+/* ---------------------------------------------------------------- communicators ---------- */
+/* replaces MPI_Comm + MPI_Comm_split (src/mpicufft.cpp:42-51, mpicufft_pencil_opt1.cpp:103-104) */
+
+/* all-to-all-v callback: byte counts/displacements, `group` = global ranks of the members,
+ * `me` = caller's index in group.  Buffers are device pointers; `stream` is the hipStream_t
+ * the plan enqueues on.  Must return 0 on success. */
+typedef int (*dfft_alltoallv_fn)(void *user, const void *sendbuf, const size_t *sendcounts,
+                                 const size_t *sdispls, void *recvbuf, const size_t *recvcounts,
+                                 const size_t *rdispls, const int *group, int ngroup, int me,
+                                 void *stream);
+
+/* nranks virtual ranks inside this process sharing the current device; each rank's exec must be
+ * called from its own host thread (they meet in a barrier like MPI ranks would). */
+int dfft_comm_create_local(int nranks, dfft_comm **world);
+/* one process per GPU over RCCL/xGMI; id = 128-byte ncclUniqueId made on rank 0 by
+ * dfft_rccl_unique_id and broadcast by the caller (MPI_Bcast, torch.distributed, ...) */
+int dfft_rccl_unique_id(void *id128);
+int dfft_comm_create_rccl(const void *id128, int nranks, int rank, dfft_comm **comm);
+/* caller-supplied exchange (e.g. torch.distributed.all_to_all_single, MPI_Alltoallv) */
+int dfft_comm_create_callback(int nranks, int rank, dfft_alltoallv_fn fn, void *user, dfft_comm **comm);
+int dfft_comm_destroy(dfft_comm *comm);
+
+/* ---------------------------------------------------------------- plan -------------------- */
+/* MPIcuFFT<T>::MPIcuFFT(Configurations, MPI_Comm, int max_world_size)   src/mpicufft.cpp:42-66.
+ * comm may be NULL for a single rank.  `rank` selects the virtual rank of a local world and is
+ * ignored (taken from the comm) otherwise.  max_world_size < 0 = all ranks. */
+int dfft_plan_create(dfft_plan **plan, int kind, int precision, const dfft_config *config,
+                     dfft_comm *comm, int rank, int max_world_size);
+/* ~MPIcuFFT  src/mpicufft.cpp:68-73 (frees the work area if the library allocated it) */
+int dfft_plan_destroy(dfft_plan *plan);
+
+/* initFFT(GlobalSize*, Partition*, bool allocate)   include/mpicufft.hpp:60,
+ * src/pencil/mpicufft_pencil_opt1.cpp:46-326, src/slab/default/mpicufft_slab.cpp:97-281.
+ * P1*P2 must equal the number of ranks.  c2c = 0: R2C/C2R plan (Nz_out = Nz/2+1,
+ * include/params.hpp:30); c2c = 1: complex plan (Nz_out = Nz). */
+int dfft_init(dfft_plan *plan, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int c2c, int allocate);
+/* setWorkArea(void *device, void *host)   mpicufft_pencil_opt1.cpp:329-387.  NULL device =
+ * library allocates dfft_work_size_device() bytes. */
+int dfft_set_work_area(dfft_plan *plan, void *device, void *host);
+/* HIP stream all kernels/exchanges are enqueued on (default: a stream owned by the plan) */
+int dfft_set_stream(dfft_plan *plan, void *hip_stream);
+
+/* execR2C(void *out, const void *in)   include/mpicufft.hpp:63; mpicufft_pencil_opt1.cpp:1422-1519.
+ * in: device, real [xs][ys][Nz], not modified.  out: device, >= dfft_domain_size() bytes;
+ * holds [Nx][yo][zs] complex on return.  Blocking (returns after the stream is drained), like
+ * the reference's trailing cudaDeviceSynchronize. */
+int dfft_exec_r2c(dfft_plan *plan, void *out, const void *in);
+/* execC2R(void *out, const void *in)   include/mpicufft_pencil.hpp:106-111; :1522-1600.
+ * `in` is DESTROYED (used as scratch, as in the reference :1534,1544,1563). */
+int dfft_exec_c2r(dfft_plan *plan, void *out, void *in);
+/* new: complex-to-complex, same layouts with Nz_out = Nz.  Forward: in [xs][ys][Nz] -> out
+ * [Nx][yo][zs].  Inverse: in [Nx][yo][zs] (destroyed) -> out [xs][ys][Nz]. */
+int dfft_exec_c2c(dfft_plan *plan, void *out, void *in, int direction);
+/* non-blocking variants: enqueue only (caller synchronises the stream) */
+int dfft_enqueue_c2c(dfft_plan *plan, void *out, void *in, int direction);
+
+/* getInSize/getInStart/getOutSize/getOutStart   include/mpicufft_pencil.hpp:112-122
+ * (getOutStart returns start_z of the z split -- the reference indexes start_x there, a bug) */
+int dfft_get_in_size(const dfft_plan *plan, size_t size[3]);
+int dfft_get_in_start(const dfft_plan *plan, size_t start[3]);
+int dfft_get_out_size(const dfft_plan *plan, size_t size[3]);
+int dfft_get_out_start(const dfft_plan *plan, size_t start[3]);
+/* getDomainSize / getWorkSizeDevice / getWorkSizeHost / getRank / getWorldSize
+ * include/mpicufft.hpp:65-78 */
+size_t dfft_domain_size(const dfft_plan *plan);        /* bytes `out` must hold */
+size_t dfft_work_size_device(const dfft_plan *plan);
+size_t dfft_work_size_host(const dfft_plan *plan);
+void *dfft_work_area_device(const dfft_plan *plan);
+int dfft_rank(const dfft_plan *plan);
+int dfft_world_size(const dfft_plan *plan);
+
+/* exchange tables in BYTES exactly as the reference builds them for MPI_Alltoallv
+ * (mpicufft_pencil_opt1.cpp:269-273 which=1, :315-319 which=2).  Arrays hold P2 resp. P1 entries. */
+int dfft_get_exchange_tables(const dfft_plan *plan, int which, size_t *sendcounts, size_t *sdispls,
+                             size_t *recvcounts, size_t *rdispls);
+/* lines interleaved per tile in the intermediate layouts */
+int dfft_tile_lines(const dfft_plan *plan);
+
+/* per-phase device time of the last exec in milliseconds (Timer sections of the reference,
+ * include/mpicufft_pencil.hpp:263-287): up to 8 entries, names via dfft_phase_name */
+int dfft_get_phase_times(dfft_plan *plan, float *ms, int max_entries);
+const char *dfft_phase_name(int phase, int direction);
+int dfft_enable_phase_timing(dfft_plan *plan, int enable);
+
+/* standalone launch of one batched 1-D axis pass on natural lines (in [batch][N] -> out
+ * [batch][N]); used by the kernel-level parity tests and the micro-benchmarks */
+int dfft_fft1d_batched(int precision, size_t N, size_t batch, void *out, const void *in,
+                       int direction, void *hip_stream);
+
+const char *dfft_last_error(void);
+const char *dfft_version(void);
+/* kernel configuration for line length N: returns 0 if supported and fills the fields */
+int dfft_kernel_info(int precision, size_t N, int *threads, int *lds_bytes, int *points_per_thread,
+                     int *lines_per_workgroup);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFFT_C_H */

@@ -1,0 +1,132 @@
+"""Parity tests proper: HIP path (through the C ABI) vs the CPU oracle on the same seeded
+inputs.  Tolerances: fp64 forward rel L-inf (scaled by max|X|) <= 1e-11, round
+trip <= 1e-10; fp32 forward <= 1e-4 (vs the fp64 oracle), round trip <= 5e-5."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import distributedfft_amd as dfft  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+TOL_FWD = {"double": 1e-11, "float": 1e-4}
+TOL_RT = {"double": 1e-10, "float": 5e-5}
+CDT = {"double": torch.complex128, "float": torch.complex64}
+NPDT = {"double": np.complex128, "float": np.complex64}
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+@pytest.mark.parametrize("prec", ["double", "float"])
+@pytest.mark.parametrize("N", [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048])
+def test_fft1d_batched_vs_oracle(N, prec):
+    """kernel-level: batched axis pass on natural lines, ragged batch (not a multiple of the
+    lines-per-workgroup), both directions"""
+    batch = 37 if N >= 256 else 531
+    rng = np.random.default_rng(N)
+    x = rng.uniform(0, 255, (batch, N)) + 1j * rng.uniform(0, 255, (batch, N))
+    d_in = torch.from_numpy(x.astype(NPDT[prec])).cuda()
+    d_out = torch.zeros_like(d_in)
+    for direction in (dfft.FORWARD, dfft.INVERSE):
+        torch.cuda.synchronize()
+        dfft.fft1d_batched(d_out, d_in, N, batch, direction, prec)
+        torch.cuda.synchronize()
+        want = orc.fft1d(x.astype(NPDT[prec]), direction)
+        assert rel(d_out.cpu().numpy(), want) < TOL_FWD[prec]
+
+
+def run_single(shape, prec, seed=5):
+    g = orc.fill_block(shape, (0, 0, 0), shape, 2, seed=seed).astype(NPDT[prec])
+    plan = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), precision=prec)
+    plan.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(1, 1), True, c2c=True)
+    esz = 16 if prec == "double" else 8
+    d_in = torch.from_numpy(g).cuda()
+    d_out = torch.zeros(plan.getDomainSize() // esz, dtype=CDT[prec], device="cuda")
+    torch.cuda.synchronize()
+    plan.execC2C(d_out, d_in, dfft.FORWARD)
+    got = d_out[:g.size].cpu().numpy().reshape(shape)
+    assert np.array_equal(d_in.cpu().numpy(), g), "forward must not modify its input"
+    d_back = torch.zeros_like(d_in)
+    plan.execC2C(d_back, d_out, dfft.INVERSE)
+    return g, got, d_back.cpu().numpy()
+
+
+@pytest.mark.parametrize("prec", ["double", "float"])
+@pytest.mark.parametrize("shape", [(8, 8, 8), (2, 4, 8), (16, 16, 16), (32, 16, 64), (64, 64, 64),
+                                   (16, 128, 32), (128, 128, 128), (256, 8, 512), (4, 1024, 16), (2048, 4, 4)])
+def test_single_rank_3d_vs_oracle(shape, prec):
+    """fft3d branch (one rank): three local axis passes == oracle 3-D transform"""
+    g, got, back = run_single(shape, prec)
+    want = orc.fft3d_c2c(g.astype(np.complex128), -1)
+    assert rel(got, want) < TOL_FWD[prec]
+    assert rel(back / g.size, g) < TOL_RT[prec]
+
+
+def test_golden_fixture_single_rank():
+    d = np.load(os.path.join(GOLD, "fft3d_small.npz"))
+    shape = (8, 8, 8)
+    g, got, _ = run_single(shape, "double", seed=int(d["seed"]))
+    assert rel(got, d["c2c_8x8x8"]) < 1e-11
+
+
+def run_distributed(shape, P1, P2, prec, seed=7):
+    """P1*P2 virtual ranks on one GPU (one host thread per rank, like MPI ranks sharing a
+    device: tests/src/pencil/random_dist_3D.cu:175-177)."""
+    P = P1 * P2
+    world = dfft.Comm.local(P)
+    esz = 16 if prec == "double" else 8
+    plans, ins, outs, backs = [], [], [], []
+    for r in range(P):
+        pl = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), world, precision=prec, rank=r)
+        pl.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(P1, P2), True, c2c=True)
+        size, start = pl.getInSize(), pl.getInStart()
+        blk = orc.fill_block(shape, start, size, 2, seed=seed).astype(NPDT[prec])
+        plans.append(pl)
+        ins.append(torch.from_numpy(blk).cuda())
+        outs.append(torch.zeros(pl.getDomainSize() // esz, dtype=CDT[prec], device="cuda"))
+        backs.append(torch.zeros_like(ins[-1]))
+    torch.cuda.synchronize()
+    with ThreadPoolExecutor(P) as ex:
+        list(ex.map(lambda r: plans[r].execC2C(outs[r], ins[r], dfft.FORWARD), range(P)))
+    spec = []
+    for r in range(P):
+        s = plans[r].getOutSize()
+        spec.append(outs[r][:s[0] * s[1] * s[2]].cpu().numpy().reshape(s))
+    with ThreadPoolExecutor(P) as ex:
+        list(ex.map(lambda r: plans[r].execC2C(backs[r], outs[r], dfft.INVERSE), range(P)))
+    torch.cuda.synchronize()
+    return plans, [t.cpu().numpy() for t in ins], spec, [t.cpu().numpy() for t in backs]
+
+
+DIST = [((16, 16, 16), 2, 2), ((32, 32, 32), 2, 4), ((64, 32, 16), 4, 2), ((16, 16, 16), 3, 2),
+        ((32, 16, 64), 2, 1), ((32, 64, 32), 8, 1), ((16, 32, 16), 1, 4), ((64, 64, 64), 3, 5),
+        ((128, 64, 32), 2, 4)]
+
+
+@pytest.mark.parametrize("prec", ["double", "float"])
+@pytest.mark.parametrize("shape,P1,P2", DIST)
+def test_distributed_vs_oracle(shape, P1, P2, prec):
+    """reference testcase 1 (distributed == single device) and testcase 3 (round trip), with
+    even and uneven partitions, pencil and slab (P2 == 1)."""
+    plans, ins, spec, backs = run_distributed(shape, P1, P2, prec)
+    g = orc.fill_block(shape, (0, 0, 0), shape, 2, seed=7).astype(NPDT[prec]).astype(np.complex128)
+    want = orc.fft3d_c2c(g, -1)
+    opl = orc.PencilPlan(*shape, P1, P2, True)
+    n3 = float(np.prod(shape))
+    for r, pl in enumerate(plans):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        assert (s, o) == opl.out_block(r)
+        ref = want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]]
+        assert rel(spec[r], ref) < TOL_FWD[prec] * (np.max(np.abs(want)) / max(np.max(np.abs(ref)), 1e-300))
+        assert rel(backs[r] / n3, ins[r]) < TOL_RT[prec]
+        for which in (1, 2):   # byte tables == the reference's formulas (via the oracle restatement)
+            esz = 16 if prec == "double" else 8
+            assert pl.getExchangeTables(which) == [[v * esz for v in t] for t in opl.exchange_tables(r, which)]
