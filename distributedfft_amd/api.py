@@ -189,6 +189,10 @@ class MPIcuFFT:
         f = lib().dfft_exec_c2c if sync else lib().dfft_enqueue_c2c
         check(f(self._h, _ptr(out), _ptr(in_), direction))
 
+    def exchange(self, which, direction, sendbuf, recvbuf):
+        """only the all-to-all of exchange `which` (1 row group / 2 column group)"""
+        check(lib().dfft_exchange(self._h, which, direction, _ptr(sendbuf), _ptr(recvbuf)))
+
     # -- getters ------------------------------------------------------------------------
     def _get3(self, fn):
         a = (C.c_size_t * 3)()

@@ -458,6 +458,15 @@ int dfft_exec_c2c(dfft_plan *p, void *out, void *in, int direction)
     return 0;
 }
 
+int dfft_exchange(dfft_plan *p, int which, int direction, const void *sendbuf, void *recvbuf)
+{
+    if (!p || !p->initialized) return fail(ERR_STATE, "plan not initialised");
+    if (which != 1 && which != 2) return fail(ERR_ARG, "which must be 1 or 2");
+    if ((which == 1 ? p->P2 : p->P1) > 1) TRY(exchange(p, which, direction != DFFT_INVERSE, sendbuf, recvbuf));
+    if (p->stream) HIP_TRY(hipStreamSynchronize(p->stream));
+    return 0;
+}
+
 int dfft_exec_r2c(dfft_plan *p, void *out, const void *in)
 {
     (void)out; (void)in;

@@ -1,0 +1,110 @@
+"""Exchange transports for one-process-per-GPU runs under torch.distributed.
+
+`make_comm` returns a dfft Comm for a P1 x P2 process grid (rank = i*P2 + j, the reference's
+pidx = pidx_i*P2 + pidx_j, src/pencil/mpicufft_pencil_opt1.cpp:67-68):
+
+  * "rccl"  -- the library's own RCCL communicator (grouped ncclSend/ncclRecv over xGMI inside
+               libdfft_amd.so); torch.distributed only broadcasts the ncclUniqueId.
+  * "torch" -- torch.distributed.all_to_all_single on row/column process groups (backend
+               "nccl" = RCCL on ROCm, "gloo" on CPU), driven through the C ABI's callback
+               transport.  Buffers the library exchanges must be registered so raw pointers
+               can be mapped back to tensors.
+  * "auto"  -- rccl if it can be created and passes a small round-trip self-test on every
+               rank, otherwise torch.
+"""
+import torch
+
+from . import api
+
+
+class TorchComm:
+    def __init__(self, dist, rank, world, P1, P2):
+        self.dist, self.rank, self.world = dist, rank, world
+        self.groups = {}
+        # every rank creates every group, in the same order (torch.distributed requirement)
+        for i in range(P1):
+            ranks = [i * P2 + j for j in range(P2)]
+            self.groups[tuple(ranks)] = dist.new_group(ranks) if len(ranks) > 1 else None
+        for j in range(P2):
+            ranks = [i * P2 + j for i in range(P1)]
+            self.groups[tuple(ranks)] = dist.new_group(ranks) if len(ranks) > 1 else None
+        self.buffers = []
+        self.comm = api.Comm.callback(world, rank, self._alltoallv)
+        self.calls = 0
+
+    def register(self, tensor):
+        """make a tensor's storage known to the pointer -> tensor lookup"""
+        self.buffers.append(tensor.reshape(-1).view(torch.uint8))
+
+    def _slice(self, ptr, nbytes):
+        for t in self.buffers:
+            base = t.data_ptr()
+            if base <= ptr and ptr + nbytes <= base + t.numel():
+                return t[ptr - base: ptr - base + nbytes]
+        raise RuntimeError(f"exchange buffer {ptr:#x}+{nbytes} is not registered with the torch transport")
+
+    def _alltoallv(self, send, sc, sd, recv, rc, rd, group, me, stream):
+        for q in range(1, len(group)):   # peer blocks are laid out back to back in rank order
+            assert sd[q] == sd[q - 1] + sc[q - 1] and rd[q] == rd[q - 1] + rc[q - 1]
+        s = self._slice(send + sd[0], sum(sc)).view(torch.int64)
+        r = self._slice(recv + rd[0], sum(rc)).view(torch.int64)
+        self.dist.all_to_all_single(r, s, output_split_sizes=[c // 8 for c in rc],
+                                    input_split_sizes=[c // 8 for c in sc], group=self.groups[tuple(group)])
+        self.calls += 1
+
+    # duck-typing so a TorchComm can be passed wherever a Comm is expected
+    @property
+    def _h(self):
+        return self.comm._h
+
+    @property
+    def nranks(self):
+        return self.world
+
+
+def _selftest(dist, comm, rank, world, P1, P2):
+    """tiny forward+inverse through the transport; returns max round-trip error over ranks"""
+    n = 32
+    plan = api.MPIcuFFT_Pencil_Opt1(api.Configurations(), comm, precision="double", rank=rank)
+    plan.initFFT(api.GlobalSize(n, n, n), api.Partition(P1, P2), allocate=False, c2c=True)
+    plan.setStream(torch.cuda.current_stream().cuda_stream)
+    work = torch.empty(plan.getWorkSizeDevice(), dtype=torch.uint8, device="cuda")
+    plan.setWorkArea(work)
+    s = plan.getInSize()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234 + rank)
+    x = torch.view_as_complex(torch.rand((s[0] * s[1] * s[2], 2), dtype=torch.float64, device="cuda", generator=g))
+    out = torch.zeros(plan.getDomainSize() // 16, dtype=torch.complex128, device="cuda")
+    back = torch.zeros_like(x)
+    if isinstance(comm, TorchComm):
+        comm.register(work)
+        comm.register(out)
+    plan.execC2C(out, x, api.FORWARD)
+    plan.execC2C(back, out, api.INVERSE)
+    err = ((back / float(n) ** 3 - x).abs().max() / x.abs().max()).reshape(1)
+    dist.all_reduce(err, op=dist.ReduceOp.MAX)
+    return float(err.item())
+
+
+def make_comm(dist, rank, world, P1, P2, mode="auto"):
+    if mode in ("auto", "rccl"):
+        ok = torch.ones(1, device="cuda")
+        comm = None
+        try:
+            ids = [api.Comm.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = api.Comm.rccl(ids[0], world, rank)
+        except Exception as e:   # noqa: BLE001
+            if mode == "rccl":
+                raise
+            print(f"[rank {rank}] native RCCL transport unavailable ({e}); using torch transport", flush=True)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() > 0:
+            err = _selftest(dist, comm, rank, world, P1, P2)
+            if err < 1e-10:
+                return comm, "rccl (native grouped send/recv)"
+            if mode == "rccl":
+                raise RuntimeError(f"native RCCL transport failed its self-test: round trip {err}")
+    tc = TorchComm(dist, rank, world, P1, P2)
+    return tc, "torch"

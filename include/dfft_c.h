@@ -134,6 +134,11 @@ int dfft_world_size(const dfft_plan *plan);
  * (mpicufft_pencil_opt1.cpp:269-273 which=1, :315-319 which=2).  Arrays hold P2 resp. P1 entries. */
 int dfft_get_exchange_tables(const dfft_plan *plan, int which, size_t *sendcounts, size_t *sdispls,
                              size_t *recvcounts, size_t *rdispls);
+/* run only exchange `which` (1 = row group, 2 = column group) of the plan on caller buffers,
+ * forward (send tables) or inverse (tables swapped) direction, blocking.  This is the
+ * MPI_Alltoallv step of the reference in isolation (:784-785 / :829-830, :1297-1298 / :1341-1342);
+ * used by the transport tests. */
+int dfft_exchange(dfft_plan *plan, int which, int direction, const void *sendbuf, void *recvbuf);
 /* lines interleaved per tile in the intermediate layouts */
 int dfft_tile_lines(const dfft_plan *plan);
 
