@@ -14,6 +14,7 @@
 #include "fft_pass.hip.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <string>
@@ -56,16 +57,18 @@ static void split(size_t n, int p, std::vector<size_t> &size, std::vector<size_t
     for (int i = 0; i < p; i++) { start[i] = off; off += size[i]; }
 }
 
-static int launch_pass(int prec, int N, const PassArgs &A, hipStream_t s)
+static int launch_pass(int prec, int N, int variant, const PassArgs &A, hipStream_t s)
 {
-    int r = prec == DFFT_F64 ? launch_pass_f64(N, A, s) : launch_pass_f32(N, A, s);
+    PassInfo pi;
+    if (variant && !(prec == DFFT_F64 ? pass_info_f64(N, variant, &pi) : pass_info_f32(N, variant, &pi))) variant = 0;
+    int r = prec == DFFT_F64 ? launch_pass_f64(N, variant, A, s) : launch_pass_f32(N, variant, A, s);
     if (r == -1) return fail(ERR_UNSUPPORTED, "unsupported line length " + std::to_string(N));
     if (r != 0) return fail(r, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)r));
     return 0;
 }
 static bool pass_info(int prec, int N, PassInfo *pi)
 {
-    return prec == DFFT_F64 ? pass_info_f64(N, pi) : pass_info_f32(N, pi);
+    return prec == DFFT_F64 ? pass_info_f64(N, 0, pi) : pass_info_f32(N, 0, pi);
 }
 
 // twiddle table exp(-2*pi*i*j/N), evaluated in long double, rounded once
@@ -106,7 +109,7 @@ struct dfft_plan {
     size_t esz = 16, domain_elems = 0, domainsize = 0, worksize_d = 0;
     void *work_d = nullptr;
     bool work_owned = false;
-    void *tw_x = nullptr, *tw_y = nullptr, *tw_z = nullptr;
+    void *tw_x = nullptr, *tw_y = nullptr, *tw_z = nullptr, *tw_zr = nullptr;   // tw_zr: split/merge table (R2C)
     hipStream_t stream = nullptr;
     bool stream_owned = false;
     // exchange tables in bytes (row comm = 1, column comm = 2) and member lists
@@ -114,6 +117,7 @@ struct dfft_plan {
     std::vector<int> group1, group2;
     // pass descriptors without buffer pointers: [0]=z [1]=y [2]=x
     PassArgs fwd[3], inv[3];
+    int vfwd[3] = {0, 0, 0}, vinv[3] = {0, 0, 0};   // kernel variant per pass
     // phase timing
     bool timing = false;
     hipEvent_t ev[8] = {};
@@ -194,11 +198,23 @@ static int build_passes(dfft_plan *p)
     return 0;
 }
 
-static int run_pass(dfft_plan *p, const PassArgs &tmpl, size_t N, const void *tw, const void *in, void *out)
+static int run_pass(dfft_plan *p, const PassArgs &tmpl, int variant, size_t N, const void *tw, const void *in, void *out)
 {
     PassArgs A = tmpl;
     A.in = in; A.out = out; A.tw = tw;
-    return launch_pass(p->prec, (int)N, A, p->stream);
+    return launch_pass(p->prec, (int)N, variant, A, p->stream);
+}
+
+// z pass of an R2C plan: M = Nz/2 point complex FFT + split (mode 1) / merge (mode 2)
+static int run_real_pass(dfft_plan *p, const PassArgs &tmpl, int mode, const void *in, void *out)
+{
+    PassArgs A = tmpl;
+    A.in = in; A.out = out; A.tw = p->tw_z; A.tw2 = p->tw_zr;
+    const int M = (int)(p->Nz / 2);
+    int r = p->prec == DFFT_F64 ? launch_real_f64(M, mode, A, p->stream) : launch_real_f32(M, mode, A, p->stream);
+    if (r == -1) return fail(ERR_UNSUPPORTED, "unsupported real line length " + std::to_string(p->Nz));
+    if (r != 0) return fail(r, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)r));
+    return 0;
 }
 
 static int mark(dfft_plan *p)
@@ -233,18 +249,19 @@ static int enqueue_forward(dfft_plan *p, void *out, const void *in)
     char *A = static_cast<char *>(out), *B = static_cast<char *>(p->work_d), *C = B + p->domainsize;
     p->nev = 0; p->last_dir = DFFT_FORWARD;
     TRY(mark(p));
-    TRY(run_pass(p, p->fwd[0], p->Nz, p->tw_z, in, A));
+    if (p->c2c) TRY(run_pass(p, p->fwd[0], p->vfwd[0], p->Nz, p->tw_z, in, A));
+    else TRY(run_real_pass(p, p->fwd[0], 1, in, A));
     TRY(mark(p));
     char *cur = A;
     if (p->P2 > 1) { TRY(exchange(p, 1, true, A, B)); cur = B; }
     TRY(mark(p));
     char *ydst = (cur == B) ? C : B;
-    TRY(run_pass(p, p->fwd[1], p->Ny, p->tw_y, cur, ydst));
+    TRY(run_pass(p, p->fwd[1], p->vfwd[1], p->Ny, p->tw_y, cur, ydst));
     cur = ydst;
     TRY(mark(p));
     if (p->P1 > 1) { char *dst = (cur == B) ? C : B; TRY(exchange(p, 2, true, cur, dst)); cur = dst; }
     TRY(mark(p));
-    TRY(run_pass(p, p->fwd[2], p->Nx, p->tw_x, cur, A));
+    TRY(run_pass(p, p->fwd[2], p->vfwd[2], p->Nx, p->tw_x, cur, A));
     TRY(mark(p));
     return 0;
 }
@@ -255,18 +272,19 @@ static int enqueue_inverse(dfft_plan *p, void *out, void *in)
     char *I = static_cast<char *>(in), *B = static_cast<char *>(p->work_d);
     p->nev = 0; p->last_dir = DFFT_INVERSE;
     TRY(mark(p));
-    TRY(run_pass(p, p->inv[2], p->Nx, p->tw_x, I, B));
+    TRY(run_pass(p, p->inv[2], p->vinv[2], p->Nx, p->tw_x, I, B));
     TRY(mark(p));
     char *cur = B;
     if (p->P1 > 1) { TRY(exchange(p, 2, false, B, I)); cur = I; }
     TRY(mark(p));
     char *ydst = (cur == B) ? I : B;
-    TRY(run_pass(p, p->inv[1], p->Ny, p->tw_y, cur, ydst));
+    TRY(run_pass(p, p->inv[1], p->vinv[1], p->Ny, p->tw_y, cur, ydst));
     cur = ydst;
     TRY(mark(p));
     if (p->P2 > 1) { char *dst = (cur == B) ? I : B; TRY(exchange(p, 1, false, cur, dst)); cur = dst; }
     TRY(mark(p));
-    TRY(run_pass(p, p->inv[0], p->Nz, p->tw_z, cur, out));
+    if (p->c2c) TRY(run_pass(p, p->inv[0], p->vinv[0], p->Nz, p->tw_z, cur, out));
+    else TRY(run_real_pass(p, p->inv[0], 2, cur, out));
     TRY(mark(p));
     return 0;
 }
@@ -337,7 +355,7 @@ int dfft_plan_destroy(dfft_plan *p)
 {
     if (!p) return 0;
     if (p->work_owned && p->work_d) (void)hipFree(p->work_d);
-    for (void *t : {p->tw_x, p->tw_y, p->tw_z}) if (t) (void)hipFree(t);
+    for (void *t : {p->tw_x, p->tw_y, p->tw_z, p->tw_zr}) if (t) (void)hipFree(t);
     for (auto &e : p->ev) if (e) (void)hipEventDestroy(e);
     if (p->stream_owned && p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
@@ -353,9 +371,10 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         return fail(ERR_ARG, "slab decomposition needs P2 == 1");
     if (P1 > MAXSEG || P2 > MAXSEG) return fail(ERR_UNSUPPORTED, "more than 16 ranks per exchange group");
     if ((size_t)P1 > Nx || (size_t)P1 > Ny || (size_t)P2 > Ny) return fail(ERR_ARG, "partition larger than the grid");
-    if (!c2c) return fail(ERR_UNSUPPORTED, "R2C/C2R plans are not implemented yet");
     PassInfo pinfo;
-    for (size_t n : {Nx, Ny, Nz})
+    if (!c2c && (Nz % 2 || Nz < 4 || Nz > 2048))
+        return fail(ERR_UNSUPPORTED, "R2C/C2R needs an even Nz in 4..2048");
+    for (size_t n : {Nx, Ny, c2c ? Nz : Nz / 2})
         if (!pass_info(p->prec, (int)n, &pinfo))
             return fail(ERR_UNSUPPORTED, "unsupported axis length " + std::to_string(n) +
                                              " (power of two, 2..2048)");
@@ -396,7 +415,16 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         p->group2[q] = q * P2 + p->pj;
     }
     TRY(build_passes(p));
-    for (void **t : {&p->tw_x, &p->tw_y, &p->tw_z}) if (*t) { (void)hipFree(*t); *t = nullptr; }
+    // experiment hook: DFFT_VARIANTS="zyx xyz" digits = kernel variant of fwd z,y,x then inv x,y,z
+    if (const char *v = getenv("DFFT_VARIANTS")) {
+        int k = 0;
+        for (const char *c = v; *c && k < 6; c++) {
+            if (*c < '0' || *c > '9') continue;
+            if (k < 3) p->vfwd[k] = *c - '0'; else p->vinv[5 - k] = *c - '0';
+            k++;
+        }
+    }
+    for (void **t : {&p->tw_x, &p->tw_y, &p->tw_z, &p->tw_zr}) if (*t) { (void)hipFree(*t); *t = nullptr; }
     p->initialized = true;
     // device-side state (twiddles, stream, work area) is created by setWorkArea, so that the
     // decomposition tables can be queried on a host without a GPU (allocate = 0).
@@ -408,7 +436,8 @@ static int ensure_device_state(dfft_plan *p)
 {
     if (!p->tw_x) TRY(make_twiddles(p->prec, p->Nx, &p->tw_x));
     if (!p->tw_y) TRY(make_twiddles(p->prec, p->Ny, &p->tw_y));
-    if (!p->tw_z) TRY(make_twiddles(p->prec, p->Nz, &p->tw_z));
+    if (!p->tw_z) TRY(make_twiddles(p->prec, p->c2c ? p->Nz : p->Nz / 2, &p->tw_z));
+    if (!p->c2c && !p->tw_zr) TRY(make_twiddles(p->prec, p->Nz, &p->tw_zr));
     if (!p->stream) {
         HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
         p->stream_owned = true;
@@ -469,15 +498,21 @@ int dfft_exchange(dfft_plan *p, int which, int direction, const void *sendbuf, v
 
 int dfft_exec_r2c(dfft_plan *p, void *out, const void *in)
 {
-    (void)out; (void)in;
     TRY(check_ready(p));
-    return fail(ERR_UNSUPPORTED, "execR2C is not implemented yet");
+    if (p->c2c) return fail(ERR_STATE, "plan was initialised for C2C");
+    if (!out || !in) return fail(ERR_ARG, "null buffer");
+    TRY(enqueue_forward(p, out, in));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return 0;
 }
 int dfft_exec_c2r(dfft_plan *p, void *out, void *in)
 {
-    (void)out; (void)in;
     TRY(check_ready(p));
-    return fail(ERR_UNSUPPORTED, "execC2R is not implemented yet");
+    if (p->c2c) return fail(ERR_STATE, "plan was initialised for C2C");
+    if (!out || !in) return fail(ERR_ARG, "null buffer");
+    TRY(enqueue_inverse(p, out, in));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return 0;
 }
 
 int dfft_get_in_size(const dfft_plan *p, size_t s[3])
@@ -564,7 +599,7 @@ int dfft_fft1d_batched(int precision, size_t N, size_t batch, void *out, const v
     A.in = in; A.out = out; A.tw = tw;
     A.na = 1; A.LB = (uint32_t)batch; A.nb = ((uint32_t)batch + pi.TL - 1) / pi.TL; A.ntiles = A.nb;
     A.load_kind = LOAD_LINES; A.store_kind = STORE_LINES; A.swap = direction == DFFT_INVERSE;
-    return launch_pass(precision, (int)N, A, (hipStream_t)hip_stream);
+    return launch_pass(precision, (int)N, getenv("DFFT_VARIANT_1D") ? atoi(getenv("DFFT_VARIANT_1D")) : 0, A, (hipStream_t)hip_stream);
 }
 
 int dfft_kernel_info(int precision, size_t N, int *threads, int *lds_bytes, int *points_per_thread,

@@ -16,10 +16,13 @@ constexpr int TL_F64 = 8;
 constexpr int TL_F32 = 16;
 
 // returns 0 on success, -1 if the length is unsupported, else a hipError_t
-int launch_pass_f64(int N, const PassArgs &A, hipStream_t stream);
-int launch_pass_f32(int N, const PassArgs &A, hipStream_t stream);
-bool pass_info_f64(int N, PassInfo *pi);
-bool pass_info_f32(int N, PassInfo *pi);
+int launch_pass_f64(int N, int variant, const PassArgs &A, hipStream_t stream);
+int launch_pass_f32(int N, int variant, const PassArgs &A, hipStream_t stream);
+bool pass_info_f64(int N, int variant, PassInfo *pi);
+// real-transform z pass on M = Nz/2 complex points: mode 1 = R2C (forward), 2 = C2R (inverse)
+int launch_real_f64(int M, int mode, const PassArgs &A, hipStream_t stream);
+int launch_real_f32(int M, int mode, const PassArgs &A, hipStream_t stream);
+bool pass_info_f32(int N, int variant, PassInfo *pi);
 
 void set_error(const std::string &msg);
 

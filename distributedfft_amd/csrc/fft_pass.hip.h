@@ -55,6 +55,7 @@ struct PassArgs {
     const void *in;
     void *out;
     const void *tw;        // twiddle table, N complex entries exp(-2*pi*i*j/N)
+    const void *tw2;       // real transforms only: exp(-2*pi*i*k/(2N)), k = 0..N, for the split/merge step
     uint32_t na;           // extent of the outer line-set axis
     uint32_t LB;           // extent of the inner (tiled) line-set axis
     uint32_t nb;           // tiles along LB = ceil(LB / TL)
@@ -380,6 +381,163 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
             out[off] = v[c];
         });
     }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Real transforms on the z axis (the reference's cufftExecD2Z / cufftExecZ2D plans,
+// src/pencil/mpicufft_pencil_opt1.cpp:165-173).  A real line of 2M points is transformed as an
+// M-point complex FFT of z[j] = x[2j] + i x[2j+1] plus a split (R2C) or merge (C2R) step:
+//   R2C:  X[k] = (Z[k] + conj Z[M-k])/2 - (i/2) w^k (Z[k] - conj Z[M-k]),  k = 0..M
+//   C2R:  Z[k] = (X[k] + conj X[M-k]) + i w^-k (X[k] - conj X[M-k]),       k = 0..M-1
+// with w = exp(-2*pi*i/(2M)).  Cfg::kN is M.
+// ------------------------------------------------------------------------------------------
+template <typename Cfg> struct RealCfg {
+    static constexpr size_t LDS_BYTES = 2 * (size_t)Cfg::PLANE_SLOTS * sizeof(typename Cfg::real);
+};
+
+template <int TL> struct TileCtx { uint32_t a, b, tw; int l; };
+
+template <int TL>
+__device__ __forceinline__ uint64_t tiled_load_offset(const PassArgs &A, const TileCtx<TL> &c, uint32_t n)
+{
+    uint32_t s0 = A.lseg.start[0], ln = A.lseg.len[0];
+    uint64_t bs = A.lseg.base[0];
+    for (int s = 1; s < A.lseg.nseg; s++)
+        if (n >= A.lseg.start[s]) { s0 = A.lseg.start[s]; ln = A.lseg.len[s]; bs = A.lseg.base[s]; }
+    return bs + (uint64_t)c.a * ln * A.LB + (uint64_t)c.b * TL * ln + (uint64_t)(n - s0) * c.tw + c.l;
+}
+template <int TL>
+__device__ __forceinline__ uint64_t tiled_transpose_store_offset(const PassArgs &A, const TileCtx<TL> &c, uint32_t k)
+{
+    uint32_t s0 = A.sseg.start[0], ln = A.sseg.len[0];
+    uint64_t bs = A.sseg.base[0];
+    for (int s = 1; s < A.sseg.nseg; s++)
+        if (k >= A.sseg.start[s]) { s0 = A.sseg.start[s]; ln = A.sseg.len[s]; bs = A.sseg.base[s]; }
+    const uint32_t kl = k - s0;
+    const uint32_t T2 = 1u << A.T2shift;
+    const uint32_t kt = kl >> A.T2shift, kr = kl & (T2 - 1);
+    const uint32_t r2 = ln - kt * T2;
+    const uint32_t tw2 = r2 < T2 ? r2 : T2;
+    return bs + (uint64_t)c.a * ln * A.LB + (uint64_t)kt * T2 * A.LB + ((uint64_t)c.b * TL + c.l) * tw2 + kr;
+}
+
+// forward z pass of an R2C plan: real lines [a][LB][2M] -> tiled send buffer with M+1 points
+template <typename Cfg>
+__global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
+{
+    using C = typename Cfg::C;
+    using R = typename Cfg::real;
+    constexpr int M = Cfg::kN, E = Cfg::kE, TL = Cfg::kTL, NT = Cfg::NT, TW = Cfg::TW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    R *lds = reinterpret_cast<R *>(smem);
+    const int tid = threadIdx.x;
+    const int lw = tid % TW, t = tid / TW;
+    const int g = lw / TL, l = lw % TL;
+    const uint32_t w = blockIdx.x * Cfg::kG + g;
+    const bool tile_ok = w < A.ntiles;
+    TileCtx<TL> tc;
+    tc.a = tile_ok ? w / A.nb : 0; tc.b = tile_ok ? w % A.nb : 0; tc.l = l;
+    const uint32_t rem = A.LB - tc.b * TL;
+    tc.tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;
+    const bool active = tile_ok && (uint32_t)l < tc.tw;
+    const C *__restrict__ in = reinterpret_cast<const C *>(A.in);
+    C *__restrict__ out = reinterpret_cast<C *>(A.out);
+    const C *__restrict__ W = reinterpret_cast<const C *>(A.tw);
+    const C *__restrict__ W2 = reinterpret_cast<const C *>(A.tw2);
+
+    C v[E];
+    if (active) {
+        const C *p = in + ((uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + l) * M + t;
+        static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = p[NT * c]; });
+    } else {
+        static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].x = 0; v[c].y = 0; });
+    }
+    transform<Cfg>(v, lds, W, t, lw, tid);
+
+    // split step through both LDS planes: scatter Z by natural index, gather the (k, M-k) pairs
+    constexpr int RL = Cfg::RLAST, S = E / RL;
+    R *p0 = lds, *p1 = lds + Cfg::PLANE_SLOTS;
+    if (Cfg::NPASS > 1) __syncthreads();
+    static_for<0, E>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (M / RL);
+        const int idx = lds_pad<Cfg>((t + k0) * TW + lw);
+        p0[idx] = v[c].x;
+        p1[idx] = v[c].y;
+    });
+    __syncthreads();
+    if (!active) return;
+    static_for<0, E>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        const int k = t + NT * c;
+        const int km = (M - k) & (M - 1);
+        const int i0 = lds_pad<Cfg>(k * TW + lw), i1 = lds_pad<Cfg>(km * TW + lw);
+        const R zr = p0[i0], zi = p1[i0], mr = p0[i1], mi = p1[i1];
+        const C wv = W2[k];
+        const R Ar = zr + mr, Ai = zi - mi, Br = zr - mr, Bi = zi + mi;
+        C x;
+        x.x = (R)0.5 * (Ar + wv.x * Bi + wv.y * Br);
+        x.y = (R)0.5 * (Ai - wv.x * Br + wv.y * Bi);
+        out[tiled_transpose_store_offset<TL>(A, tc, (uint32_t)k)] = x;
+        if (c == 0 && t == 0) {          // k = M: X[M] = Re Z[0] - Im Z[0]
+            C xm; xm.x = zr - zi; xm.y = 0;
+            out[tiled_transpose_store_offset<TL>(A, tc, (uint32_t)M)] = xm;
+        }
+    });
+}
+
+// inverse z pass of an R2C plan: tiled recv buffer with M+1 points -> real lines [a][LB][2M]
+template <typename Cfg>
+__global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
+{
+    using C = typename Cfg::C;
+    using R = typename Cfg::real;
+    constexpr int M = Cfg::kN, E = Cfg::kE, TL = Cfg::kTL, NT = Cfg::NT, TW = Cfg::TW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    R *lds = reinterpret_cast<R *>(smem);
+    const int tid = threadIdx.x;
+    const int lw = tid % TW, t = tid / TW;
+    const int g = lw / TL, l = lw % TL;
+    const uint32_t w = blockIdx.x * Cfg::kG + g;
+    const bool tile_ok = w < A.ntiles;
+    TileCtx<TL> tc;
+    tc.a = tile_ok ? w / A.nb : 0; tc.b = tile_ok ? w % A.nb : 0; tc.l = l;
+    const uint32_t rem = A.LB - tc.b * TL;
+    tc.tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;
+    const bool active = tile_ok && (uint32_t)l < tc.tw;
+    const C *__restrict__ in = reinterpret_cast<const C *>(A.in);
+    C *__restrict__ out = reinterpret_cast<C *>(A.out);
+    const C *__restrict__ W = reinterpret_cast<const C *>(A.tw);
+    const C *__restrict__ W2 = reinterpret_cast<const C *>(A.tw2);
+
+    C v[E];
+    if (active) {
+        static_for<0, E>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            const int k = t + NT * c;
+            C x = in[tiled_load_offset<TL>(A, tc, (uint32_t)k)];
+            C m = in[tiled_load_offset<TL>(A, tc, (uint32_t)(M - k))];
+            if (k == 0) { x.y = 0; m.y = 0; }      // imaginary parts of X[0], X[M] are ignored
+            const C wv = W2[k];
+            const R Ar = x.x + m.x, Ai = x.y - m.y, Br = x.x - m.x, Bi = x.y + m.y;
+            // swapped on the fly (inverse via re<->im swap): v = (Im Z', Re Z')
+            v[c].y = Ar - wv.x * Bi + wv.y * Br;
+            v[c].x = Ai + wv.x * Br + wv.y * Bi;
+        });
+    } else {
+        static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].x = 0; v[c].y = 0; });
+    }
+    transform<Cfg>(v, lds, W, t, lw, tid);
+    if (!active) return;
+    constexpr int RL = Cfg::RLAST, S = E / RL;
+    C *p = out + ((uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + l) * M + t;
+    static_for<0, E>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (M / RL);
+        C r; r.x = v[c].y; r.y = v[c].x;     // swap back
+        p[k0] = r;
+    });
 }
 
 }  // namespace dfft

@@ -14,25 +14,43 @@ using F32_512  = PassCfg<float, 512, 16, 16, 1,  8, 8, 8, 1,   2>;
 using F32_1024 = PassCfg<float, 1024, 16, 16, 1, 16, 16, 4, 1, 1>;
 using F32_2048 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1,  1>;
 
-#define DFFT_F32_LIST(X) X(2, F32_2) X(4, F32_4) X(8, F32_8) X(16, F32_16) X(32, F32_32) X(64, F32_64) \
-    X(128, F32_128) X(256, F32_256) X(512, F32_512) X(1024, F32_1024) X(2048, F32_2048)
+using F32_1024_v1 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1>;   // 512 thr, 2 passes
+using F32_1024_v2 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 2>;   // + two planes
+using F32_1024_v3 = PassCfg<float, 1024, 16, 16, 1, 16, 16, 4, 1, 2>;   // two planes
 
-int launch_pass_f32(int N, const PassArgs &A, hipStream_t stream)
+#define DFFT_F32_LIST(X) X(1024, 1, F32_1024_v1) X(1024, 2, F32_1024_v2) X(1024, 3, F32_1024_v3) \
+    X(2, 0, F32_2) X(4, 0, F32_4) X(8, 0, F32_8) X(16, 0, F32_16) X(32, 0, F32_32) X(64, 0, F32_64) \
+    X(128, 0, F32_128) X(256, 0, F32_256) X(512, 0, F32_512) X(1024, 0, F32_1024) X(2048, 0, F32_2048)
+
+int launch_pass_f32(int N, int variant, const PassArgs &A, hipStream_t stream)
 {
-    switch (N) {
-#define X(n, cfg) case n: return launch_cfg<cfg>(A, stream);
+    switch (N * 16 + variant) {
+#define X(n, v, cfg) case n * 16 + v: return launch_cfg<cfg>(A, stream);
         DFFT_F32_LIST(X)
 #undef X
     }
     return -1;
 }
-bool pass_info_f32(int N, PassInfo *pi)
+bool pass_info_f32(int N, int variant, PassInfo *pi)
 {
-    switch (N) {
-#define X(n, cfg) case n: info_cfg<cfg>(pi); return true;
+    switch (N * 16 + variant) {
+#define X(n, v, cfg) case n * 16 + v: info_cfg<cfg>(pi); return true;
         DFFT_F32_LIST(X)
 #undef X
     }
     return false;
+}
+
+// real-transform z passes (variant 0 configurations only); M = Nz/2
+#define DFFT_F32_BASE(X) X(2, 0, F32_2) X(4, 0, F32_4) X(8, 0, F32_8) X(16, 0, F32_16) X(32, 0, F32_32) X(64, 0, F32_64) \
+    X(128, 0, F32_128) X(256, 0, F32_256) X(512, 0, F32_512) X(1024, 0, F32_1024)
+int launch_real_f32(int M, int mode, const PassArgs &A, hipStream_t stream)
+{
+    switch (M) {
+#define X(n, v, cfg) case n: return mode == 1 ? launch_real_cfg<cfg, 1>(A, stream) : launch_real_cfg<cfg, 2>(A, stream);
+        DFFT_F32_BASE(X)
+#undef X
+    }
+    return -1;
 }
 }  // namespace dfft

@@ -15,25 +15,49 @@ using F64_512  = PassCfg<double, 512, 16, 8, 1,  8, 8, 8, 1,   1>;
 using F64_1024 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1>;
 using F64_2048 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1>;
 
-#define DFFT_F64_LIST(X) X(2, F64_2) X(4, F64_4) X(8, F64_8) X(16, F64_16) X(32, F64_32) X(64, F64_64) \
-    X(128, F64_128) X(256, F64_256) X(512, F64_512) X(1024, F64_1024) X(2048, F64_2048)
+// experimental alternatives for N = 1024 (selected per pass with DFFT_VARIANTS, see dfft.hip)
+using F64_1024_v1 = PassCfg<double, 1024, 16, 8, 2, 16, 16, 4, 1, 1>;   // 16 lines / WG, 1024 thr
+using F64_1024_v2 = PassCfg<double, 1024, 32, 8, 1, 32, 32, 1, 1, 1>;   // 32 pts / thread, 2 passes
+using F64_1024_v3 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1>;   // both
+using F64_1024_v4 = PassCfg<double, 1024, 16, 8, 1, 4, 16, 16, 1, 1>;   // small radix first
+using F64_1024_v5 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 2>;   // two LDS planes, fewer barriers
+using F64_512_v1 = PassCfg<double, 512, 16, 8, 2, 8, 8, 8, 1, 1>;
+using F64_512_v2 = PassCfg<double, 512, 32, 8, 2, 32, 16, 1, 1, 1>;
 
-int launch_pass_f64(int N, const PassArgs &A, hipStream_t stream)
+#define DFFT_F64_LIST(X) X(1024, 1, F64_1024_v1) X(1024, 2, F64_1024_v2) X(1024, 3, F64_1024_v3) \
+    X(1024, 4, F64_1024_v4) X(1024, 5, F64_1024_v5) X(512, 1, F64_512_v1) X(512, 2, F64_512_v2) \
+    X(2, 0, F64_2) X(4, 0, F64_4) X(8, 0, F64_8) X(16, 0, F64_16) X(32, 0, F64_32) X(64, 0, F64_64) \
+    X(128, 0, F64_128) X(256, 0, F64_256) X(512, 0, F64_512) X(1024, 0, F64_1024) X(2048, 0, F64_2048)
+
+int launch_pass_f64(int N, int variant, const PassArgs &A, hipStream_t stream)
 {
-    switch (N) {
-#define X(n, cfg) case n: return launch_cfg<cfg>(A, stream);
+    switch (N * 16 + variant) {
+#define X(n, v, cfg) case n * 16 + v: return launch_cfg<cfg>(A, stream);
         DFFT_F64_LIST(X)
 #undef X
     }
     return -1;
 }
-bool pass_info_f64(int N, PassInfo *pi)
+bool pass_info_f64(int N, int variant, PassInfo *pi)
 {
-    switch (N) {
-#define X(n, cfg) case n: info_cfg<cfg>(pi); return true;
+    switch (N * 16 + variant) {
+#define X(n, v, cfg) case n * 16 + v: info_cfg<cfg>(pi); return true;
         DFFT_F64_LIST(X)
 #undef X
     }
     return false;
+}
+
+// real-transform z passes (variant 0 configurations only); M = Nz/2
+#define DFFT_F64_BASE(X) X(2, 0, F64_2) X(4, 0, F64_4) X(8, 0, F64_8) X(16, 0, F64_16) X(32, 0, F64_32) X(64, 0, F64_64) \
+    X(128, 0, F64_128) X(256, 0, F64_256) X(512, 0, F64_512) X(1024, 0, F64_1024)
+int launch_real_f64(int M, int mode, const PassArgs &A, hipStream_t stream)
+{
+    switch (M) {
+#define X(n, v, cfg) case n: return mode == 1 ? launch_real_cfg<cfg, 1>(A, stream) : launch_real_cfg<cfg, 2>(A, stream);
+        DFFT_F64_BASE(X)
+#undef X
+    }
+    return -1;
 }
 }  // namespace dfft

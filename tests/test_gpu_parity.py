@@ -130,3 +130,101 @@ def test_distributed_vs_oracle(shape, P1, P2, prec):
         for which in (1, 2):   # byte tables == the reference's formulas (via the oracle restatement)
             esz = 16 if prec == "double" else 8
             assert pl.getExchangeTables(which) == [[v * esz for v in t] for t in opl.exchange_tables(r, which)]
+
+
+# ------------------------------------------------------------------------------------------
+# R2C / C2R: the reference's actual API (execR2C / execC2R, Nz_out = Nz/2+1)
+# ------------------------------------------------------------------------------------------
+RDT = {"double": torch.float64, "float": torch.float32}
+NPR = {"double": np.float64, "float": np.float32}
+
+
+def run_distributed_real(shape, P1, P2, prec, field=None, seed=13, modify=None):
+    P = P1 * P2
+    world = dfft.Comm.local(P) if P > 1 else None
+    esz = 16 if prec == "double" else 8
+    plans, ins, outs, backs = [], [], [], []
+    for r in range(P):
+        pl = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), world, precision=prec, rank=r)
+        pl.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(P1, P2), True)      # R2C plan
+        size, start = pl.getInSize(), pl.getInStart()
+        if field is None:
+            blk = orc.fill_block(shape, start, size, 1, seed=seed)
+        else:
+            blk = np.ascontiguousarray(field[start[0]:start[0] + size[0], start[1]:start[1] + size[1], :])
+        plans.append(pl)
+        ins.append(torch.from_numpy(blk.astype(NPR[prec])).cuda())
+        outs.append(torch.zeros(pl.getDomainSize() // esz, dtype=CDT[prec], device="cuda"))
+        backs.append(torch.zeros_like(ins[-1]))
+    torch.cuda.synchronize()
+    with ThreadPoolExecutor(P) as ex:
+        list(ex.map(lambda r: plans[r].execR2C(outs[r], ins[r]), range(P)))
+    spec = []
+    for r in range(P):
+        s = plans[r].getOutSize()
+        spec.append(outs[r][:s[0] * s[1] * s[2]].cpu().numpy().reshape(s))
+    if modify is not None:
+        for r in range(P):
+            s, o = plans[r].getOutSize(), plans[r].getOutStart()
+            blk = np.ascontiguousarray(spec[r].astype(np.complex128))
+            modify(blk, s, o)
+            outs[r][:blk.size] = torch.from_numpy(blk.astype(NPDT[prec]).ravel()).cuda()
+    torch.cuda.synchronize()
+    with ThreadPoolExecutor(P) as ex:
+        list(ex.map(lambda r: plans[r].execC2R(backs[r], outs[r]), range(P)))
+    torch.cuda.synchronize()
+    return plans, [t.cpu().numpy() for t in ins], spec, [t.cpu().numpy() for t in backs]
+
+
+REAL = [((8, 8, 8), 1, 1), ((16, 16, 16), 1, 1), ((32, 16, 64), 1, 1), ((128, 128, 128), 1, 1),
+        ((4, 4, 2048), 1, 1), ((16, 16, 16), 2, 2), ((32, 32, 32), 2, 4), ((64, 32, 16), 4, 2),
+        ((16, 16, 16), 3, 2), ((32, 16, 64), 2, 1), ((64, 64, 64), 3, 5), ((128, 64, 32), 2, 4)]
+
+
+@pytest.mark.parametrize("prec", ["double", "float"])
+@pytest.mark.parametrize("shape,P1,P2", REAL)
+def test_r2c_c2r_vs_oracle(shape, P1, P2, prec):
+    """execR2C output == oracle rfftn block (Hermitian half, uneven Nz/2+1 split) and
+    C2R(R2C(x)) == Nx*Ny*Nz*x (reference testcase 3, random_dist_3D.cu:641-666)"""
+    plans, ins, spec, backs = run_distributed_real(shape, P1, P2, prec)
+    g = orc.fill_block(shape, (0, 0, 0), shape, 1, seed=13).astype(NPR[prec]).astype(np.float64)
+    want = orc.fft3d_r2c(g)
+    n3 = float(np.prod(shape))
+    scale = np.max(np.abs(want))
+    for r, pl in enumerate(plans):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        ref = want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]]
+        assert np.max(np.abs(spec[r] - ref)) / scale < TOL_FWD[prec]
+        assert rel(backs[r] / n3, ins[r]) < TOL_RT[prec]
+
+
+@pytest.mark.parametrize("shape,P1,P2", [((32, 32, 32), 1, 1), ((32, 32, 32), 2, 4), ((64, 32, 16), 2, 2)])
+def test_testcase4_laplacian_known_answer(shape, P1, P2):
+    """reference testcase 4 (random_dist_3D.cu:685-811): u = sin sin sin, multiply the
+    distributed spectrum by -(k1^2+k2^2+k3^2)/sqrt(N^3), inverse, compare with -3 sqrt(N^3) u"""
+    Nx, Ny, Nz = shape
+    x, y, z = np.meshgrid(np.arange(Nx), np.arange(Ny), np.arange(Nz), indexing="ij")
+    u = np.sin(2 * np.pi * x / Nx) * np.sin(2 * np.pi * y / Ny) * np.sin(2 * np.pi * z / Nz)
+
+    def modify(blk, s, o):
+        orc.derivative_coefficients(blk, shape, o[2], o[1], half=True)
+
+    plans, ins, spec, backs = run_distributed_real(shape, P1, P2, "double", field=u, modify=modify)
+    n3 = float(Nx * Ny * Nz)
+    for r in range(len(plans)):
+        want = -3.0 * np.sqrt(n3) * ins[r]
+        assert np.max(np.abs(backs[r] - want)) < 1e-9 * np.sqrt(n3)
+
+
+def test_error_behaviour():
+    """bad arguments raise instead of exit(EXIT_FAILURE) (mpicufft_pencil_opt1.cpp:22-33, 61-65)"""
+    pl = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations())
+    with pytest.raises(dfft.DfftError, match="Invalid Input Partition"):
+        pl.initFFT(dfft.GlobalSize(16, 16, 16), dfft.Pencil_Partition(2, 2))
+    with pytest.raises(dfft.DfftError, match="not initialised"):
+        pl.execR2C(1, 1)
+    pl.initFFT(dfft.GlobalSize(16, 16, 16), dfft.Pencil_Partition(1, 1))
+    with pytest.raises(dfft.DfftError, match="C2C|R2C"):
+        pl.execC2C(1, 1)
+    with pytest.raises(dfft.DfftError, match="unsupported"):
+        pl.initFFT(dfft.GlobalSize(12, 16, 16), dfft.Pencil_Partition(1, 1))
