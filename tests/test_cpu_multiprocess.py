@@ -1,0 +1,42 @@
+"""N > 1 host path on CPU: world_size 2 (slab) and 4 (pencil 2x2, uneven) over gloo."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("P1,P2,shape", [(2, 1, "16x8x8"), (1, 2, "8x8x16"), (2, 2, "16x16x8"), (2, 2, "8x8x16"), (3, 2, "16x16x16"),
+                                         (3, 1, "16x16x8")])
+def test_gloo_exchange_path(P1, P2, shape):
+    world = P1 * P2
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_gloo_worker.py"), str(P1), str(P2), shape],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=180)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{out}"
+        assert f"rank {r} ok" in out
