@@ -34,19 +34,34 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=1024, help="cube edge (BASELINE: 1024)")
+    ap.add_argument("--size", type=int, default=1024, help="cube edge (BASELINE: 1024)")
     ap.add_argument("--precision", default="double", choices=["double", "float"])
     ap.add_argument("--p1", type=int, default=0)
     ap.add_argument("--p2", type=int, default=0)
     ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "torch"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo lets several ranks share one GPU (functional test)")
+    ap.add_argument("--decomp", default="auto", choices=["auto", "slab", "pencil"],
+                    help="auto = slab on one xGMI node (every GPU pair has its own link), pencil = BASELINE 2x4 / 2x2")
+    ap.add_argument("--no-alt", action="store_true", help="skip the alternative-decomposition measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=256, help="cube edge of the CPU-baseline sample")
     return ap.parse_args()
 
 
-def default_partition(n):
+def pencil_partition(n):
     # BASELINE.json configs: 1 GPU local passes; 2 GPUs slab; 8 GPUs 2x4 pencil; 4 GPUs 2x2 pencil
     return {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (2, 4)}.get(n, (n, 1))
+
+
+def choose_partition(n, decomp):
+    """On one xGMI node every GPU pair has a private link, so a P-way all-to-all drives P-1
+    links at once: slab (one exchange over all P ranks) moves (P-1)/P of the volume once over
+    P-1 links, pencil 2x4 moves 3/4 over 3 links and then 1/2 over a single link.
+    auto therefore picks slab; the BASELINE-named pencil grid is measured next to it."""
+    if decomp == "pencil":
+        return pencil_partition(n)
+    return (n, 1)
 
 
 def cpu_baseline(n):
@@ -94,35 +109,47 @@ def main():
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         ngpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
 
-    N = args.n
+    N = args.size
     prec = args.precision
     esz = 16 if prec == "double" else 8
     cdt = torch.complex128 if prec == "double" else torch.complex64
     rdt = torch.float64 if prec == "double" else torch.float32
-    P1, P2 = (args.p1, args.p2) if args.p1 and args.p2 else default_partition(ngpus)
+    P1, P2 = (args.p1, args.p2) if args.p1 and args.p2 else choose_partition(ngpus, args.decomp)
     assert P1 * P2 == ngpus
 
-    comm, transport = None, "none"
-    stream = torch.cuda.current_stream().cuda_stream
-    if world > 1:
-        from distributedfft_amd.torch_transport import make_comm
-        comm, transport = make_comm(dist, rank, world, P1, P2, args.transport)
+    # a dedicated (non-default) torch stream carries the plan's kernels AND, being torch's current
+    # stream inside `with torch.cuda.stream(side)`, the collectives of the torch transport
+    side = torch.cuda.Stream()
+    stream = side.cuda_stream
+    tmode = "torch" if args.backend == "gloo" else args.transport
 
-    kind = dfft.MPIcuFFT_Slab_Opt1 if P2 == 1 and ngpus > 1 else dfft.MPIcuFFT_Pencil_Opt1
-    plan = kind(dfft.Configurations(), comm, precision=prec, rank=rank)
-    plan.initFFT(dfft.GlobalSize(N, N, N), dfft.Partition(P1, P2), allocate=False, c2c=True)
+    def make_plan(P1, P2):
+        comm, transport = None, "none"
+        if world > 1:
+            from distributedfft_amd.torch_transport import make_comm
+            comm, transport = make_comm(dist, rank, world, P1, P2, tmode)
+        kind = dfft.MPIcuFFT_Slab_Opt1 if P2 == 1 and ngpus > 1 else dfft.MPIcuFFT_Pencil_Opt1
+        plan = kind(dfft.Configurations(), comm, precision=prec, rank=rank)
+        plan.initFFT(dfft.GlobalSize(N, N, N), dfft.Partition(P1, P2), allocate=False, c2c=True)
+        work = torch.empty(plan.getWorkSizeDevice(), dtype=torch.uint8, device="cuda")
+        plan.setStream(stream)
+        plan.setWorkArea(work)
+        if comm is not None and transport == "torch":
+            comm.register(work)
+        return plan, comm, transport, work
+
+    plan, comm, transport, work = make_plan(P1, P2)
     domain = plan.getDomainSize()
-    work = torch.empty(plan.getWorkSizeDevice(), dtype=torch.uint8, device="cuda")
-    plan.setStream(stream)
-    plan.setWorkArea(work)
-    if comm is not None and transport == "torch":
-        comm.register(work)
 
     # synthetic input: this rank's block of a uniform[0,255) complex grid (the reference scales
     # cuRAND uniforms by 255, tests/src/pencil/base.cu:45-53), generated on the device
@@ -141,6 +168,7 @@ def main():
     if comm is not None and transport == "torch":
         comm.register(d_out)
     ref_sample = d_in[:4096].clone()
+    torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:
@@ -148,8 +176,9 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        plan.execC2C(d_out, d_in, dfft.FORWARD)       # blocking, like the reference's exec
-        plan.execC2C(d_back, d_out, dfft.INVERSE)
+        with torch.cuda.stream(side):
+            plan.execC2C(d_out, d_in, dfft.FORWARD)       # blocking, like the reference's exec
+            plan.execC2C(d_back, d_out, dfft.INVERSE)
 
     for _ in range(args.warmup):
         step()
@@ -166,10 +195,11 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        plan.execC2C(d_out, d_in, dfft.FORWARD)
-        ph_f = plan.getPhaseTimes(dfft.FORWARD)
-        plan.execC2C(d_back, d_out, dfft.INVERSE)
-        ph_b = plan.getPhaseTimes(dfft.INVERSE)
+        with torch.cuda.stream(side):
+            plan.execC2C(d_out, d_in, dfft.FORWARD)
+            ph_f = plan.getPhaseTimes(dfft.FORWARD)
+            plan.execC2C(d_back, d_out, dfft.INVERSE)
+            ph_b = plan.getPhaseTimes(dfft.INVERSE)
         for name, ms in ph_f + ph_b:
             if "FFT" in name:
                 kern_ms += ms
@@ -182,6 +212,43 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # max over ranks of the per-phase device times as well
+        t = torch.tensor([kern_ms, exch_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kern_ms, exch_ms = float(t[0]), float(t[1])
+
+    # the BASELINE-named pencil grid (2x2 / 2x4) measured next to the chosen decomposition
+    alt = None
+    alt_part = pencil_partition(ngpus)
+    if world > 1 and not args.no_alt and alt_part != (P1, P2) and not (args.p1 and args.p2):
+        del d_back
+        plan2, comm2, transport2, work2 = make_plan(*alt_part)
+        isz2 = plan2.getInSize()
+        n2 = isz2[0] * isz2[1] * isz2[2]
+        a_in = d_in[:n2] if n2 <= d_in.numel() else torch.zeros(n2, dtype=cdt, device="cuda")
+        a_out = torch.empty(plan2.getDomainSize() // esz, dtype=cdt, device="cuda")
+        a_back = torch.empty(n2, dtype=cdt, device="cuda")
+        if comm2 is not None and transport2 == "torch":
+            comm2.register(a_out)
+        with torch.cuda.stream(side):
+            for _ in range(max(1, args.warmup)):
+                plan2.execC2C(a_out, a_in, dfft.FORWARD)
+                plan2.execC2C(a_back, a_out, dfft.INVERSE)
+        alt_rt = float((a_back / float(N) ** 3 - a_in).abs().max() / a_in.abs().max())
+        barrier()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(side):
+            for _ in range(args.steps):
+                plan2.execC2C(a_out, a_in, dfft.FORWARD)
+                plan2.execC2C(a_back, a_out, dfft.INVERSE)
+        barrier()
+        dt2 = time.perf_counter() - t0
+        t = torch.tensor([dt2], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt2 = float(t.item())
+        alt = {"decomposition": f"pencil {alt_part[0]}x{alt_part[1]} (BASELINE.json configs)", "transport": transport2,
+               "ms_per_step": round(dt2 / args.steps * 1e3, 3), "round_trip_rel_linf": alt_rt,
+               "value": round(2 * 5.0 * float(N) ** 3 * math.log2(float(N) ** 3) * args.steps / dt2 / 1e9, 1)}
 
     flops_step = 2 * 5.0 * float(N) ** 3 * math.log2(float(N) ** 3)
     ms_per_step = dt / args.steps * 1e3
@@ -212,6 +279,8 @@ def main():
             "round_trip_rel_linf": rt_err,
             "roofline": roofline,
         }
+        if alt is not None:
+            out["config"]["alt"] = alt
         if not args.no_cpu_baseline and ngpus == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_n)
         print(json.dumps(out), flush=True)

@@ -112,6 +112,7 @@ struct dfft_plan {
     void *tw_x = nullptr, *tw_y = nullptr, *tw_z = nullptr, *tw_zr = nullptr;   // tw_zr: split/merge table (R2C)
     hipStream_t stream = nullptr;
     bool stream_owned = false;
+    bool stream_user = false;    // caller chose the stream (the null stream is a valid choice)
     // exchange tables in bytes (row comm = 1, column comm = 2) and member lists
     std::vector<size_t> sc1, sd1, rc1, rd1, sc2, sd2, rc2, rd2;
     std::vector<int> group1, group2;
@@ -415,6 +416,18 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         p->group2[q] = q * P2 + p->pj;
     }
     TRY(build_passes(p));
+    // point-major (strided) API layouts: neighbouring workgroups step along the outer axis so
+    // that concurrent workgroups do not all sit 128 B apart in the same DRAM/L2 channel group
+    p->fwd[2].a_fastest = 1;
+    p->inv[2].a_fastest = 1;
+    if (const char *v = getenv("DFFT_ORDER")) {   // experiment hook: 6 digits like DFFT_VARIANTS
+        int k = 0;
+        for (const char *c = v; *c && k < 6; c++) {
+            if (*c < '0' || *c > '9') continue;
+            if (k < 3) p->fwd[k].a_fastest = *c - '0'; else p->inv[5 - k].a_fastest = *c - '0';
+            k++;
+        }
+    }
     // experiment hook: DFFT_VARIANTS="zyx xyz" digits = kernel variant of fwd z,y,x then inv x,y,z
     if (const char *v = getenv("DFFT_VARIANTS")) {
         int k = 0;
@@ -438,7 +451,7 @@ static int ensure_device_state(dfft_plan *p)
     if (!p->tw_y) TRY(make_twiddles(p->prec, p->Ny, &p->tw_y));
     if (!p->tw_z) TRY(make_twiddles(p->prec, p->c2c ? p->Nz : p->Nz / 2, &p->tw_z));
     if (!p->c2c && !p->tw_zr) TRY(make_twiddles(p->prec, p->Nz, &p->tw_zr));
-    if (!p->stream) {
+    if (!p->stream && !p->stream_user) {
         HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
         p->stream_owned = true;
     }
@@ -467,6 +480,7 @@ int dfft_set_stream(dfft_plan *p, void *hip_stream)
     if (p->stream_owned && p->stream) (void)hipStreamDestroy(p->stream);
     p->stream = (hipStream_t)hip_stream;
     p->stream_owned = false;
+    p->stream_user = true;
     return 0;
 }
 
@@ -492,7 +506,7 @@ int dfft_exchange(dfft_plan *p, int which, int direction, const void *sendbuf, v
     if (!p || !p->initialized) return fail(ERR_STATE, "plan not initialised");
     if (which != 1 && which != 2) return fail(ERR_ARG, "which must be 1 or 2");
     if ((which == 1 ? p->P2 : p->P1) > 1) TRY(exchange(p, which, direction != DFFT_INVERSE, sendbuf, recvbuf));
-    if (p->stream) HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->stream || p->stream_user) HIP_TRY(hipStreamSynchronize(p->stream));
     return 0;
 }
 

@@ -62,6 +62,7 @@ struct PassArgs {
     uint32_t ntiles;       // na * nb
     int32_t load_kind, store_kind;
     int32_t swap;          // 1 = inverse transform (swap re/im on load and on store)
+    int32_t a_fastest;     // workgroup -> tile order: 0: b fastest (w = a*nb + b), 1: a fastest (w = b*na + a)
     uint32_t LA;           // STORE_TILED_SAME: extent of the a axis
     uint32_t T2shift;      // STORE_TILED_TRANSPOSE: log2 of the consumer's tile size
     uint64_t KS_in;        // LOAD_KMAJOR point stride
@@ -294,7 +295,8 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
 
     const uint32_t w = blockIdx.x * Cfg::kG + g;            // tile index, b fastest
     const bool tile_ok = w < A.ntiles;
-    const uint32_t a = tile_ok ? w / A.nb : 0, b = tile_ok ? w % A.nb : 0;
+    const uint32_t a = !tile_ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
+    const uint32_t b = !tile_ok ? 0 : (A.a_fastest ? w / A.na : w % A.nb);
     const uint32_t rem = A.LB - b * TL;
     const uint32_t tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;   // valid lines of this tile
     const bool active = tile_ok && (uint32_t)l < tw;
@@ -437,7 +439,9 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
     const uint32_t w = blockIdx.x * Cfg::kG + g;
     const bool tile_ok = w < A.ntiles;
     TileCtx<TL> tc;
-    tc.a = tile_ok ? w / A.nb : 0; tc.b = tile_ok ? w % A.nb : 0; tc.l = l;
+    tc.a = !tile_ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
+    tc.b = !tile_ok ? 0 : (A.a_fastest ? w / A.na : w % A.nb);
+    tc.l = l;
     const uint32_t rem = A.LB - tc.b * TL;
     tc.tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;
     const bool active = tile_ok && (uint32_t)l < tc.tw;
@@ -502,7 +506,9 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
     const uint32_t w = blockIdx.x * Cfg::kG + g;
     const bool tile_ok = w < A.ntiles;
     TileCtx<TL> tc;
-    tc.a = tile_ok ? w / A.nb : 0; tc.b = tile_ok ? w % A.nb : 0; tc.l = l;
+    tc.a = !tile_ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
+    tc.b = !tile_ok ? 0 : (A.a_fastest ? w / A.na : w % A.nb);
+    tc.l = l;
     const uint32_t rem = A.LB - tc.b * TL;
     tc.tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;
     const bool active = tile_ok && (uint32_t)l < tc.tw;

@@ -11,6 +11,11 @@ pidx = pidx_i*P2 + pidx_j, src/pencil/mpicufft_pencil_opt1.cpp:67-68):
                can be mapped back to tensors.
   * "auto"  -- rccl if it can be created and passes a small round-trip self-test on every
                rank, otherwise torch.
+
+Stream contract: the plan must run on torch's *current* stream while the callback executes, i.e.
+create `side = torch.cuda.Stream()`, `plan.setStream(side.cuda_stream)` and call exec inside
+`with torch.cuda.stream(side):`.  (Launching on the legacy null stream next to torch's default
+stream was observed to race with gloo's staging copies on ROCm; a dedicated stream is exact.)
 """
 import torch
 
@@ -67,7 +72,8 @@ def _selftest(dist, comm, rank, world, P1, P2):
     n = 32
     plan = api.MPIcuFFT_Pencil_Opt1(api.Configurations(), comm, precision="double", rank=rank)
     plan.initFFT(api.GlobalSize(n, n, n), api.Partition(P1, P2), allocate=False, c2c=True)
-    plan.setStream(torch.cuda.current_stream().cuda_stream)
+    side = torch.cuda.Stream()
+    plan.setStream(side.cuda_stream)
     work = torch.empty(plan.getWorkSizeDevice(), dtype=torch.uint8, device="cuda")
     plan.setWorkArea(work)
     s = plan.getInSize()
@@ -79,8 +85,11 @@ def _selftest(dist, comm, rank, world, P1, P2):
     if isinstance(comm, TorchComm):
         comm.register(work)
         comm.register(out)
-    plan.execC2C(out, x, api.FORWARD)
-    plan.execC2C(back, out, api.INVERSE)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        plan.execC2C(out, x, api.FORWARD)
+        plan.execC2C(back, out, api.INVERSE)
+    torch.cuda.synchronize()
     err = ((back / float(n) ** 3 - x).abs().max() / x.abs().max()).reshape(1)
     dist.all_reduce(err, op=dist.ReduceOp.MAX)
     return float(err.item())
