@@ -254,15 +254,18 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = flops_step * args.steps / dt / 1e9
 
-    # roofline of the dominant kernel: fft_pass_kernel.  Algorithmic bytes per launch = read the
-    # local volume once + write it once = 2 * esz * N^3 / n_gpus.
+    # roofline of the dominant kernel: fft_pass_kernel.  One axis pass (one launch on a single
+    # GPU; `pipeline_chunks` launches when the pass is pipelined against an exchange) reads the
+    # local volume once and writes it once: algorithmic bytes = 2 * esz * N^3 / n_gpus
+    # (SURVEY.md 8d).  Duration = HIP events around the launches on the launch stream.
     bytes_launch = 2.0 * esz * float(N) ** 3 / ngpus
     avg_ms = kern_ms / max(kern_launches, 1)
     achieved = bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "kernel": "dfft::fft_pass_kernel", "avg_launch_ms": round(avg_ms, 4),
-                "launches_timed": kern_launches, "alg_bytes_per_launch": bytes_launch}
+                "launches_timed": kern_launches, "alg_bytes_per_launch": bytes_launch,
+                "launches_per_pass": plan.getPipelineChunks() if ngpus > 1 else 1}
 
     if rank == 0:
         out = {

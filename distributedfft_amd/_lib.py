@@ -29,6 +29,8 @@ SYMBOLS = [
     ("dfft_plan_destroy", _i, [_vp]),
     ("dfft_init", _i, [_vp, _sz, _sz, _sz, _i, _i, _i, _i]),
     ("dfft_set_work_area", _i, [_vp, _vp, _vp]),
+    ("dfft_set_pipeline_chunks", _i, [_vp, _i]),
+    ("dfft_get_pipeline_chunks", _i, [_vp]),
     ("dfft_set_stream", _i, [_vp, _vp]),
     ("dfft_exec_r2c", _i, [_vp, _vp, _vp]),
     ("dfft_exec_c2r", _i, [_vp, _vp, _vp]),

@@ -174,6 +174,13 @@ class MPIcuFFT:
         self._work = device
         check(lib().dfft_set_work_area(self._h, _ptr(device), _ptr(host)))
 
+    def setPipelineChunks(self, chunks):
+        """pipeline depth of the exchanges (before initFFT); 1 = no overlap, 0 = default"""
+        check(lib().dfft_set_pipeline_chunks(self._h, int(chunks)))
+
+    def getPipelineChunks(self):
+        return lib().dfft_get_pipeline_chunks(self._h)
+
     def setStream(self, stream):
         """HIP stream (int handle, e.g. torch.cuda.current_stream().cuda_stream)"""
         check(lib().dfft_set_stream(self._h, C.c_void_p(int(stream))))

@@ -96,6 +96,26 @@ static int make_twiddles(int prec, size_t N, void **dev)
 
 using namespace dfft;
 
+struct Launch {
+    PassArgs args;            // in/out/tw filled at enqueue time
+    size_t in_off = 0;        // byte offset added to the stage's input buffer
+    size_t out_off = 0;       // byte offset added to the stage's output buffer
+};
+struct A2A {
+    std::vector<size_t> sc, sd, rc, rd;   // bytes, absolute displacements in the stage buffers
+};
+
+struct Pipeline {
+    int C = 1;
+    std::vector<Launch> fz, fy, ix, iy, iz;   // per chunk
+    Launch fx;                                 // forward x pass (needs complete lines)
+    std::vector<A2A> f1, f2, i2, i1;          // per chunk exchange tables
+    std::vector<hipEvent_t> ev;               // reusable events
+    hipStream_t comm_stream = nullptr;
+};
+
+struct TimedSpan { hipEvent_t a = nullptr, b = nullptr; int phase = 0; bool used = false; };
+
 struct dfft_plan {
     int kind = DFFT_PENCIL_OPT1, prec = DFFT_F64;
     dfft_config cfg{};
@@ -116,101 +136,191 @@ struct dfft_plan {
     // exchange tables in bytes (row comm = 1, column comm = 2) and member lists
     std::vector<size_t> sc1, sd1, rc1, rd1, sc2, sd2, rc2, rd2;
     std::vector<int> group1, group2;
-    // pass descriptors without buffer pointers: [0]=z [1]=y [2]=x
-    PassArgs fwd[3], inv[3];
-    int vfwd[3] = {0, 0, 0}, vinv[3] = {0, 0, 0};   // kernel variant per pass
-    // phase timing
+    int vfwd[3] = {0, 0, 0}, vinv[3] = {0, 0, 0};   // kernel variant per pass: [0]=z [1]=y [2]=x
+    int chunks_req = 0;          // requested pipeline depth (0 = default)
+    Pipeline pl;
+    // phase timing: (start, stop) event pairs, phases 0..4 = z, exchange 1, y, exchange 2, x
     bool timing = false;
-    hipEvent_t ev[8] = {};
-    int nev = 0, last_dir = -1;
+    std::vector<TimedSpan> spans;
+    size_t nspans = 0;
+    int last_dir = -1;
 };
 
-static void seg_from(SegTable &t, const std::vector<size_t> &start, const std::vector<size_t> &len,
-                     const std::vector<size_t> &base_elems)
+// ------------------------------------------------------------------------------------------
+// Pipelined execution plan.
+//
+// Every axis pass that feeds an exchange is cut into C chunks along its outer line-set axis
+// (x for the forward z/y passes and the inverse y/z passes, ky for the inverse x pass).  Send
+// and receive buffers are laid out chunk-outermost, [chunk][peer block], so one (chunk, peer)
+// message is contiguous: chunk c is exchanged on the communication stream while chunk c+1 is
+// still being transformed on the compute stream.  This replaces the reference's only overlap
+// mechanism, the Peer2Peer modes with MPI_Waitany / the sender thread
+// (src/pencil/mpicufft_pencil_opt1.cpp:601-754, src/pencil/mpicufft_pencil.cpp:513-585), at
+// chunk instead of whole-peer granularity.  C = 1 reproduces the reference's message sizes and
+// displacements exactly (mpicufft_pencil_opt1.cpp:269-273, 315-319).
+// ------------------------------------------------------------------------------------------
+static void seg_push(SegTable &t, size_t start, size_t len, size_t base_elems)
 {
-    t.nseg = (int)start.size();
-    for (int s = 0; s < t.nseg; s++) {
-        t.start[s] = (uint32_t)start[s];
-        t.len[s] = (uint32_t)len[s];
-        t.base[s] = base_elems[s];
-    }
+    int s = t.nseg++;
+    t.start[s] = (uint32_t)start;
+    t.len[s] = (uint32_t)len;
+    t.base[s] = base_elems;
 }
 
-static int build_passes(dfft_plan *p)
+static int build_pipeline(dfft_plan *p, Pipeline &pl)
 {
-    const int TL = p->TL;
+    const int TL = p->TL, P1 = p->P1, P2 = p->P2, C = pl.C;
     const uint32_t T2shift = ilog2(TL);
     const size_t xs = p->xs[p->pi], ys = p->ys[p->pj], zs = p->zs[p->pj], yo = p->yo[p->pi];
-    const size_t e = p->esz;
-    auto elems = [&](const std::vector<size_t> &bytes) {
-        std::vector<size_t> v(bytes.size());
-        for (size_t i = 0; i < bytes.size(); i++) v[i] = bytes[i] / e;
-        return v;
-    };
-    const std::vector<size_t> sd1 = elems(p->sd1), rd1 = elems(p->rd1), sd2 = elems(p->sd2), rd2 = elems(p->rd2);
-    auto base = [&](uint32_t na, uint32_t LB, int lk, int sk, int swap) {
+    const size_t Nx = p->Nx, Ny = p->Ny, Nzc = p->Nzc, e = p->esz;
+    // bytes per input/output LINE of the z pass as the caller sees it (real lines in R2C mode)
+    const size_t zline_bytes = p->c2c ? p->Nz * e : p->Nz * (e / 2);
+    auto base = [&](size_t na, size_t LB, int lk, int sk, int swap) {
         PassArgs A;
         memset(&A, 0, sizeof(A));
-        A.na = na; A.LB = LB; A.nb = (LB + TL - 1) / TL; A.ntiles = A.na * A.nb;
+        A.na = (uint32_t)na; A.LB = (uint32_t)LB; A.nb = (uint32_t)((LB + TL - 1) / TL); A.ntiles = A.na * A.nb;
         A.load_kind = lk; A.store_kind = sk; A.swap = swap; A.T2shift = T2shift;
         return A;
     };
+    std::vector<size_t> xl, x0, kl, k0, tmp_l, tmp_0;
+    split(xs, C, xl, x0);       // my x range in chunks (forward z/y, inverse y/z passes)
+    split(yo, C, kl, k0);       // my ky range in chunks (inverse x pass)
+    // chunk c of every column peer's x / ky range (they split with the same rule)
+    std::vector<std::vector<size_t>> xlq(P1), x0q(P1), klq(P1), k0q(P1);
+    for (int q = 0; q < P1; q++) { split(p->xs[q], C, xlq[q], x0q[q]); split(p->yo[q], C, klq[q], k0q[q]); }
+
+    pl.fz.assign(C, Launch()); pl.fy.assign(C, Launch()); pl.ix.assign(C, Launch());
+    pl.iy.assign(C, Launch()); pl.iz.assign(C, Launch());
+    pl.f1.assign(C, A2A()); pl.f2.assign(C, A2A()); pl.i2.assign(C, A2A()); pl.i1.assign(C, A2A());
+
     // ---------------- forward (mpicufft_pencil_opt1.cpp:1422-1519) ----------------
-    {   // z pass: lines along z from the caller's [xs][ys][Nz]; tiles of TL adjacent y.
-        // Output = send buffer of exchange 1: block p = [x][kz/TL][y][kz%TL] for kz in zs[p].
-        PassArgs A = base((uint32_t)xs, (uint32_t)ys, LOAD_LINES, STORE_TILED_TRANSPOSE, 0);
-        seg_from(A.sseg, p->zstart, p->zs, sd1);
-        p->fwd[0] = A;
+    size_t R2c = 0;   // running element offset of chunk c in the exchange-2 receive buffer
+    {
+        PassArgs X = base(yo, zs, LOAD_TILED, STORE_KMAJOR, 0);
+        X.KS_out = (uint64_t)yo * zs;
+        X.a_fastest = 1;
+        // segments of the x axis, ascending: peer q major, chunk c minor
+        std::vector<size_t> r2c_of(C, 0);
+        { size_t acc = 0; for (int c = 0; c < C; c++) { r2c_of[c] = acc; for (int q = 0; q < P1; q++) acc += xlq[q][c] * yo * zs; } }
+        for (int q = 0; q < P1; q++)
+            for (int c = 0; c < C; c++) {
+                size_t off = r2c_of[c];
+                for (int q2 = 0; q2 < q; q2++) off += xlq[q2][c] * yo * zs;
+                if (xlq[q][c]) seg_push(X.lseg, p->xstart[q] + x0q[q][c], xlq[q][c], off);
+            }
+        pl.fx.args = X;
     }
-    {   // y pass: lines along y gathered from the P2 received blocks; tiles of TL adjacent kz.
-        // Output = send buffer of exchange 2: block p = [ky][kz/TL][x][kz%TL] for ky in yo[p].
-        PassArgs A = base((uint32_t)xs, (uint32_t)zs, LOAD_TILED, STORE_TILED_SAME, 0);
-        seg_from(A.lseg, p->ystart, p->ys, rd1);
-        seg_from(A.sseg, p->yostart, p->yo, sd2);
-        A.LA = (uint32_t)xs;
-        p->fwd[1] = A;
-    }
-    {   // x pass: lines along x gathered from the P1 received blocks; writes the API output
-        // [kx][y'][z'] (include/mpicufft_pencil.hpp:119-122).
-        PassArgs A = base((uint32_t)yo, (uint32_t)zs, LOAD_TILED, STORE_KMAJOR, 0);
-        seg_from(A.lseg, p->xstart, p->xs, rd2);
-        A.KS_out = (uint64_t)yo * zs;
-        p->fwd[2] = A;
+    for (int c = 0; c < C; c++) {
+        const size_t S1c = x0[c] * Nzc * ys, R1c = x0[c] * zs * Ny, S2c = x0[c] * zs * Ny;
+        {   // z pass chunk: natural lines -> send1 block (c,p) = [x][kz/TL][y][kz%TL], kz in zs[p]
+            Launch &L = pl.fz[c];
+            L.args = base(xl[c], ys, LOAD_LINES, STORE_TILED_TRANSPOSE, 0);
+            L.in_off = x0[c] * ys * zline_bytes;
+            for (int q = 0; q < P2; q++) seg_push(L.args.sseg, p->zstart[q], p->zs[q], S1c + xl[c] * p->zstart[q] * ys);
+        }
+        {   // exchange 1, row group (:269-273 restricted to the chunk)
+            A2A &T = pl.f1[c];
+            for (int q = 0; q < P2; q++) {
+                T.sc.push_back(e * xl[c] * p->zs[q] * ys);
+                T.sd.push_back(e * (S1c + xl[c] * p->zstart[q] * ys));
+                T.rc.push_back(e * xl[c] * p->ys[q] * zs);
+                T.rd.push_back(e * (R1c + xl[c] * p->ystart[q] * zs));
+            }
+        }
+        {   // y pass chunk: lines along y from the P2 blocks -> send2 block (c,p) = [ky][kz/TL][x][kz%TL]
+            Launch &L = pl.fy[c];
+            L.args = base(xl[c], zs, LOAD_TILED, STORE_TILED_SAME, 0);
+            for (int q = 0; q < P2; q++) seg_push(L.args.lseg, p->ystart[q], p->ys[q], R1c + xl[c] * p->ystart[q] * zs);
+            for (int q = 0; q < P1; q++) seg_push(L.args.sseg, p->yostart[q], p->yo[q], S2c + xl[c] * zs * p->yostart[q]);
+            L.args.LA = (uint32_t)xl[c];
+        }
+        {   // exchange 2, column group (:315-319 restricted to the chunk)
+            A2A &T = pl.f2[c];
+            size_t roff = R2c;
+            for (int q = 0; q < P1; q++) {
+                T.sc.push_back(e * xl[c] * zs * p->yo[q]);
+                T.sd.push_back(e * (S2c + xl[c] * zs * p->yostart[q]));
+                T.rc.push_back(e * xlq[q][c] * yo * zs);
+                T.rd.push_back(e * roff);
+                roff += xlq[q][c] * yo * zs;
+            }
+            R2c = roff;
+        }
     }
     // ---------------- inverse (mpicufft_pencil_opt1.cpp:1522-1600) ----------------
-    {   // x^-1: reads the API output layout point-major; block p = [x][kz/TL][ky][kz%TL], x in xs[p]
-        PassArgs A = base((uint32_t)yo, (uint32_t)zs, LOAD_KMAJOR, STORE_TILED_SAME, 1);
-        A.KS_in = (uint64_t)yo * zs;
-        seg_from(A.sseg, p->xstart, p->xs, rd2);
-        A.LA = (uint32_t)yo;
-        p->inv[2] = A;
+    std::vector<size_t> r2i_of(C, 0);
+    { size_t acc = 0; for (int c = 0; c < C; c++) { r2i_of[c] = acc; for (int q = 0; q < P1; q++) acc += xs * zs * klq[q][c]; } }
+    for (int c = 0; c < C; c++) {
+        const size_t S2i = k0[c] * zs * Nx;
+        {   // x^-1 chunk (ky range): API layout point-major -> block (c,p) = [x][kz/TL][ky][kz%TL], x in xs[p]
+            Launch &L = pl.ix[c];
+            L.args = base(kl[c], zs, LOAD_KMAJOR, STORE_TILED_SAME, 1);
+            L.args.KS_in = (uint64_t)yo * zs;
+            L.args.a_fastest = 1;
+            L.in_off = e * k0[c] * zs;
+            for (int q = 0; q < P1; q++) seg_push(L.args.sseg, p->xstart[q], p->xs[q], S2i + p->xstart[q] * zs * kl[c]);
+            L.args.LA = (uint32_t)kl[c];
+        }
+        {   // exchange 2 backwards
+            A2A &T = pl.i2[c];
+            size_t roff = r2i_of[c];
+            for (int q = 0; q < P1; q++) {
+                T.sc.push_back(e * p->xs[q] * zs * kl[c]);
+                T.sd.push_back(e * (S2i + p->xstart[q] * zs * kl[c]));
+                T.rc.push_back(e * xs * zs * klq[q][c]);
+                T.rd.push_back(e * roff);
+                roff += xs * zs * klq[q][c];
+            }
+        }
     }
-    {   // y^-1: lines along ky from the P1 blocks; block p = [x][y/TL][kz][y%TL], y in ys[p]
-        PassArgs A = base((uint32_t)xs, (uint32_t)zs, LOAD_TILED, STORE_TILED_TRANSPOSE, 1);
-        seg_from(A.lseg, p->yostart, p->yo, sd2);
-        seg_from(A.sseg, p->ystart, p->ys, rd1);
-        p->inv[1] = A;
-    }
-    {   // z^-1: lines along kz from the P2 blocks; writes natural [xs][ys][Nz]
-        PassArgs A = base((uint32_t)xs, (uint32_t)ys, LOAD_TILED, STORE_LINES, 1);
-        seg_from(A.lseg, p->zstart, p->zs, sd1);
-        p->inv[0] = A;
+    for (int c = 0; c < C; c++) {
+        const size_t S1i = x0[c] * Ny * zs, R1i = x0[c] * ys * Nzc;
+        {   // y^-1 chunk (x range): lines along ky from the (peer, ky-chunk) blocks ->
+            // block (c,p) = [x][y/TL][kz][y%TL], y in ys[p]
+            Launch &L = pl.iy[c];
+            L.args = base(xl[c], zs, LOAD_TILED, STORE_TILED_TRANSPOSE, 1);
+            for (int q = 0; q < P1; q++)
+                for (int c2 = 0; c2 < C; c2++) {
+                    size_t off = r2i_of[c2];
+                    for (int q2 = 0; q2 < q; q2++) off += xs * zs * klq[q2][c2];
+                    // the block is [x in xs][kz/TL][ky][kz%TL]: skip the x rows before this chunk
+                    if (klq[q][c2]) seg_push(L.args.lseg, p->yostart[q] + k0q[q][c2], klq[q][c2], off + x0[c] * klq[q][c2] * zs);
+                }
+            for (int q = 0; q < P2; q++) seg_push(L.args.sseg, p->ystart[q], p->ys[q], S1i + xl[c] * p->ystart[q] * zs);
+        }
+        {   // exchange 1 backwards
+            A2A &T = pl.i1[c];
+            for (int q = 0; q < P2; q++) {
+                T.sc.push_back(e * xl[c] * p->ys[q] * zs);
+                T.sd.push_back(e * (S1i + xl[c] * p->ystart[q] * zs));
+                T.rc.push_back(e * xl[c] * ys * p->zs[q]);
+                T.rd.push_back(e * (R1i + xl[c] * ys * p->zstart[q]));
+            }
+        }
+        {   // z^-1 chunk: lines along kz from the P2 blocks -> natural [x][y][z]
+            Launch &L = pl.iz[c];
+            L.args = base(xl[c], ys, LOAD_TILED, STORE_LINES, 1);
+            for (int q = 0; q < P2; q++) seg_push(L.args.lseg, p->zstart[q], p->zs[q], R1i + xl[c] * ys * p->zstart[q]);
+            L.out_off = x0[c] * ys * zline_bytes;
+        }
     }
     return 0;
 }
 
-static int run_pass(dfft_plan *p, const PassArgs &tmpl, int variant, size_t N, const void *tw, const void *in, void *out)
+static int launch(dfft_plan *p, const Launch &L, int variant, size_t N, const void *tw, const char *in, char *out)
 {
-    PassArgs A = tmpl;
-    A.in = in; A.out = out; A.tw = tw;
+    if (L.args.ntiles == 0) return 0;
+    PassArgs A = L.args;
+    A.in = in + L.in_off; A.out = out + L.out_off; A.tw = tw;
     return launch_pass(p->prec, (int)N, variant, A, p->stream);
 }
 
 // z pass of an R2C plan: M = Nz/2 point complex FFT + split (mode 1) / merge (mode 2)
-static int run_real_pass(dfft_plan *p, const PassArgs &tmpl, int mode, const void *in, void *out)
+static int launch_real(dfft_plan *p, const Launch &L, int mode, const char *in, char *out)
 {
-    PassArgs A = tmpl;
-    A.in = in; A.out = out; A.tw = p->tw_z; A.tw2 = p->tw_zr;
+    if (L.args.ntiles == 0) return 0;
+    PassArgs A = L.args;
+    A.in = in + L.in_off; A.out = out + L.out_off; A.tw = p->tw_z; A.tw2 = p->tw_zr;
     const int M = (int)(p->Nz / 2);
     int r = p->prec == DFFT_F64 ? launch_real_f64(M, mode, A, p->stream) : launch_real_f32(M, mode, A, p->stream);
     if (r == -1) return fail(ERR_UNSUPPORTED, "unsupported real line length " + std::to_string(p->Nz));
@@ -218,75 +328,167 @@ static int run_real_pass(dfft_plan *p, const PassArgs &tmpl, int mode, const voi
     return 0;
 }
 
-static int mark(dfft_plan *p)
-{
-    if (!p->timing) return 0;
-    if (p->nev >= 8) return 0;
-    if (!p->ev[p->nev]) HIP_TRY(hipEventCreate(&p->ev[p->nev]));
-    HIP_TRY(hipEventRecord(p->ev[p->nev], p->stream));
-    p->nev++;
-    return 0;
-}
-
-static int exchange(dfft_plan *p, int which, bool forward, const void *send, void *recv)
+static int exchange_tables(dfft_plan *p, int which, const A2A &T, bool forward, const char *send, char *recv,
+                           hipStream_t stream)
 {
     const bool first = which == 1;
     const std::vector<int> &grp = first ? p->group1 : p->group2;
     const int me = first ? p->pj : p->pi;
-    const std::vector<size_t> &sc = first ? p->sc1 : p->sc2, &sd = first ? p->sd1 : p->sd2;
-    const std::vector<size_t> &rc = first ? p->rc1 : p->rc2, &rd = first ? p->rd1 : p->rd2;
     if (!p->comm) return fail(ERR_STATE, "exchange without a communicator");
     // the inverse all-to-all swaps the send and receive tables (mpicufft_pencil_opt1.cpp:829-830)
     if (forward)
-        return p->comm->alltoallv(p->rank, send, sc.data(), sd.data(), recv, rc.data(), rd.data(), grp.data(),
-                                  (int)grp.size(), me, p->stream);
-    return p->comm->alltoallv(p->rank, send, rc.data(), rd.data(), recv, sc.data(), sd.data(), grp.data(),
-                              (int)grp.size(), me, p->stream);
+        return p->comm->alltoallv(p->rank, send, T.sc.data(), T.sd.data(), recv, T.rc.data(), T.rd.data(), grp.data(),
+                                  (int)grp.size(), me, stream);
+    return p->comm->alltoallv(p->rank, send, T.rc.data(), T.rd.data(), recv, T.sc.data(), T.sd.data(), grp.data(),
+                              (int)grp.size(), me, stream);
 }
 
-// forward chain, complex input.  Buffers: A = caller's out, B/C = work area halves.
-static int enqueue_forward(dfft_plan *p, void *out, const void *in)
+static int exchange(dfft_plan *p, int which, bool forward, const void *send, void *recv)
 {
-    char *A = static_cast<char *>(out), *B = static_cast<char *>(p->work_d), *C = B + p->domainsize;
-    p->nev = 0; p->last_dir = DFFT_FORWARD;
-    TRY(mark(p));
-    if (p->c2c) TRY(run_pass(p, p->fwd[0], p->vfwd[0], p->Nz, p->tw_z, in, A));
-    else TRY(run_real_pass(p, p->fwd[0], 1, in, A));
-    TRY(mark(p));
-    char *cur = A;
-    if (p->P2 > 1) { TRY(exchange(p, 1, true, A, B)); cur = B; }
-    TRY(mark(p));
-    char *ydst = (cur == B) ? C : B;
-    TRY(run_pass(p, p->fwd[1], p->vfwd[1], p->Ny, p->tw_y, cur, ydst));
-    cur = ydst;
-    TRY(mark(p));
-    if (p->P1 > 1) { char *dst = (cur == B) ? C : B; TRY(exchange(p, 2, true, cur, dst)); cur = dst; }
-    TRY(mark(p));
-    TRY(run_pass(p, p->fwd[2], p->vfwd[2], p->Nx, p->tw_x, cur, A));
-    TRY(mark(p));
+    A2A T;
+    T.sc = which == 1 ? p->sc1 : p->sc2; T.sd = which == 1 ? p->sd1 : p->sd2;
+    T.rc = which == 1 ? p->rc1 : p->rc2; T.rd = which == 1 ? p->rd1 : p->rd2;
+    return exchange_tables(p, which, T, forward, static_cast<const char *>(send), static_cast<char *>(recv), p->stream);
+}
+
+
+// ---- per-phase timing: (start, stop) event pairs on whatever stream the work runs on --------
+static int span_begin(dfft_plan *p, int phase, hipStream_t s)
+{
+    if (!p->timing) return 0;
+    if (p->nspans == p->spans.size()) p->spans.emplace_back();
+    TimedSpan &t = p->spans[p->nspans];
+    if (!t.a) { HIP_TRY(hipEventCreate(&t.a)); HIP_TRY(hipEventCreate(&t.b)); }
+    t.phase = phase; t.used = true;
+    HIP_TRY(hipEventRecord(t.a, s));
+    return 0;
+}
+static int span_end(dfft_plan *p, hipStream_t s)
+{
+    if (!p->timing) return 0;
+    HIP_TRY(hipEventRecord(p->spans[p->nspans].b, s));
+    p->nspans++;
     return 0;
 }
 
-// inverse chain, complex output.  `in` is scratch after the first pass, B = work area.
+static hipEvent_t pipe_event(dfft_plan *p, size_t i)
+{
+    Pipeline &pl = p->pl;
+    while (pl.ev.size() <= i) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        pl.ev.push_back(e);
+    }
+    return pl.ev[i];
+}
+#define EV_RECORD(i, stream) do { hipEvent_t pev_ = pipe_event(p, (i)); if (!pev_) return fail(1, "hipEventCreate failed"); HIP_TRY(hipEventRecord(pev_, (stream))); } while (0)
+#define EV_WAIT(i, stream) do { HIP_TRY(hipStreamWaitEvent((stream), pipe_event(p, (i)), 0)); } while (0)
+
+// forward chain.  Buffers: A = caller's out, W0..W2 = work area slices (one per exchange + 1).
+//   z: in -> A   [ex1: A -> W0]   y: -> next   [ex2: -> next]   x: -> A
+static int enqueue_forward(dfft_plan *p, void *out, const void *in)
+{
+    Pipeline &pl = p->pl;
+    const int C = pl.C;
+    char *A = static_cast<char *>(out), *W = static_cast<char *>(p->work_d);
+    const char *I = static_cast<const char *>(in);
+    int nextw = 0;
+    auto next_work = [&]() { return W + (size_t)(nextw++) * p->domainsize; };
+    char *zdst = A;
+    char *ysrc = p->P2 > 1 ? next_work() : A;
+    char *ydst = next_work();
+    char *xsrc = p->P1 > 1 ? next_work() : ydst;
+    hipStream_t Sc = p->stream, Sm = pl.comm_stream;
+    p->nspans = 0; p->last_dir = DFFT_FORWARD;
+    // event ids: [0,C) z done, [C,2C) ex1 done, [2C,3C) y done, [3C,4C) ex2 done, 4C = entry fence
+    if (p->comm) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); }     // comm stream starts after prior work
+    for (int c = 0; c < C; c++) {
+        TRY(span_begin(p, 0, Sc));
+        if (p->c2c) TRY(launch(p, pl.fz[c], p->vfwd[0], p->Nz, p->tw_z, I, zdst));
+        else TRY(launch_real(p, pl.fz[c], 1, I, zdst));
+        TRY(span_end(p, Sc));
+        if (p->P2 > 1) {
+            EV_RECORD(c, Sc);
+            EV_WAIT(c, Sm);
+            TRY(span_begin(p, 1, Sm));
+            TRY(exchange_tables(p, 1, pl.f1[c], true, zdst, ysrc, Sm));
+            TRY(span_end(p, Sm));
+            EV_RECORD(C + c, Sm);
+        }
+    }
+    for (int c = 0; c < C; c++) {
+        if (p->P2 > 1) EV_WAIT(C + c, Sc);
+        TRY(span_begin(p, 2, Sc));
+        TRY(launch(p, pl.fy[c], p->vfwd[1], p->Ny, p->tw_y, ysrc, ydst));
+        TRY(span_end(p, Sc));
+        if (p->P1 > 1) {
+            EV_RECORD(2 * C + c, Sc);
+            EV_WAIT(2 * C + c, Sm);
+            TRY(span_begin(p, 3, Sm));
+            TRY(exchange_tables(p, 2, pl.f2[c], true, ydst, xsrc, Sm));
+            TRY(span_end(p, Sm));
+            EV_RECORD(3 * C + c, Sm);
+        }
+    }
+    if (p->P1 > 1) EV_WAIT(3 * C + C - 1, Sc);     // the comm stream is in order: last chunk covers all
+    else if (p->P2 > 1) { /* y passes already waited for every ex1 chunk */ }
+    TRY(span_begin(p, 4, Sc));
+    TRY(launch(p, pl.fx, p->vfwd[2], p->Nx, p->tw_x, xsrc, A));
+    TRY(span_end(p, Sc));
+    return 0;
+}
+
+// inverse chain.  `in` (I) is scratch once every x^-1 chunk has read it.
+//   x^-1: I -> W0   [ex2: W0 -> W1]   y^-1: -> I   [ex1: I -> W0]   z^-1: -> out
 static int enqueue_inverse(dfft_plan *p, void *out, void *in)
 {
-    char *I = static_cast<char *>(in), *B = static_cast<char *>(p->work_d);
-    p->nev = 0; p->last_dir = DFFT_INVERSE;
-    TRY(mark(p));
-    TRY(run_pass(p, p->inv[2], p->vinv[2], p->Nx, p->tw_x, I, B));
-    TRY(mark(p));
-    char *cur = B;
-    if (p->P1 > 1) { TRY(exchange(p, 2, false, B, I)); cur = I; }
-    TRY(mark(p));
-    char *ydst = (cur == B) ? I : B;
-    TRY(run_pass(p, p->inv[1], p->vinv[1], p->Ny, p->tw_y, cur, ydst));
-    cur = ydst;
-    TRY(mark(p));
-    if (p->P2 > 1) { char *dst = (cur == B) ? I : B; TRY(exchange(p, 1, false, cur, dst)); cur = dst; }
-    TRY(mark(p));
-    if (p->c2c) TRY(run_pass(p, p->inv[0], p->vinv[0], p->Nz, p->tw_z, cur, out));
-    else TRY(run_real_pass(p, p->inv[0], 2, cur, out));
-    TRY(mark(p));
+    Pipeline &pl = p->pl;
+    const int C = pl.C;
+    char *I = static_cast<char *>(in), *W = static_cast<char *>(p->work_d), *O = static_cast<char *>(out);
+    char *W0 = W, *W1 = W + p->domainsize;
+    char *xdst = W0;
+    char *ysrc = p->P1 > 1 ? W1 : W0;
+    char *ydst = I;
+    char *zsrc = p->P2 > 1 ? (p->P1 > 1 ? W0 : W1) : I;   // W0 is still read by y^-1 when there is no exchange 2
+    hipStream_t Sc = p->stream, Sm = pl.comm_stream;
+    p->nspans = 0; p->last_dir = DFFT_INVERSE;
+    if (p->comm) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); }
+    for (int c = 0; c < C; c++) {
+        TRY(span_begin(p, 0, Sc));
+        TRY(launch(p, pl.ix[c], p->vinv[2], p->Nx, p->tw_x, I, xdst));
+        TRY(span_end(p, Sc));
+        if (p->P1 > 1) {
+            EV_RECORD(c, Sc);
+            EV_WAIT(c, Sm);
+            TRY(span_begin(p, 1, Sm));
+            TRY(exchange_tables(p, 2, pl.i2[c], true, xdst, ysrc, Sm));    // i2/i1 tables are already in send/recv order
+            TRY(span_end(p, Sm));
+            EV_RECORD(C + c, Sm);
+        }
+    }
+    // y^-1 needs complete ky lines: every chunk of exchange 2 must have landed.  It also
+    // overwrites I, which every x^-1 chunk has read by now (same stream).
+    if (p->P1 > 1) EV_WAIT(C + C - 1, Sc);
+    for (int c = 0; c < C; c++) {
+        TRY(span_begin(p, 2, Sc));
+        TRY(launch(p, pl.iy[c], p->vinv[1], p->Ny, p->tw_y, ysrc, ydst));
+        TRY(span_end(p, Sc));
+        if (p->P2 > 1) {
+            EV_RECORD(2 * C + c, Sc);
+            EV_WAIT(2 * C + c, Sm);
+            TRY(span_begin(p, 3, Sm));
+            TRY(exchange_tables(p, 1, pl.i1[c], true, ydst, zsrc, Sm));
+            TRY(span_end(p, Sm));
+            EV_RECORD(3 * C + c, Sm);
+        }
+    }
+    for (int c = 0; c < C; c++) {
+        if (p->P2 > 1) EV_WAIT(3 * C + c, Sc);
+        TRY(span_begin(p, 4, Sc));
+        if (p->c2c) TRY(launch(p, pl.iz[c], p->vinv[0], p->Nz, p->tw_z, zsrc, O));
+        else TRY(launch_real(p, pl.iz[c], 2, zsrc, O));
+        TRY(span_end(p, Sc));
+    }
     return 0;
 }
 
@@ -357,7 +559,9 @@ int dfft_plan_destroy(dfft_plan *p)
     if (!p) return 0;
     if (p->work_owned && p->work_d) (void)hipFree(p->work_d);
     for (void *t : {p->tw_x, p->tw_y, p->tw_z, p->tw_zr}) if (t) (void)hipFree(t);
-    for (auto &e : p->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &t : p->spans) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
+    for (auto &e : p->pl.ev) if (e) (void)hipEventDestroy(e);
+    if (p->pl.comm_stream) (void)hipStreamDestroy(p->pl.comm_stream);
     if (p->stream_owned && p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
     return 0;
@@ -370,7 +574,7 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
     if (P1 < 1 || P2 < 1 || P1 * P2 != p->nranks) return fail(ERR_ARG, "Invalid Input Partition!");
     if ((p->kind == DFFT_SLAB || p->kind == DFFT_SLAB_OPT1) && P2 != 1)
         return fail(ERR_ARG, "slab decomposition needs P2 == 1");
-    if (P1 > MAXSEG || P2 > MAXSEG) return fail(ERR_UNSUPPORTED, "more than 16 ranks per exchange group");
+    if (P1 > MAXSEG || P2 > MAXSEG) return fail(ERR_UNSUPPORTED, "more than 32 ranks per exchange group");
     if ((size_t)P1 > Nx || (size_t)P1 > Ny || (size_t)P2 > Ny) return fail(ERR_ARG, "partition larger than the grid");
     PassInfo pinfo;
     if (!c2c && (Nz % 2 || Nz < 4 || Nz > 2048))
@@ -394,7 +598,7 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
     p->domainsize = p->domain_elems * p->esz;
     p->domainsize = (p->domainsize + 255) & ~(size_t)255;
     const int nexch = (P1 > 1) + (P2 > 1);
-    p->worksize_d = p->domainsize * (nexch ? 2 : 1);
+    p->worksize_d = p->domainsize * (size_t)(nexch + 1);   // one slice per exchange + 1
     // all-to-all tables in bytes (:269-273, :315-319)
     const size_t e = p->esz;
     p->sc1.assign(P2, 0); p->sd1.assign(P2, 0); p->rc1.assign(P2, 0); p->rd1.assign(P2, 0);
@@ -415,19 +619,18 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         p->rd2[q] = e * p->xstart[q] * yo * zs;
         p->group2[q] = q * P2 + p->pj;
     }
-    TRY(build_passes(p));
-    // point-major (strided) API layouts: neighbouring workgroups step along the outer axis so
-    // that concurrent workgroups do not all sit 128 B apart in the same DRAM/L2 channel group
-    p->fwd[2].a_fastest = 1;
-    p->inv[2].a_fastest = 1;
-    if (const char *v = getenv("DFFT_ORDER")) {   // experiment hook: 6 digits like DFFT_VARIANTS
-        int k = 0;
-        for (const char *c = v; *c && k < 6; c++) {
-            if (*c < '0' || *c > '9') continue;
-            if (k < 3) p->fwd[k].a_fastest = *c - '0'; else p->inv[5 - k].a_fastest = *c - '0';
-            k++;
-        }
+    // pipeline depth: chunks of the outer axis exchanged while the next chunk is transformed
+    {
+        int C = p->chunks_req;
+        if (C <= 0) if (const char *v = getenv("DFFT_CHUNKS")) C = atoi(v);
+        if (C <= 0) C = nexch ? 4 : 1;
+        size_t lim = (size_t)MAXSEG / (size_t)P1;            // segments of the x / ky axis = P1 * C
+        for (int q = 0; q < P1; q++) lim = std::min({lim, p->xs[q], p->yo[q]});
+        if ((size_t)C > lim) C = (int)lim;
+        if (C < 1) C = 1;
+        p->pl.C = C;
     }
+    TRY(build_pipeline(p, p->pl));
     // experiment hook: DFFT_VARIANTS="zyx xyz" digits = kernel variant of fwd z,y,x then inv x,y,z
     if (const char *v = getenv("DFFT_VARIANTS")) {
         int k = 0;
@@ -455,6 +658,7 @@ static int ensure_device_state(dfft_plan *p)
         HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
         p->stream_owned = true;
     }
+    if (p->comm && !p->pl.comm_stream) HIP_TRY(hipStreamCreateWithFlags(&p->pl.comm_stream, hipStreamNonBlocking));
     return 0;
 }
 
@@ -473,6 +677,16 @@ int dfft_set_work_area(dfft_plan *p, void *device, void *host)
     }
     return 0;
 }
+
+int dfft_set_pipeline_chunks(dfft_plan *p, int chunks)
+{
+    if (!p) return fail(ERR_ARG, "null plan");
+    if (chunks < 0) return fail(ERR_ARG, "chunks must be >= 0");
+    if (p->initialized) return fail(ERR_STATE, "set the pipeline depth before initFFT");
+    p->chunks_req = chunks;
+    return 0;
+}
+int dfft_get_pipeline_chunks(const dfft_plan *p) { return p ? p->pl.C : 0; }
 
 int dfft_set_stream(dfft_plan *p, void *hip_stream)
 {
@@ -580,11 +794,16 @@ int dfft_enable_phase_timing(dfft_plan *p, int enable)
 int dfft_get_phase_times(dfft_plan *p, float *ms, int max_entries)
 {
     if (!p) return fail(ERR_ARG, "null plan");
-    int n = 0;
-    for (int i = 0; i + 1 < p->nev && n < max_entries; i++, n++) {
-        if (hipEventElapsedTime(&ms[n], p->ev[i], p->ev[i + 1]) != hipSuccess) ms[n] = -1.f;
+    // sums per phase over all chunks: 0 first FFT pass, 1 first exchange, 2 second pass,
+    // 3 second exchange, 4 last pass (overlapping spans are both counted in full)
+    float acc[5] = {0, 0, 0, 0, 0};
+    for (size_t i = 0; i < p->nspans; i++) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, p->spans[i].a, p->spans[i].b) == hipSuccess) acc[p->spans[i].phase] += t;
     }
-    return n;
+    int n = 0;
+    for (; n < 5 && n < max_entries; n++) ms[n] = acc[n];
+    return p->nspans ? n : 0;
 }
 const char *dfft_phase_name(int phase, int direction)
 {

@@ -30,7 +30,7 @@
 
 namespace dfft {
 
-constexpr int MAXSEG = 16;   // max peers in one exchange group
+constexpr int MAXSEG = 32;   // max segments of a gathered/scattered axis (peers x pipeline chunks)
 
 enum LoadKind : int {
     LOAD_LINES = 0,    // natural lines:        (a*LB + b*TL + l)*N + n

@@ -53,8 +53,18 @@ class TorchComm:
             assert sd[q] == sd[q - 1] + sc[q - 1] and rd[q] == rd[q - 1] + rc[q - 1]
         s = self._slice(send + sd[0], sum(sc)).view(torch.int64)
         r = self._slice(recv + rd[0], sum(rc)).view(torch.int64)
-        self.dist.all_to_all_single(r, s, output_split_sizes=[c // 8 for c in rc],
-                                    input_split_sizes=[c // 8 for c in sc], group=self.groups[tuple(group)])
+
+        def run():
+            self.dist.all_to_all_single(r, s, output_split_sizes=[c // 8 for c in rc],
+                                        input_split_sizes=[c // 8 for c in sc], group=self.groups[tuple(group)])
+
+        if s.is_cuda:
+            # the library hands over the HIP stream this exchange is ordered on (its communication
+            # stream); torch collectives order themselves against torch's *current* stream
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream or 0)):
+                run()
+        else:
+            run()
         self.calls += 1
 
     # duck-typing so a TorchComm can be passed wherever a Comm is expected

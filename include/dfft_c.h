@@ -98,6 +98,13 @@ int dfft_init(dfft_plan *plan, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, 
 /* setWorkArea(void *device, void *host)   mpicufft_pencil_opt1.cpp:329-387.  NULL device =
  * library allocates dfft_work_size_device() bytes. */
 int dfft_set_work_area(dfft_plan *plan, void *device, void *host);
+/* Pipeline depth of the exchanges: every pass that feeds an all-to-all is cut into `chunks`
+ * pieces so that chunk c travels (communication stream) while chunk c+1 is transformed (compute
+ * stream).  The reference's counterpart is the Peer2Peer overlap of
+ * src/pencil/mpicufft_pencil_opt1.cpp:601-754.  Call before dfft_init; 0 = default (4 when the
+ * plan has an exchange, else 1), 1 = no pipelining = the reference's exact message sizes. */
+int dfft_set_pipeline_chunks(dfft_plan *plan, int chunks);
+int dfft_get_pipeline_chunks(const dfft_plan *plan);
 /* HIP stream all kernels/exchanges are enqueued on (default: a stream owned by the plan) */
 int dfft_set_stream(dfft_plan *plan, void *hip_stream);
 

@@ -63,7 +63,7 @@ def test_plan_algebra_matches_reference_formulas(shape, P1, P2, c2c, prec):
         dom = opl.domain_elems(r) * esz
         assert dom <= pl.getDomainSize() < dom + 256
         nexch = (P1 > 1) + (P2 > 1)
-        assert pl.getWorkSizeDevice() == pl.getDomainSize() * (2 if nexch else 1)
+        assert pl.getWorkSizeDevice() == pl.getDomainSize() * (nexch + 1)
         for which in (1, 2):
             assert pl.getExchangeTables(which) == [[v * esz for v in t] for t in opl.exchange_tables(r, which)]
 

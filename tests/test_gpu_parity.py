@@ -77,7 +77,7 @@ def test_golden_fixture_single_rank():
     assert rel(got, d["c2c_8x8x8"]) < 1e-11
 
 
-def run_distributed(shape, P1, P2, prec, seed=7):
+def run_distributed(shape, P1, P2, prec, seed=7, chunks=None):
     """P1*P2 virtual ranks on one GPU (one host thread per rank, like MPI ranks sharing a
     device: tests/src/pencil/random_dist_3D.cu:175-177)."""
     P = P1 * P2
@@ -86,6 +86,8 @@ def run_distributed(shape, P1, P2, prec, seed=7):
     plans, ins, outs, backs = [], [], [], []
     for r in range(P):
         pl = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), world, precision=prec, rank=r)
+        if chunks is not None:
+            pl.setPipelineChunks(chunks)
         pl.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(P1, P2), True, c2c=True)
         size, start = pl.getInSize(), pl.getInStart()
         blk = orc.fill_block(shape, start, size, 2, seed=seed).astype(NPDT[prec])
@@ -228,3 +230,19 @@ def test_error_behaviour():
         pl.execC2C(1, 1)
     with pytest.raises(dfft.DfftError, match="unsupported"):
         pl.initFFT(dfft.GlobalSize(12, 16, 16), dfft.Pencil_Partition(1, 1))
+
+
+@pytest.mark.parametrize("chunks", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("shape,P1,P2", [((32, 32, 32), 2, 4), ((16, 16, 16), 3, 2), ((64, 32, 16), 8, 1), ((16, 32, 16), 1, 4)])
+def test_pipelined_exchange_chunks(shape, P1, P2, chunks):
+    """the chunked two-stream pipeline (compute of chunk c+1 overlapped with the exchange of chunk c)
+    gives the same result for every depth, including depths that do not divide the extents"""
+    plans, ins, spec, backs = run_distributed(shape, P1, P2, "double", chunks=chunks)
+    assert 1 <= plans[0].getPipelineChunks() <= chunks
+    want = orc.fft3d_c2c(orc.fill_block(shape, (0, 0, 0), shape, 2, seed=7), -1)
+    n3 = float(np.prod(shape))
+    for r, pl in enumerate(plans):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        ref = want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]]
+        assert np.max(np.abs(spec[r] - ref)) / np.max(np.abs(want)) < 1e-11
+        assert rel(backs[r] / n3, ins[r]) < 1e-10
