@@ -267,6 +267,16 @@ def main():
                 "launches_timed": kern_launches, "alg_bytes_per_launch": bytes_launch,
                 "launches_per_pass": plan.getPipelineChunks() if ngpus > 1 else 1}
 
+    # HBM bytes per launch from the committed PMC profile of this kernel on this workload
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 read correction applied)
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        if ngpus == 1 and N == 1024 and prec == "double":
+            roofline["traffic"] = pm["hbm_bytes_per_launch"]
+            roofline["traffic_source"] = "profiles/r1_pmc_traffic.json"
+    except Exception:   # noqa: BLE001
+        pass
+
     if rank == 0:
         out = {
             "metric": "3D FFT GFLOP/s (5N^3 log2 N^3 per direction), forward+inverse",
