@@ -97,7 +97,9 @@ static int make_twiddles(int prec, size_t N, void **dev)
 using namespace dfft;
 
 struct Launch {
-    PassArgs args;            // in/out/tw filled at enqueue time
+    PassArgs args;            // in/out/tw and the device table pointers are filled at enqueue time
+    SegTable lseg{}, sseg{};  // host copies of the segment tables (uploaded by upload_tables)
+    size_t ltab = 0, stab = 0;   // byte offsets of the tables in the plan's device table buffer
     size_t in_off = 0;        // byte offset added to the stage's input buffer
     size_t out_off = 0;       // byte offset added to the stage's output buffer
 };
@@ -130,6 +132,7 @@ struct dfft_plan {
     void *work_d = nullptr;
     bool work_owned = false;
     void *tw_x = nullptr, *tw_y = nullptr, *tw_z = nullptr, *tw_zr = nullptr;   // tw_zr: split/merge table (R2C)
+    void *tables_d = nullptr;    // segment tables of every launch, device copy
     hipStream_t stream = nullptr;
     bool stream_owned = false;
     bool stream_user = false;    // caller chose the stream (the null stream is a valid choice)
@@ -206,7 +209,7 @@ static int build_pipeline(dfft_plan *p, Pipeline &pl)
             for (int c = 0; c < C; c++) {
                 size_t off = r2c_of[c];
                 for (int q2 = 0; q2 < q; q2++) off += xlq[q2][c] * yo * zs;
-                if (xlq[q][c]) seg_push(X.lseg, p->xstart[q] + x0q[q][c], xlq[q][c], off);
+                if (xlq[q][c]) seg_push(pl.fx.lseg, p->xstart[q] + x0q[q][c], xlq[q][c], off);
             }
         pl.fx.args = X;
     }
@@ -216,7 +219,7 @@ static int build_pipeline(dfft_plan *p, Pipeline &pl)
             Launch &L = pl.fz[c];
             L.args = base(xl[c], ys, LOAD_LINES, STORE_TILED_TRANSPOSE, 0);
             L.in_off = x0[c] * ys * zline_bytes;
-            for (int q = 0; q < P2; q++) seg_push(L.args.sseg, p->zstart[q], p->zs[q], S1c + xl[c] * p->zstart[q] * ys);
+            for (int q = 0; q < P2; q++) seg_push(L.sseg, p->zstart[q], p->zs[q], S1c + xl[c] * p->zstart[q] * ys);
         }
         {   // exchange 1, row group (:269-273 restricted to the chunk)
             A2A &T = pl.f1[c];
@@ -230,8 +233,8 @@ static int build_pipeline(dfft_plan *p, Pipeline &pl)
         {   // y pass chunk: lines along y from the P2 blocks -> send2 block (c,p) = [ky][kz/TL][x][kz%TL]
             Launch &L = pl.fy[c];
             L.args = base(xl[c], zs, LOAD_TILED, STORE_TILED_SAME, 0);
-            for (int q = 0; q < P2; q++) seg_push(L.args.lseg, p->ystart[q], p->ys[q], R1c + xl[c] * p->ystart[q] * zs);
-            for (int q = 0; q < P1; q++) seg_push(L.args.sseg, p->yostart[q], p->yo[q], S2c + xl[c] * zs * p->yostart[q]);
+            for (int q = 0; q < P2; q++) seg_push(L.lseg, p->ystart[q], p->ys[q], R1c + xl[c] * p->ystart[q] * zs);
+            for (int q = 0; q < P1; q++) seg_push(L.sseg, p->yostart[q], p->yo[q], S2c + xl[c] * zs * p->yostart[q]);
             L.args.LA = (uint32_t)xl[c];
         }
         {   // exchange 2, column group (:315-319 restricted to the chunk)
@@ -258,7 +261,7 @@ static int build_pipeline(dfft_plan *p, Pipeline &pl)
             L.args.KS_in = (uint64_t)yo * zs;
             L.args.a_fastest = 1;
             L.in_off = e * k0[c] * zs;
-            for (int q = 0; q < P1; q++) seg_push(L.args.sseg, p->xstart[q], p->xs[q], S2i + p->xstart[q] * zs * kl[c]);
+            for (int q = 0; q < P1; q++) seg_push(L.sseg, p->xstart[q], p->xs[q], S2i + p->xstart[q] * zs * kl[c]);
             L.args.LA = (uint32_t)kl[c];
         }
         {   // exchange 2 backwards
@@ -284,9 +287,9 @@ static int build_pipeline(dfft_plan *p, Pipeline &pl)
                     size_t off = r2i_of[c2];
                     for (int q2 = 0; q2 < q; q2++) off += xs * zs * klq[q2][c2];
                     // the block is [x in xs][kz/TL][ky][kz%TL]: skip the x rows before this chunk
-                    if (klq[q][c2]) seg_push(L.args.lseg, p->yostart[q] + k0q[q][c2], klq[q][c2], off + x0[c] * klq[q][c2] * zs);
+                    if (klq[q][c2]) seg_push(L.lseg, p->yostart[q] + k0q[q][c2], klq[q][c2], off + x0[c] * klq[q][c2] * zs);
                 }
-            for (int q = 0; q < P2; q++) seg_push(L.args.sseg, p->ystart[q], p->ys[q], S1i + xl[c] * p->ystart[q] * zs);
+            for (int q = 0; q < P2; q++) seg_push(L.sseg, p->ystart[q], p->ys[q], S1i + xl[c] * p->ystart[q] * zs);
         }
         {   // exchange 1 backwards
             A2A &T = pl.i1[c];
@@ -300,7 +303,7 @@ static int build_pipeline(dfft_plan *p, Pipeline &pl)
         {   // z^-1 chunk: lines along kz from the P2 blocks -> natural [x][y][z]
             Launch &L = pl.iz[c];
             L.args = base(xl[c], ys, LOAD_TILED, STORE_LINES, 1);
-            for (int q = 0; q < P2; q++) seg_push(L.args.lseg, p->zstart[q], p->zs[q], R1i + xl[c] * ys * p->zstart[q]);
+            for (int q = 0; q < P2; q++) seg_push(L.lseg, p->zstart[q], p->zs[q], R1i + xl[c] * ys * p->zstart[q]);
             L.out_off = x0[c] * ys * zline_bytes;
         }
     }
@@ -312,6 +315,9 @@ static int launch(dfft_plan *p, const Launch &L, int variant, size_t N, const vo
     if (L.args.ntiles == 0) return 0;
     PassArgs A = L.args;
     A.in = in + L.in_off; A.out = out + L.out_off; A.tw = tw;
+    A.lseg = reinterpret_cast<const SegTable *>(static_cast<const char *>(p->tables_d) + L.ltab);
+    A.sseg = reinterpret_cast<const SegTable *>(static_cast<const char *>(p->tables_d) + L.stab);
+    A.lnseg = L.lseg.nseg; A.snseg = L.sseg.nseg;
     return launch_pass(p->prec, (int)N, variant, A, p->stream);
 }
 
@@ -321,6 +327,9 @@ static int launch_real(dfft_plan *p, const Launch &L, int mode, const char *in, 
     if (L.args.ntiles == 0) return 0;
     PassArgs A = L.args;
     A.in = in + L.in_off; A.out = out + L.out_off; A.tw = p->tw_z; A.tw2 = p->tw_zr;
+    A.lseg = reinterpret_cast<const SegTable *>(static_cast<const char *>(p->tables_d) + L.ltab);
+    A.sseg = reinterpret_cast<const SegTable *>(static_cast<const char *>(p->tables_d) + L.stab);
+    A.lnseg = L.lseg.nseg; A.snseg = L.sseg.nseg;
     const int M = (int)(p->Nz / 2);
     int r = p->prec == DFFT_F64 ? launch_real_f64(M, mode, A, p->stream) : launch_real_f32(M, mode, A, p->stream);
     if (r == -1) return fail(ERR_UNSUPPORTED, "unsupported real line length " + std::to_string(p->Nz));
@@ -558,7 +567,7 @@ int dfft_plan_destroy(dfft_plan *p)
 {
     if (!p) return 0;
     if (p->work_owned && p->work_d) (void)hipFree(p->work_d);
-    for (void *t : {p->tw_x, p->tw_y, p->tw_z, p->tw_zr}) if (t) (void)hipFree(t);
+    for (void *t : {p->tw_x, p->tw_y, p->tw_z, p->tw_zr, p->tables_d}) if (t) (void)hipFree(t);
     for (auto &t : p->spans) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
     for (auto &e : p->pl.ev) if (e) (void)hipEventDestroy(e);
     if (p->pl.comm_stream) (void)hipStreamDestroy(p->pl.comm_stream);
@@ -631,6 +640,13 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         p->pl.C = C;
     }
     TRY(build_pipeline(p, p->pl));
+    // the inverse x pass reads the point-major API layout: use the strided-read configuration
+    // (variant 1) where one exists for this length
+    {
+        PassInfo vi;
+        const bool has = p->prec == DFFT_F64 ? pass_info_f64((int)Nx, 1, &vi) : false;
+        p->vinv[2] = has ? 1 : 0;
+    }
     // experiment hook: DFFT_VARIANTS="zyx xyz" digits = kernel variant of fwd z,y,x then inv x,y,z
     if (const char *v = getenv("DFFT_VARIANTS")) {
         int k = 0;
@@ -640,7 +656,7 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
             k++;
         }
     }
-    for (void **t : {&p->tw_x, &p->tw_y, &p->tw_z, &p->tw_zr}) if (*t) { (void)hipFree(*t); *t = nullptr; }
+    for (void **t : {&p->tw_x, &p->tw_y, &p->tw_z, &p->tw_zr, &p->tables_d}) if (*t) { (void)hipFree(*t); *t = nullptr; }
     p->initialized = true;
     // device-side state (twiddles, stream, work area) is created by setWorkArea, so that the
     // decomposition tables can be queried on a host without a GPU (allocate = 0).
@@ -648,8 +664,27 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
     return 0;
 }
 
+static int upload_tables(dfft_plan *p)
+{
+    Pipeline &pl = p->pl;
+    std::vector<Launch *> all;
+    for (auto *v : {&pl.fz, &pl.fy, &pl.ix, &pl.iy, &pl.iz}) for (auto &L : *v) all.push_back(&L);
+    all.push_back(&pl.fx);
+    std::vector<char> host(all.size() * 2 * sizeof(SegTable));
+    size_t off = 0;
+    for (Launch *L : all) {
+        L->ltab = off; memcpy(host.data() + off, &L->lseg, sizeof(SegTable)); off += sizeof(SegTable);
+        L->stab = off; memcpy(host.data() + off, &L->sseg, sizeof(SegTable)); off += sizeof(SegTable);
+    }
+    if (p->tables_d) { (void)hipFree(p->tables_d); p->tables_d = nullptr; }
+    HIP_TRY(hipMalloc(&p->tables_d, host.size()));
+    HIP_TRY(hipMemcpy(p->tables_d, host.data(), host.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
 static int ensure_device_state(dfft_plan *p)
 {
+    if (!p->tables_d) TRY(upload_tables(p));
     if (!p->tw_x) TRY(make_twiddles(p->prec, p->Nx, &p->tw_x));
     if (!p->tw_y) TRY(make_twiddles(p->prec, p->Ny, &p->tw_y));
     if (!p->tw_z) TRY(make_twiddles(p->prec, p->c2c ? p->Nz : p->Nz / 2, &p->tw_z));

@@ -67,7 +67,10 @@ struct PassArgs {
     uint32_t T2shift;      // STORE_TILED_TRANSPOSE: log2 of the consumer's tile size
     uint64_t KS_in;        // LOAD_KMAJOR point stride
     uint64_t KS_out;       // STORE_KMAJOR point stride
-    SegTable lseg, sseg;
+    // segment tables live in device memory (plan-owned): dynamically indexed by-value kernel
+    // arguments would be copied to scratch
+    const SegTable *lseg, *sseg;
+    int32_t lnseg, snseg;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -154,12 +157,14 @@ template <int R, int OFF, int STRIDE, typename C> struct Dif {
 };
 
 // ------------------------------------------------------------------------------------------
-template <typename R, int N, int E, int TL, int G, int R1, int R2, int R3, int R4, int PLANES>
+// TWCHAIN = 1: load only w^k per butterfly and build w^(m k) by successive multiplication
+// (2 live registers instead of RP-1 table loads in flight; error grows by ~RP ulp)
+template <typename R, int N, int E, int TL, int G, int R1, int R2, int R3, int R4, int PLANES, int TWCHAIN = 0>
 struct PassCfg {
     using real = R;
     using C = typename Vec2<R>::type;
     static constexpr int kN = N, kE = E, kTL = TL, kG = G;
-    static constexpr int r1 = R1, r2 = R2, r3 = R3, r4 = R4, kPLANES = PLANES;
+    static constexpr int r1 = R1, r2 = R2, r3 = R3, r4 = R4, kPLANES = PLANES, kTWCHAIN = TWCHAIN;
     static constexpr int RLAST = R4 > 1 ? R4 : (R3 > 1 ? R3 : (R2 > 1 ? R2 : R1));
     static constexpr int NT = N / E;                 // threads per line
     static constexpr int TW = TL * G;                // lines per workgroup
@@ -193,14 +198,32 @@ __device__ __forceinline__ void pass_compute(typename Cfg::C *v, int t, const ty
             const int j = t + Cfg::NT * i;
             const int k = j & (NS - 1);
             constexpr int step = N / (NS * RP);
-            static_for<1, RP>([&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-                const C w = W[(m * k) * step];
-                C x = v[i + m * S], r;
-                r.x = x.x * w.x - x.y * w.y;
-                r.y = x.x * w.y + x.y * w.x;
-                v[i + m * S] = r;
-            });
+            if constexpr (Cfg::kTWCHAIN) {
+                const C w1 = W[k * step];
+                C cur = w1;
+                static_for<1, RP>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    C x = v[i + m * S], r;
+                    r.x = x.x * cur.x - x.y * cur.y;
+                    r.y = x.x * cur.y + x.y * cur.x;
+                    v[i + m * S] = r;
+                    if constexpr (m + 1 < RP) {
+                        C nx;
+                        nx.x = cur.x * w1.x - cur.y * w1.y;
+                        nx.y = cur.x * w1.y + cur.y * w1.x;
+                        cur = nx;
+                    }
+                });
+            } else {
+                static_for<1, RP>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    const C w = W[(m * k) * step];
+                    C x = v[i + m * S], r;
+                    r.x = x.x * w.x - x.y * w.y;
+                    r.y = x.x * w.y + x.y * w.x;
+                    v[i + m * S] = r;
+                });
+            }
         }
         Dif<RP, i, S, C>::run(v);
     });
@@ -315,18 +338,18 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
             const C *p = in + (uint64_t)a * A.LB + (uint64_t)b * TL + l + (uint64_t)t * A.KS_in;
             static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = p[(uint64_t)(NT * c) * A.KS_in]; });
         } else {
-            if (A.lseg.nseg == 1) {
-                const uint64_t len = A.lseg.len[0];
-                const C *p = in + A.lseg.base[0] + (uint64_t)a * len * A.LB + (uint64_t)b * TL * len + l + (uint64_t)t * tw;
+            if (A.lnseg == 1) {
+                const uint64_t len = A.lseg->len[0];
+                const C *p = in + A.lseg->base[0] + (uint64_t)a * len * A.LB + (uint64_t)b * TL * len + l + (uint64_t)t * tw;
                 static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = p[(uint64_t)(NT * c) * tw]; });
             } else {
                 static_for<0, E>([&](auto cc) {
                     constexpr int c = decltype(cc)::value;
                     const uint32_t n = t + NT * c;
-                    uint32_t s0 = A.lseg.start[0], ln = A.lseg.len[0];
-                    uint64_t bs = A.lseg.base[0];
-                    for (int s = 1; s < A.lseg.nseg; s++)
-                        if (n >= A.lseg.start[s]) { s0 = A.lseg.start[s]; ln = A.lseg.len[s]; bs = A.lseg.base[s]; }
+                    uint32_t s0 = A.lseg->start[0], ln = A.lseg->len[0];
+                    uint64_t bs = A.lseg->base[0];
+                    for (int s = 1; s < A.lnseg; s++)
+                        if (n >= A.lseg->start[s]) { s0 = A.lseg->start[s]; ln = A.lseg->len[s]; bs = A.lseg->base[s]; }
                     v[c] = in[bs + (uint64_t)a * ln * A.LB + (uint64_t)b * TL * ln + (uint64_t)(n - s0) * tw + l];
                 });
             }
@@ -365,10 +388,10 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
             constexpr int c = decltype(cc)::value;
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
             const uint32_t k = t + k0;
-            uint32_t s0 = A.sseg.start[0], ln = A.sseg.len[0];
-            uint64_t bs = A.sseg.base[0];
-            for (int s = 1; s < A.sseg.nseg; s++)
-                if (k >= A.sseg.start[s]) { s0 = A.sseg.start[s]; ln = A.sseg.len[s]; bs = A.sseg.base[s]; }
+            uint32_t s0 = A.sseg->start[0], ln = A.sseg->len[0];
+            uint64_t bs = A.sseg->base[0];
+            for (int s = 1; s < A.snseg; s++)
+                if (k >= A.sseg->start[s]) { s0 = A.sseg->start[s]; ln = A.sseg->len[s]; bs = A.sseg->base[s]; }
             const uint32_t kl = k - s0;
             uint64_t off;
             if (A.store_kind == STORE_TILED_SAME) {
@@ -403,19 +426,19 @@ template <int TL> struct TileCtx { uint32_t a, b, tw; int l; };
 template <int TL>
 __device__ __forceinline__ uint64_t tiled_load_offset(const PassArgs &A, const TileCtx<TL> &c, uint32_t n)
 {
-    uint32_t s0 = A.lseg.start[0], ln = A.lseg.len[0];
-    uint64_t bs = A.lseg.base[0];
-    for (int s = 1; s < A.lseg.nseg; s++)
-        if (n >= A.lseg.start[s]) { s0 = A.lseg.start[s]; ln = A.lseg.len[s]; bs = A.lseg.base[s]; }
+    uint32_t s0 = A.lseg->start[0], ln = A.lseg->len[0];
+    uint64_t bs = A.lseg->base[0];
+    for (int s = 1; s < A.lnseg; s++)
+        if (n >= A.lseg->start[s]) { s0 = A.lseg->start[s]; ln = A.lseg->len[s]; bs = A.lseg->base[s]; }
     return bs + (uint64_t)c.a * ln * A.LB + (uint64_t)c.b * TL * ln + (uint64_t)(n - s0) * c.tw + c.l;
 }
 template <int TL>
 __device__ __forceinline__ uint64_t tiled_transpose_store_offset(const PassArgs &A, const TileCtx<TL> &c, uint32_t k)
 {
-    uint32_t s0 = A.sseg.start[0], ln = A.sseg.len[0];
-    uint64_t bs = A.sseg.base[0];
-    for (int s = 1; s < A.sseg.nseg; s++)
-        if (k >= A.sseg.start[s]) { s0 = A.sseg.start[s]; ln = A.sseg.len[s]; bs = A.sseg.base[s]; }
+    uint32_t s0 = A.sseg->start[0], ln = A.sseg->len[0];
+    uint64_t bs = A.sseg->base[0];
+    for (int s = 1; s < A.snseg; s++)
+        if (k >= A.sseg->start[s]) { s0 = A.sseg->start[s]; ln = A.sseg->len[s]; bs = A.sseg->base[s]; }
     const uint32_t kl = k - s0;
     const uint32_t T2 = 1u << A.T2shift;
     const uint32_t kt = kl >> A.T2shift, kr = kl & (T2 - 1);

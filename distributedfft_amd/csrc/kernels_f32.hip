@@ -8,17 +8,16 @@ using F32_8    = PassCfg<float, 8,    8, 16, 16, 8, 1, 1, 1,   1>;
 using F32_16   = PassCfg<float, 16,  16, 16, 16, 16, 1, 1, 1,  1>;
 using F32_32   = PassCfg<float, 32,   8, 16, 4,  8, 4, 1, 1,   2>;
 using F32_64   = PassCfg<float, 64,   8, 16, 2,  8, 8, 1, 1,   2>;
-using F32_128  = PassCfg<float, 128, 16, 16, 2,  16, 8, 1, 1,  2>;
-using F32_256  = PassCfg<float, 256, 16, 16, 1,  16, 16, 1, 1, 2>;
-using F32_512  = PassCfg<float, 512, 16, 16, 1,  8, 8, 8, 1,   2>;
-using F32_1024 = PassCfg<float, 1024, 16, 16, 1, 16, 16, 4, 1, 1>;
-using F32_2048 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1,  1>;
+using F32_128  = PassCfg<float, 128, 16, 16, 2,  16, 8, 1, 1,  2, 1>;
+using F32_256  = PassCfg<float, 256, 16, 16, 1,  16, 16, 1, 1, 2, 1>;
+using F32_512  = PassCfg<float, 512, 16, 16, 1,  8, 8, 8, 1,   2, 1>;
+// 32 points per thread: fp32 runs out of instruction issue, not bandwidth, at 16
+using F32_1024 = PassCfg<float, 1024, 32, 16, 1, 32, 8, 4, 1,  1, 1>;
+using F32_2048 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1,  1, 1>;
+using F32_1024_v1 = PassCfg<float, 1024, 16, 16, 1, 16, 16, 4, 1, 1>;   // round-1 baseline, for A/B runs
+using F32_512_v1 = PassCfg<float, 512, 32, 16, 1, 32, 4, 4, 1, 1, 1>;
 
-using F32_1024_v1 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1>;   // 512 thr, 2 passes
-using F32_1024_v2 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 2>;   // + two planes
-using F32_1024_v3 = PassCfg<float, 1024, 16, 16, 1, 16, 16, 4, 1, 2>;   // two planes
-
-#define DFFT_F32_LIST(X) X(1024, 1, F32_1024_v1) X(1024, 2, F32_1024_v2) X(1024, 3, F32_1024_v3) \
+#define DFFT_F32_LIST(X) X(1024, 1, F32_1024_v1) X(512, 1, F32_512_v1) \
     X(2, 0, F32_2) X(4, 0, F32_4) X(8, 0, F32_8) X(16, 0, F32_16) X(32, 0, F32_32) X(64, 0, F32_64) \
     X(128, 0, F32_128) X(256, 0, F32_256) X(512, 0, F32_512) X(1024, 0, F32_1024) X(2048, 0, F32_2048)
 

@@ -2,30 +2,27 @@
 #include "kernels.hip.inc"
 
 namespace dfft {
-//                 real    N     E  TL  G   radices      planes
+//                 real    N     E  TL  G   radices      planes  chained twiddles
 using F64_2    = PassCfg<double, 2,    2, 8, 32, 2, 1, 1, 1,   1>;
 using F64_4    = PassCfg<double, 4,    4, 8, 32, 4, 1, 1, 1,   1>;
 using F64_8    = PassCfg<double, 8,    8, 8, 32, 8, 1, 1, 1,   1>;
 using F64_16   = PassCfg<double, 16,  16, 8, 32, 16, 1, 1, 1,  1>;
 using F64_32   = PassCfg<double, 32,   8, 8, 8,  8, 4, 1, 1,   2>;
 using F64_64   = PassCfg<double, 64,   8, 8, 4,  8, 8, 1, 1,   2>;
-using F64_128  = PassCfg<double, 128, 16, 8, 4,  16, 8, 1, 1,  2>;
-using F64_256  = PassCfg<double, 256, 16, 8, 2,  16, 16, 1, 1, 2>;
-using F64_512  = PassCfg<double, 512, 16, 8, 1,  8, 8, 8, 1,   1>;
-using F64_1024 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1>;
-using F64_2048 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1>;
+using F64_128  = PassCfg<double, 128, 16, 8, 4,  16, 8, 1, 1,  2, 1>;
+using F64_256  = PassCfg<double, 256, 16, 8, 2,  16, 16, 1, 1, 2, 1>;
+using F64_512  = PassCfg<double, 512, 16, 8, 1,  8, 8, 8, 1,   1, 1>;
+// 1024: 512 threads, 124 VGPRs, 68 KiB LDS -> two workgroups per CU (measured best)
+using F64_1024 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1>;
+using F64_2048 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1>;
+// variant 1 = "strided read" configuration for passes that load the point-major API layout
+// (inverse x pass): 16 lines per workgroup (256-B runs per row) and 32 points per thread (twice
+// the loads in flight); 4.18 vs 3.76 TB/s at 1024^3
+using F64_1024_v1 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1>;
+// variant 2 = table-loaded twiddles (bit-for-bit the round-1 baseline), kept for A/B runs
+using F64_1024_v2 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 0>;
 
-// experimental alternatives for N = 1024 (selected per pass with DFFT_VARIANTS, see dfft.hip)
-using F64_1024_v1 = PassCfg<double, 1024, 16, 8, 2, 16, 16, 4, 1, 1>;   // 16 lines / WG, 1024 thr
-using F64_1024_v2 = PassCfg<double, 1024, 32, 8, 1, 32, 32, 1, 1, 1>;   // 32 pts / thread, 2 passes
-using F64_1024_v3 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1>;   // both
-using F64_1024_v4 = PassCfg<double, 1024, 16, 8, 1, 4, 16, 16, 1, 1>;   // small radix first
-using F64_1024_v5 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 2>;   // two LDS planes, fewer barriers
-using F64_512_v1 = PassCfg<double, 512, 16, 8, 2, 8, 8, 8, 1, 1>;
-using F64_512_v2 = PassCfg<double, 512, 32, 8, 2, 32, 16, 1, 1, 1>;
-
-#define DFFT_F64_LIST(X) X(1024, 1, F64_1024_v1) X(1024, 2, F64_1024_v2) X(1024, 3, F64_1024_v3) \
-    X(1024, 4, F64_1024_v4) X(1024, 5, F64_1024_v5) X(512, 1, F64_512_v1) X(512, 2, F64_512_v2) \
+#define DFFT_F64_LIST(X) X(1024, 1, F64_1024_v1) X(1024, 2, F64_1024_v2) \
     X(2, 0, F64_2) X(4, 0, F64_4) X(8, 0, F64_8) X(16, 0, F64_16) X(32, 0, F64_32) X(64, 0, F64_64) \
     X(128, 0, F64_128) X(256, 0, F64_256) X(512, 0, F64_512) X(1024, 0, F64_1024) X(2048, 0, F64_2048)
 
