@@ -8,9 +8,9 @@ using F32_8    = PassCfg<float, 8,    8, 16, 16, 8, 1, 1, 1,   1>;
 using F32_16   = PassCfg<float, 16,  16, 16, 16, 16, 1, 1, 1,  1>;
 using F32_32   = PassCfg<float, 32,   8, 16, 4,  8, 4, 1, 1,   2>;
 using F32_64   = PassCfg<float, 64,   8, 16, 2,  8, 8, 1, 1,   2>;
-using F32_128  = PassCfg<float, 128, 16, 16, 2,  16, 8, 1, 1,  2, 1>;
-using F32_256  = PassCfg<float, 256, 16, 16, 1,  16, 16, 1, 1, 2, 1>;
-using F32_512  = PassCfg<float, 512, 16, 16, 1,  8, 8, 8, 1,   2, 1>;
+using F32_128  = PassCfg<float, 128, 16, 16, 2,  16, 8, 1, 1,  2>;
+using F32_256  = PassCfg<float, 256, 16, 16, 1,  16, 16, 1, 1, 2>;
+using F32_512  = PassCfg<float, 512, 16, 16, 1,  8, 8, 8, 1,   2>;
 // 32 points per thread: fp32 runs out of instruction issue, not bandwidth, at 16
 using F32_1024 = PassCfg<float, 1024, 32, 16, 1, 32, 8, 4, 1,  1, 1>;
 using F32_2048 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1,  1, 1>;

@@ -9,9 +9,9 @@ using F64_8    = PassCfg<double, 8,    8, 8, 32, 8, 1, 1, 1,   1>;
 using F64_16   = PassCfg<double, 16,  16, 8, 32, 16, 1, 1, 1,  1>;
 using F64_32   = PassCfg<double, 32,   8, 8, 8,  8, 4, 1, 1,   2>;
 using F64_64   = PassCfg<double, 64,   8, 8, 4,  8, 8, 1, 1,   2>;
-using F64_128  = PassCfg<double, 128, 16, 8, 4,  16, 8, 1, 1,  2, 1>;
-using F64_256  = PassCfg<double, 256, 16, 8, 2,  16, 16, 1, 1, 2, 1>;
-using F64_512  = PassCfg<double, 512, 16, 8, 1,  8, 8, 8, 1,   1, 1>;
+using F64_128  = PassCfg<double, 128, 16, 8, 4,  16, 8, 1, 1,  2>;
+using F64_256  = PassCfg<double, 256, 16, 8, 2,  16, 16, 1, 1, 2>;
+using F64_512  = PassCfg<double, 512, 16, 8, 1,  8, 8, 8, 1,   1>;
 // 1024: 512 threads, 124 VGPRs, 68 KiB LDS -> two workgroups per CU (measured best)
 using F64_1024 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1>;
 using F64_2048 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1>;
