@@ -163,14 +163,26 @@ void orc_fft1d_many(cplx *x, size_t n, size_t stride, size_t dist, size_t howman
  * single-rank 3-D transforms, C order [x][y][z], z contiguous (README.md:247)
  * ---------------------------------------------------------------------------------------- */
 
+/* lines of length n, element stride `stride`; line (i, j) starts at x + i*dist1 + j*dist2.
+ * One parallel region and one twiddle table per thread for the whole batch. */
+static void fft_lines_2d(cplx *x, size_t n, size_t stride, size_t n1, size_t dist1, size_t n2, size_t dist2, int sign)
+{
+#pragma omp parallel
+    {
+        line_plan lp; line_plan_init(&lp, n, sign);
+#pragma omp for schedule(static) collapse(2)
+        for (long long i = 0; i < (long long)n1; i++)
+            for (long long j = 0; j < (long long)n2; j++)
+                line_exec(&lp, x + (size_t)i * dist1 + (size_t)j * dist2, stride);
+        line_plan_free(&lp);
+    }
+}
+
 void orc_fft3d_c2c(cplx *a, size_t Nx, size_t Ny, size_t Nz, int sign)
 {
-    /* z lines */
-    orc_fft1d_many(a, Nz, 1, Nz, Nx * Ny, sign);
-    /* y lines: for each x, Nz lines of stride Nz */
-    for (size_t x = 0; x < Nx; x++) orc_fft1d_many(a + x * Ny * Nz, Ny, Nz, 1, Nz, sign);
-    /* x lines */
-    orc_fft1d_many(a, Nx, Ny * Nz, 1, Ny * Nz, sign);
+    fft_lines_2d(a, Nz, 1, Nx, Ny * Nz, Ny, Nz, sign);          /* z lines */
+    fft_lines_2d(a, Ny, Nz, Nx, Ny * Nz, Nz, 1, sign);          /* y lines */
+    fft_lines_2d(a, Nx, Ny * Nz, Ny, Nz, Nz, 1, sign);          /* x lines */
 }
 
 /* R2C: in real [x][y][Nz] -> out complex [x][y][Nz/2+1] (cufftMakePlan3d R2C semantics,
