@@ -36,6 +36,7 @@ SYMBOLS = [
     ("dfft_exec_c2r", _i, [_vp, _vp, _vp]),
     ("dfft_exec_c2c", _i, [_vp, _vp, _vp, _i]),
     ("dfft_enqueue_c2c", _i, [_vp, _vp, _vp, _i]),
+    ("dfft_exec_dim", _i, [_vp, _vp, _vp, _i, _i]),
     ("dfft_get_in_size", _i, [_vp, _psz]),
     ("dfft_get_in_start", _i, [_vp, _psz]),
     ("dfft_get_out_size", _i, [_vp, _psz]),

@@ -186,13 +186,27 @@ class MPIcuFFT:
         check(lib().dfft_set_stream(self._h, C.c_void_p(int(stream))))
 
     # -- execute ------------------------------------------------------------------------
-    def execR2C(self, out, in_):
-        check(lib().dfft_exec_r2c(self._h, _ptr(out), _ptr(in_)))
+    def execR2C(self, out, in_, d=3):
+        """execR2C(out, in) and the pencil classes' execR2C(out, in, d) (d = 1, 2: partial)"""
+        if d == 3:
+            check(lib().dfft_exec_r2c(self._h, _ptr(out), _ptr(in_)))
+        else:
+            if self.c2c:
+                raise DfftError("plan was initialised for C2C")
+            check(lib().dfft_exec_dim(self._h, _ptr(out), _ptr(in_), FORWARD, d))
 
-    def execC2R(self, out, in_):
-        check(lib().dfft_exec_c2r(self._h, _ptr(out), _ptr(in_)))
+    def execC2R(self, out, in_, d=3):
+        if d == 3:
+            check(lib().dfft_exec_c2r(self._h, _ptr(out), _ptr(in_)))
+        else:
+            if self.c2c:
+                raise DfftError("plan was initialised for C2C")
+            check(lib().dfft_exec_dim(self._h, _ptr(out), _ptr(in_), INVERSE, d))
 
-    def execC2C(self, out, in_, direction=FORWARD, sync=True):
+    def execC2C(self, out, in_, direction=FORWARD, sync=True, d=3):
+        if d != 3:
+            check(lib().dfft_exec_dim(self._h, _ptr(out), _ptr(in_), direction, d))
+            return
         f = lib().dfft_exec_c2c if sync else lib().dfft_enqueue_c2c
         check(f(self._h, _ptr(out), _ptr(in_), direction))
 

@@ -111,6 +111,9 @@ struct Pipeline {
     int C = 1;
     std::vector<Launch> fz, fy, ix, iy, iz;   // per chunk
     Launch fx;                                 // forward x pass (needs complete lines)
+    // partial transforms (reference: execR2C/C2R(out, in, d), src/pencil/mpicufft_pencil.cpp:1644-1839)
+    Launch pz1, qz1;                           // d = 1: z pass natural -> natural [xs][ys][Nzc] and back
+    std::vector<Launch> py2, qy2;              // d = 2: y pass chunk -> [xs][Ny][zs] and back
     std::vector<A2A> f1, f2, i2, i1;          // per chunk exchange tables
     std::vector<hipEvent_t> ev;               // reusable events
     hipStream_t comm_stream = nullptr;
@@ -201,6 +204,7 @@ static int build_pipeline(dfft_plan *p, Pipeline &pl)
     {
         PassArgs X = base(yo, zs, LOAD_TILED, STORE_KMAJOR, 0);
         X.KS_out = (uint64_t)yo * zs;
+        X.AS_out = zs;
         X.a_fastest = 1;
         // segments of the x axis, ascending: peer q major, chunk c minor
         std::vector<size_t> r2c_of(C, 0);
@@ -259,6 +263,7 @@ static int build_pipeline(dfft_plan *p, Pipeline &pl)
             Launch &L = pl.ix[c];
             L.args = base(kl[c], zs, LOAD_KMAJOR, STORE_TILED_SAME, 1);
             L.args.KS_in = (uint64_t)yo * zs;
+            L.args.AS_in = zs;
             L.args.a_fastest = 1;
             L.in_off = e * k0[c] * zs;
             for (int q = 0; q < P1; q++) seg_push(L.sseg, p->xstart[q], p->xs[q], S2i + p->xstart[q] * zs * kl[c]);
@@ -305,6 +310,28 @@ static int build_pipeline(dfft_plan *p, Pipeline &pl)
             L.args = base(xl[c], ys, LOAD_TILED, STORE_LINES, 1);
             for (int q = 0; q < P2; q++) seg_push(L.lseg, p->zstart[q], p->zs[q], R1i + xl[c] * ys * p->zstart[q]);
             L.out_off = x0[c] * ys * zline_bytes;
+        }
+    }
+    // ---------------- partial transforms (d = 1, 2) ----------------
+    pl.pz1 = Launch(); pl.qz1 = Launch();
+    pl.pz1.args = base(xs, ys, LOAD_LINES, STORE_LINES, 0);
+    pl.qz1.args = base(xs, ys, LOAD_LINES, STORE_LINES, 1);
+    pl.py2.assign(C, Launch()); pl.qy2.assign(C, Launch());
+    for (int c = 0; c < C; c++) {
+        const size_t R1c = x0[c] * zs * Ny, S1i = x0[c] * Ny * zs;
+        {   // forward y pass chunk writing the reference's opt0 stage layout [xs][Ny][zs]
+            Launch &L = pl.py2[c];
+            L.args = base(xl[c], zs, LOAD_TILED, STORE_KMAJOR, 0);
+            for (int q = 0; q < P2; q++) seg_push(L.lseg, p->ystart[q], p->ys[q], R1c + xl[c] * p->ystart[q] * zs);
+            L.args.KS_out = zs; L.args.AS_out = Ny * zs;
+            L.out_off = e * x0[c] * Ny * zs;
+        }
+        {   // inverse y pass chunk reading [xs][Ny][zs]
+            Launch &L = pl.qy2[c];
+            L.args = base(xl[c], zs, LOAD_KMAJOR, STORE_TILED_TRANSPOSE, 1);
+            L.args.KS_in = zs; L.args.AS_in = Ny * zs;
+            L.in_off = e * x0[c] * Ny * zs;
+            for (int q = 0; q < P2; q++) seg_push(L.sseg, p->ystart[q], p->ys[q], S1i + xl[c] * p->ystart[q] * zs);
         }
     }
     return 0;
@@ -501,6 +528,69 @@ static int enqueue_inverse(dfft_plan *p, void *out, void *in)
     return 0;
 }
 
+
+// partial transforms of the reference's MPIcuFFT_Pencil::execR2C/execC2R(out, in, d)
+// (src/pencil/mpicufft_pencil.cpp:1644-1839): d = 1 stops after the z pass with the natural
+// stage layout [xs][ys][Nzc]; d = 2 stops after the y pass with [xs][Ny][zs] (z contiguous).
+static int enqueue_partial_forward(dfft_plan *p, void *out, const void *in, int d)
+{
+    Pipeline &pl = p->pl;
+    const int C = pl.C;
+    const char *I = static_cast<const char *>(in);
+    char *O = static_cast<char *>(out), *W = static_cast<char *>(p->work_d);
+    hipStream_t Sc = p->stream, Sm = pl.comm_stream;
+    p->nspans = 0; p->last_dir = DFFT_FORWARD;
+    if (d == 1) {
+        if (p->c2c) return launch(p, pl.pz1, p->vfwd[0], p->Nz, p->tw_z, I, O);
+        return launch_real(p, pl.pz1, 1, I, O);
+    }
+    char *zdst = W, *ysrc = p->P2 > 1 ? W + p->domainsize : W;
+    if (p->comm) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); }
+    for (int c = 0; c < C; c++) {
+        if (p->c2c) TRY(launch(p, pl.fz[c], p->vfwd[0], p->Nz, p->tw_z, I, zdst));
+        else TRY(launch_real(p, pl.fz[c], 1, I, zdst));
+        if (p->P2 > 1) {
+            EV_RECORD(c, Sc); EV_WAIT(c, Sm);
+            TRY(exchange_tables(p, 1, pl.f1[c], true, zdst, ysrc, Sm));
+            EV_RECORD(C + c, Sm);
+        }
+    }
+    for (int c = 0; c < C; c++) {
+        if (p->P2 > 1) EV_WAIT(C + c, Sc);
+        TRY(launch(p, pl.py2[c], p->vfwd[1], p->Ny, p->tw_y, ysrc, O));
+    }
+    return 0;
+}
+
+static int enqueue_partial_inverse(dfft_plan *p, void *out, void *in, int d)
+{
+    Pipeline &pl = p->pl;
+    const int C = pl.C;
+    char *I = static_cast<char *>(in), *O = static_cast<char *>(out), *W = static_cast<char *>(p->work_d);
+    hipStream_t Sc = p->stream, Sm = pl.comm_stream;
+    p->nspans = 0; p->last_dir = DFFT_INVERSE;
+    if (d == 1) {
+        if (p->c2c) return launch(p, pl.qz1, p->vinv[0], p->Nz, p->tw_z, I, O);
+        return launch_real(p, pl.qz1, 2, I, O);
+    }
+    char *ydst = W, *zsrc = p->P2 > 1 ? W + p->domainsize : W;
+    if (p->comm) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); }
+    for (int c = 0; c < C; c++) {
+        TRY(launch(p, pl.qy2[c], p->vinv[1], p->Ny, p->tw_y, I, ydst));
+        if (p->P2 > 1) {
+            EV_RECORD(c, Sc); EV_WAIT(c, Sm);
+            TRY(exchange_tables(p, 1, pl.i1[c], true, ydst, zsrc, Sm));
+            EV_RECORD(C + c, Sm);
+        }
+    }
+    for (int c = 0; c < C; c++) {
+        if (p->P2 > 1) EV_WAIT(C + c, Sc);
+        if (p->c2c) TRY(launch(p, pl.iz[c], p->vinv[0], p->Nz, p->tw_z, zsrc, O));
+        else TRY(launch_real(p, pl.iz[c], 2, zsrc, O));
+    }
+    return 0;
+}
+
 static int check_ready(dfft_plan *p)
 {
     if (!p) return fail(ERR_ARG, "null plan");
@@ -668,8 +758,8 @@ static int upload_tables(dfft_plan *p)
 {
     Pipeline &pl = p->pl;
     std::vector<Launch *> all;
-    for (auto *v : {&pl.fz, &pl.fy, &pl.ix, &pl.iy, &pl.iz}) for (auto &L : *v) all.push_back(&L);
-    all.push_back(&pl.fx);
+    for (auto *v : {&pl.fz, &pl.fy, &pl.ix, &pl.iy, &pl.iz, &pl.py2, &pl.qy2}) for (auto &L : *v) all.push_back(&L);
+    all.push_back(&pl.fx); all.push_back(&pl.pz1); all.push_back(&pl.qz1);
     std::vector<char> host(all.size() * 2 * sizeof(SegTable));
     size_t off = 0;
     for (Launch *L : all) {
@@ -746,6 +836,18 @@ int dfft_enqueue_c2c(dfft_plan *p, void *out, void *in, int direction)
 int dfft_exec_c2c(dfft_plan *p, void *out, void *in, int direction)
 {
     TRY(dfft_enqueue_c2c(p, out, in, direction));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return 0;
+}
+
+int dfft_exec_dim(dfft_plan *p, void *out, void *in, int direction, int d)
+{
+    TRY(check_ready(p));
+    if (!out || !in) return fail(ERR_ARG, "null buffer");
+    if (d < 1 || d > 3) return fail(ERR_ARG, "d must be 1, 2 or 3");
+    if (direction != DFFT_FORWARD && direction != DFFT_INVERSE) return fail(ERR_ARG, "bad direction");
+    if (d == 3) TRY(direction == DFFT_FORWARD ? enqueue_forward(p, out, in) : enqueue_inverse(p, out, in));
+    else TRY(direction == DFFT_FORWARD ? enqueue_partial_forward(p, out, in, d) : enqueue_partial_inverse(p, out, in, d));
     HIP_TRY(hipStreamSynchronize(p->stream));
     return 0;
 }

@@ -35,11 +35,11 @@ constexpr int MAXSEG = 32;   // max segments of a gathered/scattered axis (peers
 enum LoadKind : int {
     LOAD_LINES = 0,    // natural lines:        (a*LB + b*TL + l)*N + n
     LOAD_TILED = 1,    // tiled, segmented by source peer: base[s] + a*len[s]*LB + b*TL*len[s] + (n-start[s])*tw + l
-    LOAD_KMAJOR = 2    // point-major:          n*KS + a*LB + b*TL + l
+    LOAD_KMAJOR = 2    // point-major:          n*KS + a*AS + b*TL + l
 };
 enum StoreKind : int {
     STORE_LINES = 0,           // (a*LB + b*TL + l)*N + k
-    STORE_KMAJOR = 1,          // k*KS + a*LB + b*TL + l
+    STORE_KMAJOR = 1,          // k*KS + a*AS + b*TL + l
     STORE_TILED_SAME = 2,      // base[p] + (k-start[p])*LB*LA + b*TL*LA + a*tw + l
     STORE_TILED_TRANSPOSE = 3  // base[p] + a*len[p]*LB + kt*T2*LB + (b*TL+l)*tw2 + kr
 };
@@ -67,6 +67,8 @@ struct PassArgs {
     uint32_t T2shift;      // STORE_TILED_TRANSPOSE: log2 of the consumer's tile size
     uint64_t KS_in;        // LOAD_KMAJOR point stride
     uint64_t KS_out;       // STORE_KMAJOR point stride
+    uint64_t AS_in;        // LOAD_KMAJOR stride of the outer axis a (LB for the API output layout)
+    uint64_t AS_out;       // STORE_KMAJOR stride of the outer axis a
     // segment tables live in device memory (plan-owned): dynamically indexed by-value kernel
     // arguments would be copied to scratch
     const SegTable *lseg, *sseg;
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
             const C *p = in + ((uint64_t)a * A.LB + (uint64_t)b * TL + l) * N + t;
             static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = p[NT * c]; });
         } else if (A.load_kind == LOAD_KMAJOR) {
-            const C *p = in + (uint64_t)a * A.LB + (uint64_t)b * TL + l + (uint64_t)t * A.KS_in;
+            const C *p = in + (uint64_t)a * A.AS_in + (uint64_t)b * TL + l + (uint64_t)t * A.KS_in;
             static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = p[(uint64_t)(NT * c) * A.KS_in]; });
         } else {
             if (A.lnseg == 1) {
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
             p[k0] = v[c];
         });
     } else if (A.store_kind == STORE_KMAJOR) {
-        C *p = out + (uint64_t)a * A.LB + (uint64_t)b * TL + l + (uint64_t)t * A.KS_out;
+        C *p = out + (uint64_t)a * A.AS_out + (uint64_t)b * TL + l + (uint64_t)t * A.KS_out;
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
@@ -495,6 +497,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
     });
     __syncthreads();
     if (!active) return;
+    const bool lines_out = A.store_kind == STORE_LINES;
     static_for<0, E>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
         const int k = t + NT * c;
@@ -506,10 +509,12 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
         C x;
         x.x = (R)0.5 * (Ar + wv.x * Bi + wv.y * Br);
         x.y = (R)0.5 * (Ai - wv.x * Br + wv.y * Bi);
-        out[tiled_transpose_store_offset<TL>(A, tc, (uint32_t)k)] = x;
+        // natural [line][M+1] rows (partial transform, d = 1) or the tiled send buffer
+        const uint64_t row = ((uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + tc.l) * (uint64_t)(M + 1);
+        out[lines_out ? row + k : tiled_transpose_store_offset<TL>(A, tc, (uint32_t)k)] = x;
         if (c == 0 && t == 0) {          // k = M: X[M] = Re Z[0] - Im Z[0]
             C xm; xm.x = zr - zi; xm.y = 0;
-            out[tiled_transpose_store_offset<TL>(A, tc, (uint32_t)M)] = xm;
+            out[lines_out ? row + M : tiled_transpose_store_offset<TL>(A, tc, (uint32_t)M)] = xm;
         }
     });
 }
@@ -545,8 +550,10 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             const int k = t + NT * c;
-            C x = in[tiled_load_offset<TL>(A, tc, (uint32_t)k)];
-            C m = in[tiled_load_offset<TL>(A, tc, (uint32_t)(M - k))];
+            const bool lines_in = A.load_kind == LOAD_LINES;
+            const uint64_t row = ((uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + tc.l) * (uint64_t)(M + 1);
+            C x = in[lines_in ? row + k : tiled_load_offset<TL>(A, tc, (uint32_t)k)];
+            C m = in[lines_in ? row + (M - k) : tiled_load_offset<TL>(A, tc, (uint32_t)(M - k))];
             if (k == 0) { x.y = 0; m.y = 0; }      // imaginary parts of X[0], X[M] are ignored
             const C wv = W2[k];
             const R Ar = x.x + m.x, Ai = x.y - m.y, Br = x.x - m.x, Bi = x.y + m.y;

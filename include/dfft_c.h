@@ -119,6 +119,12 @@ int dfft_exec_c2r(dfft_plan *plan, void *out, void *in);
 /* new: complex-to-complex, same layouts with Nz_out = Nz.  Forward: in [xs][ys][Nz] -> out
  * [Nx][yo][zs].  Inverse: in [Nx][yo][zs] (destroyed) -> out [xs][ys][Nz]. */
 int dfft_exec_c2c(dfft_plan *plan, void *out, void *in, int direction);
+/* partial transforms: execR2C(out, in, d) / execC2R(out, in, d) of MPIcuFFT_Pencil
+ * (include/mpicufft_pencil.hpp:101-111, src/pencil/mpicufft_pencil.cpp:1644-1839).  Works for
+ * R2C and C2C plans alike (the plan decides).  d = 3: the full transform.  d = 1: z axis only,
+ * stage layout [xs][ys][Nzc] (natural, z contiguous).  d = 2: z then y, stage layout
+ * [xs][Ny][zs].  The inverse direction takes those layouts as input and returns [xs][ys][Nz]. */
+int dfft_exec_dim(dfft_plan *plan, void *out, void *in, int direction, int d);
 /* non-blocking variants: enqueue only (caller synchronises the stream) */
 int dfft_enqueue_c2c(dfft_plan *plan, void *out, void *in, int direction);
 

@@ -246,3 +246,67 @@ def test_pipelined_exchange_chunks(shape, P1, P2, chunks):
         ref = want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]]
         assert np.max(np.abs(spec[r] - ref)) / np.max(np.abs(want)) < 1e-11
         assert rel(backs[r] / n3, ins[r]) < 1e-10
+
+
+# ------------------------------------------------------------------------------------------
+# partial transforms: MPIcuFFT_Pencil::execR2C/execC2R(out, in, d), d = 1, 2
+# (reference tests random_dist_1D.cu:180-451, random_dist_2D.cu:181-455)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c2c", [False, True])
+@pytest.mark.parametrize("shape,P1,P2", [((16, 16, 16), 1, 1), ((32, 32, 32), 2, 4), ((16, 32, 64), 3, 2), ((64, 32, 16), 4, 1)])
+@pytest.mark.parametrize("d", [1, 2])
+def test_partial_dimension_transforms(shape, P1, P2, d, c2c):
+    P = P1 * P2
+    world = dfft.Comm.local(P) if P > 1 else None
+    Nx, Ny, Nz = shape
+    Nzc = Nz if c2c else Nz // 2 + 1
+    g = orc.fill_block(shape, (0, 0, 0), shape, 2 if c2c else 1, seed=31)
+    # d = 1: FFT along z only; d = 2: along z then y (numpy as the independent reference)
+    ref = np.fft.fft(g, axis=2) if c2c else np.fft.rfft(g, axis=2)
+    if d == 2:
+        ref = np.fft.fft(ref, axis=1)
+    plans, ins, outs, backs = [], [], [], []
+    for r in range(P):
+        pl = dfft.MPIcuFFT_Pencil(dfft.Configurations(), world, precision="double", rank=r)
+        pl.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(P1, P2), True, c2c=c2c)
+        s, o = pl.getInSize(), pl.getInStart()
+        blk = np.ascontiguousarray(g[o[0]:o[0] + s[0], o[1]:o[1] + s[1], :])
+        plans.append(pl)
+        ins.append(torch.from_numpy(blk).cuda())
+        outs.append(torch.zeros(pl.getDomainSize() // 16, dtype=torch.complex128, device="cuda"))
+        backs.append(torch.zeros_like(ins[-1]))
+    torch.cuda.synchronize()
+
+    def fwd(r):
+        if c2c:
+            plans[r].execC2C(outs[r], ins[r], dfft.FORWARD, d=d)
+        else:
+            plans[r].execR2C(outs[r], ins[r], d)
+
+    def inv(r):
+        if c2c:
+            plans[r].execC2C(backs[r], outs[r], dfft.INVERSE, d=d)
+        else:
+            plans[r].execC2R(backs[r], outs[r], d)
+
+    with ThreadPoolExecutor(P) as ex:
+        list(ex.map(fwd, range(P)))
+    torch.cuda.synchronize()
+    scale = np.max(np.abs(ref))
+    for r, pl in enumerate(plans):
+        isz, ist = pl.getInSize(), pl.getInStart()
+        osz, ost = pl.getOutSize(), pl.getOutStart()
+        if d == 1:      # [xs][ys][Nzc]
+            shp = (isz[0], isz[1], Nzc)
+            want = ref[ist[0]:ist[0] + isz[0], ist[1]:ist[1] + isz[1], :]
+        else:           # [xs][Ny][zs]
+            shp = (isz[0], Ny, osz[2])
+            want = ref[ist[0]:ist[0] + isz[0], :, ost[2]:ost[2] + osz[2]]
+        got = outs[r][:int(np.prod(shp))].cpu().numpy().reshape(shp)
+        assert np.max(np.abs(got - want)) / scale < 1e-11
+    with ThreadPoolExecutor(P) as ex:
+        list(ex.map(inv, range(P)))
+    torch.cuda.synchronize()
+    norm = float(Nz if d == 1 else Nz * Ny)
+    for r in range(P):
+        assert rel(backs[r].cpu().numpy() / norm, ins[r].cpu().numpy()) < 1e-10
