@@ -111,9 +111,17 @@ template <typename T> struct MPIcuFFT_Slab : MPIcuFFT<T> {
 template <typename T> struct MPIcuFFT_Slab_Opt1 : MPIcuFFT<T> {
     MPIcuFFT_Slab_Opt1(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1) : MPIcuFFT<T>(c, comm, max_world_size, DFFT_SLAB_OPT1) {}
 };
-template <typename T> struct MPIcuFFT_Pencil : MPIcuFFT<T> {
-    MPIcuFFT_Pencil(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1) : MPIcuFFT<T>(c, comm, max_world_size, DFFT_PENCIL) {}
+// partial transforms execR2C/execC2R(out, in, d), include/mpicufft_pencil.hpp:101-111
+template <typename T> struct MPIcuFFT_PencilBase : MPIcuFFT<T> {
+    using MPIcuFFT<T>::MPIcuFFT;
+    using MPIcuFFT<T>::execR2C;
+    using MPIcuFFT<T>::execC2R;
+    void execR2C(void *out, const void *in, int d) { this->check(dfft_exec_dim(this->plan_, out, const_cast<void *>(in), DFFT_FORWARD, d)); }
+    void execC2R(void *out, const void *in, int d) { this->check(dfft_exec_dim(this->plan_, out, const_cast<void *>(in), DFFT_INVERSE, d)); }
 };
-template <typename T> struct MPIcuFFT_Pencil_Opt1 : MPIcuFFT<T> {
-    MPIcuFFT_Pencil_Opt1(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1) : MPIcuFFT<T>(c, comm, max_world_size, DFFT_PENCIL_OPT1) {}
+template <typename T> struct MPIcuFFT_Pencil : MPIcuFFT_PencilBase<T> {
+    MPIcuFFT_Pencil(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1) : MPIcuFFT_PencilBase<T>(c, comm, max_world_size, DFFT_PENCIL) {}
+};
+template <typename T> struct MPIcuFFT_Pencil_Opt1 : MPIcuFFT_PencilBase<T> {
+    MPIcuFFT_Pencil_Opt1(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1) : MPIcuFFT_PencilBase<T>(c, comm, max_world_size, DFFT_PENCIL_OPT1) {}
 };

@@ -1,0 +1,50 @@
+"""The reference-style test driver (distributedfft_amd/cli.py): testcases 0-4 with the reference's
+flags, its printed error norms and its timer CSV format (src/timer.cpp:58-101)."""
+import math
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+pytest.importorskip("torch")
+
+from distributedfft_amd import cli  # noqa: E402
+
+
+def test_testcase3_round_trip_pencil(tmp_path, capsys):
+    r = cli.run(["pencil", "-nx", "64", "-ny", "64", "-nz", "64", "-p1", "2", "-p2", "4", "-o", "1", "-t", "3", "-i", "2",
+                 "-w", "1", "-d", "-c", "-b", str(tmp_path)])
+    out = capsys.readouterr().out
+    assert out.count("Result (avg):") == 3 and out.count("Result (max):") == 3
+    # absolute error of inv - N^3 * in on values up to 255 * 64^3 = 6.7e7
+    assert r["max"] < 1e-6 and r["avg"] < 1e-7
+    path = r["csv"]
+    assert os.path.basename(path) == "test_1_1_0_1_0_64_64_64_1_2_4.csv" and os.path.dirname(path).endswith("pencil")
+    lines = open(path).read().split("\n")
+    assert lines[0] == "," + "".join(f"{i}," for i in range(8))
+    body = [ln for ln in lines[1:] if ln]
+    assert body[0].startswith("init,")
+    names = [ln.split(",")[0] for ln in body]
+    for sec in ("1D FFT Z-Direction", "First Transpose (Finished All2All)", "1D FFT Y-Direction",
+                "Second Transpose (Finished All2All)", "1D FFT X-Direction", "Run complete"):
+        assert sec in names
+    row = [ln for ln in body if ln.startswith("Run complete")][0].split(",")
+    assert len(row) == 8 + 2 and all(float(v) > 0 for v in row[1:9])
+    # warm-up iteration is not stored: 2 iterations x (forward + inverse) blocks
+    assert names.count("Run complete") == 4
+
+
+def test_testcase4_laplacian_slab(tmp_path):
+    r = cli.run(["slab", "-nx", "32", "-ny", "32", "-nz", "32", "-p", "4", "-t", "4", "-d", "-b", str(tmp_path)])
+    assert r["max"] < 1e-9 * math.sqrt(32.0 ** 3) * 3
+
+
+def test_testcase1_distributed_vs_single_and_benchmarks(tmp_path, capsys):
+    r = cli.run(["pencil", "-nx", "32", "-ny", "64", "-nz", "16", "-p1", "3", "-p2", "2", "-t", "1", "-d", "-b", str(tmp_path)])
+    assert r["sum"] < 1e-6
+    for t in ("0", "2"):
+        r = cli.run(["pencil", "-nx", "64", "-ny", "64", "-nz", "64", "-p1", "2", "-p2", "2", "-t", t, "-i", "3", "-b", str(tmp_path)])
+        assert os.path.exists(r["csv"])
+    r = cli.run(["pencil", "-nx", "64", "-ny", "64", "-nz", "64", "-p1", "2", "-p2", "2", "-t", "0", "-f", "2", "-d", "--complex",
+                 "-b", str(tmp_path)])
+    assert os.path.exists(r["csv"])
