@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <complex>
 #include <string>
 #include <vector>
 
@@ -92,6 +93,99 @@ static int make_twiddles(int prec, size_t N, void **dev)
     return 0;
 }
 
+
+static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+static size_t next_pow2(size_t n) { size_t m = 1; while (m < n) m <<= 1; return m; }
+
+// One axis of the 3-D transform: native power-of-two Stockham chain or Bluestein on top of it
+struct Axis {
+    size_t N = 0;          // line length
+    bool bluestein = false;
+    size_t M = 0;          // inner power-of-two length (== N when native)
+    void *tw = nullptr;    // exp(-2 pi i j / M), M entries
+    void *chirp = nullptr; // Bluestein: exp(-i pi n^2 / N), N entries
+    void *bhat = nullptr;  // Bluestein: FFT_M(conj chirp, wrapped) / M
+};
+
+static void host_fft_pow2(std::vector<std::complex<long double>> &a)
+{
+    const long double PI = 3.141592653589793238462643383279502884L;
+    const size_t n = a.size();
+    for (size_t i = 1, j = 0; i < n; i++) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; k++) {
+                long double ang = -2.0L * PI * (long double)k / (long double)len;
+                std::complex<long double> w(cosl(ang), sinl(ang));
+                auto u = a[i + k], v = a[i + k + len / 2] * w;
+                a[i + k] = u + v;
+                a[i + k + len / 2] = u - v;
+            }
+    }
+}
+
+static int upload_complex(int prec, const std::vector<std::complex<long double>> &h, void **dev)
+{
+    const size_t esz = prec == DFFT_F64 ? 16 : 8;
+    std::vector<char> buf(esz * h.size());
+    for (size_t j = 0; j < h.size(); j++) {
+        if (prec == DFFT_F64) {
+            double *d = reinterpret_cast<double *>(buf.data()) + 2 * j;
+            d[0] = (double)h[j].real(); d[1] = (double)h[j].imag();
+        } else {
+            float *d = reinterpret_cast<float *>(buf.data()) + 2 * j;
+            d[0] = (float)h[j].real(); d[1] = (float)h[j].imag();
+        }
+    }
+    HIP_TRY(hipMalloc(dev, buf.size()));
+    HIP_TRY(hipMemcpy(*dev, buf.data(), buf.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static void axis_free(Axis &a)
+{
+    for (void **t : {&a.tw, &a.chirp, &a.bhat}) if (*t) { (void)hipFree(*t); *t = nullptr; }
+}
+
+// decide how an axis of length N is transformed; returns false if unsupported
+static bool axis_plan(int prec, size_t N, Axis &a)
+{
+    PassInfo pi;
+    a.N = N;
+    if (is_pow2(N) && pass_info(prec, (int)N, &pi)) { a.bluestein = false; a.M = N; return true; }
+    const size_t M = next_pow2(2 * N - 1);
+    if (N < 2 || !pass_info(prec, (int)M, &pi)) return false;
+    a.bluestein = true; a.M = M;
+    return true;
+}
+
+static int axis_upload(int prec, Axis &a)
+{
+    const long double PI = 3.141592653589793238462643383279502884L;
+    if (!a.tw) TRY(make_twiddles(prec, a.M, &a.tw));
+    if (a.bluestein && !a.chirp) {
+        const size_t N = a.N, M = a.M;
+        std::vector<std::complex<long double>> ch(N), b(M, std::complex<long double>(0, 0));
+        for (size_t n = 0; n < N; n++) {
+            const size_t q = (size_t)(((unsigned __int128)n * n) % (2 * N));      // n^2 mod 2N keeps the angle exact
+            const long double ang = PI * (long double)q / (long double)N;
+            ch[n] = std::complex<long double>(cosl(ang), -sinl(ang));           // exp(-i pi n^2 / N)
+            b[n] = std::conj(ch[n]);
+            if (n) b[M - n] = std::conj(ch[n]);
+        }
+        host_fft_pow2(b);
+        for (auto &v : b) v /= (long double)M;
+        TRY(upload_complex(prec, ch, &a.chirp));
+        TRY(upload_complex(prec, b, &a.bhat));
+    }
+    return 0;
+}
+
 }  // namespace dfft
 
 using namespace dfft;
@@ -134,7 +228,9 @@ struct dfft_plan {
     size_t esz = 16, domain_elems = 0, domainsize = 0, worksize_d = 0;
     void *work_d = nullptr;
     bool work_owned = false;
-    void *tw_x = nullptr, *tw_y = nullptr, *tw_z = nullptr, *tw_zr = nullptr;   // tw_zr: split/merge table (R2C)
+    Axis ax[3];                  // [0] = z, [1] = y, [2] = x
+    bool zreal_native = false;   // R2C plan whose z axis uses the packed Nz/2-point kernels
+    void *tw_zr = nullptr;       // split/merge table exp(-2 pi i k / Nz) of the packed real kernels
     void *tables_d = nullptr;    // segment tables of every launch, device copy
     hipStream_t stream = nullptr;
     bool stream_owned = false;
@@ -337,28 +433,45 @@ static int build_pipeline(dfft_plan *p, Pipeline &pl)
     return 0;
 }
 
-static int launch(dfft_plan *p, const Launch &L, int variant, size_t N, const void *tw, const char *in, char *out)
+static void fill_tables(dfft_plan *p, const Launch &L, PassArgs &A)
 {
-    if (L.args.ntiles == 0) return 0;
-    PassArgs A = L.args;
-    A.in = in + L.in_off; A.out = out + L.out_off; A.tw = tw;
     A.lseg = reinterpret_cast<const SegTable *>(static_cast<const char *>(p->tables_d) + L.ltab);
     A.sseg = reinterpret_cast<const SegTable *>(static_cast<const char *>(p->tables_d) + L.stab);
     A.lnseg = L.lseg.nseg; A.snseg = L.sseg.nseg;
-    return launch_pass(p->prec, (int)N, variant, A, p->stream);
 }
 
-// z pass of an R2C plan: M = Nz/2 point complex FFT + split (mode 1) / merge (mode 2)
+// complex axis pass on axis `axis` (0 = z, 1 = y, 2 = x)
+static int launch(dfft_plan *p, const Launch &L, int variant, int axis, const char *in, char *out)
+{
+    if (L.args.ntiles == 0) return 0;
+    const Axis &ax = p->ax[axis];
+    PassArgs A = L.args;
+    A.in = in + L.in_off; A.out = out + L.out_off; A.tw = ax.tw;
+    fill_tables(p, L, A);
+    if (!ax.bluestein) return launch_pass(p->prec, (int)ax.N, variant, A, p->stream);
+    A.tw2 = ax.chirp; A.tw3 = ax.bhat; A.NL = (uint32_t)ax.N; A.NK = (uint32_t)ax.N; A.real_mode = 0;
+    int r = p->prec == DFFT_F64 ? launch_bluestein_f64((int)ax.M, A, p->stream) : launch_bluestein_f32((int)ax.M, A, p->stream);
+    if (r != 0) return fail(r == -1 ? ERR_UNSUPPORTED : r, "Bluestein pass launch failed for length " + std::to_string(ax.N));
+    return 0;
+}
+
+// z pass of an R2C plan.  Power-of-two Nz: M = Nz/2 point complex FFT + split (mode 1) / merge
+// (mode 2); any other Nz: Bluestein on the real line (real_mode 1 / 2).
 static int launch_real(dfft_plan *p, const Launch &L, int mode, const char *in, char *out)
 {
     if (L.args.ntiles == 0) return 0;
+    const Axis &ax = p->ax[0];
     PassArgs A = L.args;
-    A.in = in + L.in_off; A.out = out + L.out_off; A.tw = p->tw_z; A.tw2 = p->tw_zr;
-    A.lseg = reinterpret_cast<const SegTable *>(static_cast<const char *>(p->tables_d) + L.ltab);
-    A.sseg = reinterpret_cast<const SegTable *>(static_cast<const char *>(p->tables_d) + L.stab);
-    A.lnseg = L.lseg.nseg; A.snseg = L.sseg.nseg;
-    const int M = (int)(p->Nz / 2);
-    int r = p->prec == DFFT_F64 ? launch_real_f64(M, mode, A, p->stream) : launch_real_f32(M, mode, A, p->stream);
+    A.in = in + L.in_off; A.out = out + L.out_off; A.tw = ax.tw; A.tw2 = p->tw_zr;
+    fill_tables(p, L, A);
+    int r;
+    if (p->zreal_native) {
+        const int M = (int)(p->Nz / 2);
+        r = p->prec == DFFT_F64 ? launch_real_f64(M, mode, A, p->stream) : launch_real_f32(M, mode, A, p->stream);
+    } else {
+        A.tw2 = ax.chirp; A.tw3 = ax.bhat; A.NL = (uint32_t)p->Nz; A.NK = (uint32_t)p->Nzc; A.real_mode = mode;
+        r = p->prec == DFFT_F64 ? launch_bluestein_f64((int)ax.M, A, p->stream) : launch_bluestein_f32((int)ax.M, A, p->stream);
+    }
     if (r == -1) return fail(ERR_UNSUPPORTED, "unsupported real line length " + std::to_string(p->Nz));
     if (r != 0) return fail(r, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)r));
     return 0;
@@ -440,7 +553,7 @@ static int enqueue_forward(dfft_plan *p, void *out, const void *in)
     if (p->comm) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); }     // comm stream starts after prior work
     for (int c = 0; c < C; c++) {
         TRY(span_begin(p, 0, Sc));
-        if (p->c2c) TRY(launch(p, pl.fz[c], p->vfwd[0], p->Nz, p->tw_z, I, zdst));
+        if (p->c2c) TRY(launch(p, pl.fz[c], p->vfwd[0], 0, I, zdst));
         else TRY(launch_real(p, pl.fz[c], 1, I, zdst));
         TRY(span_end(p, Sc));
         if (p->P2 > 1) {
@@ -455,7 +568,7 @@ static int enqueue_forward(dfft_plan *p, void *out, const void *in)
     for (int c = 0; c < C; c++) {
         if (p->P2 > 1) EV_WAIT(C + c, Sc);
         TRY(span_begin(p, 2, Sc));
-        TRY(launch(p, pl.fy[c], p->vfwd[1], p->Ny, p->tw_y, ysrc, ydst));
+        TRY(launch(p, pl.fy[c], p->vfwd[1], 1, ysrc, ydst));
         TRY(span_end(p, Sc));
         if (p->P1 > 1) {
             EV_RECORD(2 * C + c, Sc);
@@ -469,7 +582,7 @@ static int enqueue_forward(dfft_plan *p, void *out, const void *in)
     if (p->P1 > 1) EV_WAIT(3 * C + C - 1, Sc);     // the comm stream is in order: last chunk covers all
     else if (p->P2 > 1) { /* y passes already waited for every ex1 chunk */ }
     TRY(span_begin(p, 4, Sc));
-    TRY(launch(p, pl.fx, p->vfwd[2], p->Nx, p->tw_x, xsrc, A));
+    TRY(launch(p, pl.fx, p->vfwd[2], 2, xsrc, A));
     TRY(span_end(p, Sc));
     return 0;
 }
@@ -491,7 +604,7 @@ static int enqueue_inverse(dfft_plan *p, void *out, void *in)
     if (p->comm) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); }
     for (int c = 0; c < C; c++) {
         TRY(span_begin(p, 0, Sc));
-        TRY(launch(p, pl.ix[c], p->vinv[2], p->Nx, p->tw_x, I, xdst));
+        TRY(launch(p, pl.ix[c], p->vinv[2], 2, I, xdst));
         TRY(span_end(p, Sc));
         if (p->P1 > 1) {
             EV_RECORD(c, Sc);
@@ -507,7 +620,7 @@ static int enqueue_inverse(dfft_plan *p, void *out, void *in)
     if (p->P1 > 1) EV_WAIT(C + C - 1, Sc);
     for (int c = 0; c < C; c++) {
         TRY(span_begin(p, 2, Sc));
-        TRY(launch(p, pl.iy[c], p->vinv[1], p->Ny, p->tw_y, ysrc, ydst));
+        TRY(launch(p, pl.iy[c], p->vinv[1], 1, ysrc, ydst));
         TRY(span_end(p, Sc));
         if (p->P2 > 1) {
             EV_RECORD(2 * C + c, Sc);
@@ -521,7 +634,7 @@ static int enqueue_inverse(dfft_plan *p, void *out, void *in)
     for (int c = 0; c < C; c++) {
         if (p->P2 > 1) EV_WAIT(3 * C + c, Sc);
         TRY(span_begin(p, 4, Sc));
-        if (p->c2c) TRY(launch(p, pl.iz[c], p->vinv[0], p->Nz, p->tw_z, zsrc, O));
+        if (p->c2c) TRY(launch(p, pl.iz[c], p->vinv[0], 0, zsrc, O));
         else TRY(launch_real(p, pl.iz[c], 2, zsrc, O));
         TRY(span_end(p, Sc));
     }
@@ -541,13 +654,13 @@ static int enqueue_partial_forward(dfft_plan *p, void *out, const void *in, int 
     hipStream_t Sc = p->stream, Sm = pl.comm_stream;
     p->nspans = 0; p->last_dir = DFFT_FORWARD;
     if (d == 1) {
-        if (p->c2c) return launch(p, pl.pz1, p->vfwd[0], p->Nz, p->tw_z, I, O);
+        if (p->c2c) return launch(p, pl.pz1, p->vfwd[0], 0, I, O);
         return launch_real(p, pl.pz1, 1, I, O);
     }
     char *zdst = W, *ysrc = p->P2 > 1 ? W + p->domainsize : W;
     if (p->comm) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); }
     for (int c = 0; c < C; c++) {
-        if (p->c2c) TRY(launch(p, pl.fz[c], p->vfwd[0], p->Nz, p->tw_z, I, zdst));
+        if (p->c2c) TRY(launch(p, pl.fz[c], p->vfwd[0], 0, I, zdst));
         else TRY(launch_real(p, pl.fz[c], 1, I, zdst));
         if (p->P2 > 1) {
             EV_RECORD(c, Sc); EV_WAIT(c, Sm);
@@ -557,7 +670,7 @@ static int enqueue_partial_forward(dfft_plan *p, void *out, const void *in, int 
     }
     for (int c = 0; c < C; c++) {
         if (p->P2 > 1) EV_WAIT(C + c, Sc);
-        TRY(launch(p, pl.py2[c], p->vfwd[1], p->Ny, p->tw_y, ysrc, O));
+        TRY(launch(p, pl.py2[c], p->vfwd[1], 1, ysrc, O));
     }
     return 0;
 }
@@ -570,13 +683,13 @@ static int enqueue_partial_inverse(dfft_plan *p, void *out, void *in, int d)
     hipStream_t Sc = p->stream, Sm = pl.comm_stream;
     p->nspans = 0; p->last_dir = DFFT_INVERSE;
     if (d == 1) {
-        if (p->c2c) return launch(p, pl.qz1, p->vinv[0], p->Nz, p->tw_z, I, O);
+        if (p->c2c) return launch(p, pl.qz1, p->vinv[0], 0, I, O);
         return launch_real(p, pl.qz1, 2, I, O);
     }
     char *ydst = W, *zsrc = p->P2 > 1 ? W + p->domainsize : W;
     if (p->comm) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); }
     for (int c = 0; c < C; c++) {
-        TRY(launch(p, pl.qy2[c], p->vinv[1], p->Ny, p->tw_y, I, ydst));
+        TRY(launch(p, pl.qy2[c], p->vinv[1], 1, I, ydst));
         if (p->P2 > 1) {
             EV_RECORD(c, Sc); EV_WAIT(c, Sm);
             TRY(exchange_tables(p, 1, pl.i1[c], true, ydst, zsrc, Sm));
@@ -585,7 +698,7 @@ static int enqueue_partial_inverse(dfft_plan *p, void *out, void *in, int d)
     }
     for (int c = 0; c < C; c++) {
         if (p->P2 > 1) EV_WAIT(C + c, Sc);
-        if (p->c2c) TRY(launch(p, pl.iz[c], p->vinv[0], p->Nz, p->tw_z, zsrc, O));
+        if (p->c2c) TRY(launch(p, pl.iz[c], p->vinv[0], 0, zsrc, O));
         else TRY(launch_real(p, pl.iz[c], 2, zsrc, O));
     }
     return 0;
@@ -657,7 +770,8 @@ int dfft_plan_destroy(dfft_plan *p)
 {
     if (!p) return 0;
     if (p->work_owned && p->work_d) (void)hipFree(p->work_d);
-    for (void *t : {p->tw_x, p->tw_y, p->tw_z, p->tw_zr, p->tables_d}) if (t) (void)hipFree(t);
+    for (auto &a : p->ax) axis_free(a);
+    for (void *t : {p->tw_zr, p->tables_d}) if (t) (void)hipFree(t);
     for (auto &t : p->spans) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
     for (auto &e : p->pl.ev) if (e) (void)hipEventDestroy(e);
     if (p->pl.comm_stream) (void)hipStreamDestroy(p->pl.comm_stream);
@@ -675,13 +789,17 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         return fail(ERR_ARG, "slab decomposition needs P2 == 1");
     if (P1 > MAXSEG || P2 > MAXSEG) return fail(ERR_UNSUPPORTED, "more than 32 ranks per exchange group");
     if ((size_t)P1 > Nx || (size_t)P1 > Ny || (size_t)P2 > Ny) return fail(ERR_ARG, "partition larger than the grid");
-    PassInfo pinfo;
-    if (!c2c && (Nz % 2 || Nz < 4 || Nz > 2048))
-        return fail(ERR_UNSUPPORTED, "R2C/C2R needs an even Nz in 4..2048");
-    for (size_t n : {Nx, Ny, c2c ? Nz : Nz / 2})
-        if (!pass_info(p->prec, (int)n, &pinfo))
-            return fail(ERR_UNSUPPORTED, "unsupported axis length " + std::to_string(n) +
-                                             " (power of two, 2..2048)");
+    // axis plans: native power-of-two chain (2..2048) or Bluestein (any length with 2N-1 <= 2048)
+    {
+        Axis az, ay, axx;
+        const bool zr_native = !c2c && is_pow2(Nz) && Nz >= 4 && Nz <= 2048;
+        const size_t zlen = zr_native ? Nz / 2 : Nz;
+        if (!axis_plan(p->prec, zlen, az) || !axis_plan(p->prec, Ny, ay) || !axis_plan(p->prec, Nx, axx))
+            return fail(ERR_UNSUPPORTED, "unsupported axis length (powers of two up to 2048, any other length up to 1024)");
+        for (auto &a : p->ax) axis_free(a);
+        p->ax[0] = az; p->ax[1] = ay; p->ax[2] = axx;
+        p->zreal_native = zr_native;
+    }
     p->Nx = Nx; p->Ny = Ny; p->Nz = Nz; p->c2c = c2c != 0;
     p->Nzc = c2c ? Nz : Nz / 2 + 1;
     if ((size_t)P2 > p->Nzc) return fail(ERR_ARG, "partition larger than the grid");
@@ -734,7 +852,7 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
     // (variant 1) where one exists for this length
     {
         PassInfo vi;
-        const bool has = p->prec == DFFT_F64 ? pass_info_f64((int)Nx, 1, &vi) : false;
+        const bool has = p->prec == DFFT_F64 && !p->ax[2].bluestein ? pass_info_f64((int)Nx, 1, &vi) : false;
         p->vinv[2] = has ? 1 : 0;
     }
     // experiment hook: DFFT_VARIANTS="zyx xyz" digits = kernel variant of fwd z,y,x then inv x,y,z
@@ -746,7 +864,8 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
             k++;
         }
     }
-    for (void **t : {&p->tw_x, &p->tw_y, &p->tw_z, &p->tw_zr, &p->tables_d}) if (*t) { (void)hipFree(*t); *t = nullptr; }
+    for (auto &a : p->ax) axis_free(a);
+    for (void **t : {&p->tw_zr, &p->tables_d}) if (*t) { (void)hipFree(*t); *t = nullptr; }
     p->initialized = true;
     // device-side state (twiddles, stream, work area) is created by setWorkArea, so that the
     // decomposition tables can be queried on a host without a GPU (allocate = 0).
@@ -775,10 +894,8 @@ static int upload_tables(dfft_plan *p)
 static int ensure_device_state(dfft_plan *p)
 {
     if (!p->tables_d) TRY(upload_tables(p));
-    if (!p->tw_x) TRY(make_twiddles(p->prec, p->Nx, &p->tw_x));
-    if (!p->tw_y) TRY(make_twiddles(p->prec, p->Ny, &p->tw_y));
-    if (!p->tw_z) TRY(make_twiddles(p->prec, p->c2c ? p->Nz : p->Nz / 2, &p->tw_z));
-    if (!p->c2c && !p->tw_zr) TRY(make_twiddles(p->prec, p->Nz, &p->tw_zr));
+    for (auto &a : p->ax) TRY(axis_upload(p->prec, a));
+    if (p->zreal_native && !p->tw_zr) TRY(make_twiddles(p->prec, p->Nz, &p->tw_zr));
     if (!p->stream && !p->stream_user) {
         HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
         p->stream_owned = true;
@@ -953,30 +1070,37 @@ const char *dfft_phase_name(int phase, int direction)
 int dfft_fft1d_batched(int precision, size_t N, size_t batch, void *out, const void *in, int direction,
                        void *hip_stream)
 {
-    PassInfo pi;
-    if (!pass_info(precision, (int)N, &pi)) return fail(ERR_UNSUPPORTED, "unsupported line length");
-    static thread_local void *tw = nullptr;
-    static thread_local size_t twN = 0;
-    static thread_local int twP = -1;
-    if (twN != N || twP != precision) {
-        if (tw) (void)hipFree(tw);
-        tw = nullptr;
-        TRY(make_twiddles(precision, N, &tw));
-        twN = N; twP = precision;
+    static thread_local Axis ax;
+    static thread_local int axP = -1;
+    if (ax.N != N || axP != precision) {
+        axis_free(ax);
+        ax = Axis();
+        if (!axis_plan(precision, N, ax)) return fail(ERR_UNSUPPORTED, "unsupported line length");
+        TRY(axis_upload(precision, ax));
+        axP = precision;
     }
+    PassInfo pi;
+    pass_info(precision, (int)ax.M, &pi);
     PassArgs A;
     memset(&A, 0, sizeof(A));
-    A.in = in; A.out = out; A.tw = tw;
+    A.in = in; A.out = out; A.tw = ax.tw;
     A.na = 1; A.LB = (uint32_t)batch; A.nb = ((uint32_t)batch + pi.TL - 1) / pi.TL; A.ntiles = A.nb;
     A.load_kind = LOAD_LINES; A.store_kind = STORE_LINES; A.swap = direction == DFFT_INVERSE;
-    return launch_pass(precision, (int)N, getenv("DFFT_VARIANT_1D") ? atoi(getenv("DFFT_VARIANT_1D")) : 0, A, (hipStream_t)hip_stream);
+    if (!ax.bluestein)
+        return launch_pass(precision, (int)N, getenv("DFFT_VARIANT_1D") ? atoi(getenv("DFFT_VARIANT_1D")) : 0, A, (hipStream_t)hip_stream);
+    A.tw2 = ax.chirp; A.tw3 = ax.bhat; A.NL = (uint32_t)N; A.NK = (uint32_t)N;
+    int r = precision == DFFT_F64 ? launch_bluestein_f64((int)ax.M, A, (hipStream_t)hip_stream)
+                                  : launch_bluestein_f32((int)ax.M, A, (hipStream_t)hip_stream);
+    if (r != 0) return fail(r == -1 ? ERR_UNSUPPORTED : r, "Bluestein launch failed");
+    return 0;
 }
 
 int dfft_kernel_info(int precision, size_t N, int *threads, int *lds_bytes, int *points_per_thread,
                      int *lines_per_workgroup)
 {
     PassInfo pi;
-    if (!pass_info(precision, (int)N, &pi)) return ERR_UNSUPPORTED;
+    Axis a;
+    if (!axis_plan(precision, N, a) || !pass_info(precision, (int)a.M, &pi)) return ERR_UNSUPPORTED;
     if (threads) *threads = pi.threads;
     if (lds_bytes) *lds_bytes = pi.lds_bytes;
     if (points_per_thread) *points_per_thread = pi.E;

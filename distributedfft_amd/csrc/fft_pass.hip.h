@@ -55,7 +55,11 @@ struct PassArgs {
     const void *in;
     void *out;
     const void *tw;        // twiddle table, N complex entries exp(-2*pi*i*j/N)
-    const void *tw2;       // real transforms only: exp(-2*pi*i*k/(2N)), k = 0..N, for the split/merge step
+    const void *tw2;       // real transforms: exp(-2*pi*i*k/(2N)), k = 0..N (split/merge); Bluestein: chirp exp(-i*pi*n^2/NL)
+    const void *tw3;       // Bluestein: FFT_N of the conjugate chirp, already divided by N
+    uint32_t NL;           // Bluestein: true line length (<= N/2 + 1/2); 0 otherwise
+    int32_t real_mode;     // Bluestein: 0 complex, 1 real input lines (R2C z pass), 2 real output lines (C2R z pass)
+    uint32_t NK;           // Bluestein: number of points on the spectral side of a real transform (NL/2+1), else NL
     uint32_t na;           // extent of the outer line-set axis
     uint32_t LB;           // extent of the inner (tiled) line-set axis
     uint32_t nb;           // tiles along LB = ceil(LB / TL)
@@ -574,6 +578,160 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
         C r; r.x = v[c].y; r.y = v[c].x;     // swap back
         p[k0] = r;
     });
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Arbitrary line lengths (the reference accepts any size through cuFFT): Bluestein's chirp-z
+// algorithm on top of the power-of-two Stockham chain, all inside one kernel and with the same
+// fused load/store address forms as fft_pass_kernel.
+//   X[k] = w[k] * sum_n (x[n] w[n]) conj(w)[k-n],   w[n] = exp(-i*pi*n^2/NL)
+// = one zero-padded N-point forward transform, a pointwise product with the precomputed
+// spectrum of the conjugate chirp (tw3, includes the 1/N of the inverse), one N-point inverse
+// transform (re<->im swap), and two chirp multiplications.  N = Cfg::kN >= 2*NL - 1.
+// Real plans (real_mode 1/2) run the full complex transform of the real line and keep / rebuild
+// the Hermitian half, which also covers odd lengths.
+// ------------------------------------------------------------------------------------------
+template <int TL>
+__device__ __forceinline__ uint64_t generic_load_offset(const PassArgs &A, const TileCtx<TL> &c, uint32_t n, uint32_t NP)
+{
+    if (A.load_kind == LOAD_LINES) return ((uint64_t)c.a * A.LB + (uint64_t)c.b * TL + c.l) * NP + n;
+    if (A.load_kind == LOAD_KMAJOR) return (uint64_t)n * A.KS_in + (uint64_t)c.a * A.AS_in + (uint64_t)c.b * TL + c.l;
+    return tiled_load_offset<TL>(A, c, n);
+}
+template <int TL>
+__device__ __forceinline__ uint64_t generic_store_offset(const PassArgs &A, const TileCtx<TL> &c, uint32_t k, uint32_t NP)
+{
+    if (A.store_kind == STORE_LINES) return ((uint64_t)c.a * A.LB + (uint64_t)c.b * TL + c.l) * NP + k;
+    if (A.store_kind == STORE_KMAJOR) return (uint64_t)k * A.KS_out + (uint64_t)c.a * A.AS_out + (uint64_t)c.b * TL + c.l;
+    if (A.store_kind == STORE_TILED_TRANSPOSE) return tiled_transpose_store_offset<TL>(A, c, k);
+    uint32_t s0 = A.sseg->start[0], ln = A.sseg->len[0];
+    uint64_t bs = A.sseg->base[0];
+    for (int s = 1; s < A.snseg; s++)
+        if (k >= A.sseg->start[s]) { s0 = A.sseg->start[s]; ln = A.sseg->len[s]; bs = A.sseg->base[s]; }
+    (void)ln;
+    return bs + (uint64_t)(k - s0) * A.LB * A.LA + (uint64_t)c.b * TL * A.LA + (uint64_t)c.a * c.tw + c.l;
+}
+
+// registers hold the outputs of a transform (slot c <-> index t + k0(c)); bring them back to the
+// input order of the next transform (slot c <-> index t + NT*c) through the LDS plane
+template <typename Cfg>
+__device__ __forceinline__ void reorder_natural(typename Cfg::C *v, typename Cfg::real *lds, int t, int lw, int tid, bool lds_dirty)
+{
+    using R = typename Cfg::real;
+    constexpr int N = Cfg::kN, E = Cfg::kE, NT = Cfg::NT, TW = Cfg::TW, RL = Cfg::RLAST, S = E / RL;
+    if constexpr (Cfg::NPASS == 1) {
+        // single thread per line: a register permutation
+        typename Cfg::C tmp[E];
+        static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL); tmp[k0] = v[c]; });
+        static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = tmp[c]; });
+    } else {
+        static_for<0, 2>([&](auto pc) {
+            constexpr int comp = decltype(pc)::value;
+            if (lds_dirty || comp == 1) __syncthreads();
+            static_for<0, E>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
+                lds[lds_pad<Cfg>((t + k0) * TW + lw)] = comp == 0 ? v[c].x : v[c].y;
+            });
+            __syncthreads();
+            static_for<0, E>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                const R val = lds[lds_pad<Cfg>(tid + NT * TW * c)];
+                if (comp == 0) v[c].x = val; else v[c].y = val;
+            });
+        });
+    }
+}
+
+template <typename Cfg>
+__global__ __launch_bounds__(Cfg::THREADS) void fft_bluestein_kernel(const PassArgs A)
+{
+    using C = typename Cfg::C;
+    using R = typename Cfg::real;
+    constexpr int N = Cfg::kN, E = Cfg::kE, TL = Cfg::kTL, NT = Cfg::NT, TW = Cfg::TW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    R *lds = reinterpret_cast<R *>(smem);
+    const int tid = threadIdx.x;
+    const int lw = tid % TW, t = tid / TW;
+    const int g = lw / TL, l = lw % TL;
+    const uint32_t w = blockIdx.x * Cfg::kG + g;
+    const bool tile_ok = w < A.ntiles;
+    TileCtx<TL> tc;
+    tc.a = !tile_ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
+    tc.b = !tile_ok ? 0 : (A.a_fastest ? w / A.na : w % A.nb);
+    tc.l = l;
+    const uint32_t rem = A.LB - tc.b * TL;
+    tc.tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;
+    const bool active = tile_ok && (uint32_t)l < tc.tw;
+    const uint32_t NL = A.NL, NK = A.NK;
+    const C *__restrict__ in = reinterpret_cast<const C *>(A.in);
+    const R *__restrict__ rin = reinterpret_cast<const R *>(A.in);
+    C *__restrict__ out = reinterpret_cast<C *>(A.out);
+    R *__restrict__ rout = reinterpret_cast<R *>(A.out);
+    const C *__restrict__ W = reinterpret_cast<const C *>(A.tw);
+    const C *__restrict__ CH = reinterpret_cast<const C *>(A.tw2);
+    const C *__restrict__ BH = reinterpret_cast<const C *>(A.tw3);
+
+    C v[E];
+    static_for<0, E>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        const uint32_t n = t + NT * c;
+        C x; x.x = 0; x.y = 0;
+        if (active && n < NL) {
+            if (A.real_mode == 1) {            // real input line
+                x.x = rin[generic_load_offset<TL>(A, tc, n, NL)];
+            } else if (A.real_mode == 2) {     // Hermitian half in, rebuild the full spectrum
+                if (n < NK) {
+                    x = in[generic_load_offset<TL>(A, tc, n, NK)];
+                    if (n == 0 || 2 * n == NL) x.y = 0;
+                } else {
+                    x = in[generic_load_offset<TL>(A, tc, NL - n, NK)];
+                    x.y = -x.y;
+                }
+            } else {
+                x = in[generic_load_offset<TL>(A, tc, n, NL)];
+            }
+            if (A.swap) { R tmp = x.x; x.x = x.y; x.y = tmp; }
+            const C ch = CH[n];
+            C r; r.x = x.x * ch.x - x.y * ch.y; r.y = x.x * ch.y + x.y * ch.x;
+            x = r;
+        }
+        v[c] = x;
+    });
+    transform<Cfg>(v, lds, W, t, lw, tid);
+    {   // pointwise product with the chirp spectrum, then swap for the inverse transform
+        constexpr int RL = Cfg::RLAST, S = E / RL;
+        static_for<0, E>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
+            const C b = BH[t + k0];
+            C x = v[c];
+            v[c].y = x.x * b.x - x.y * b.y;      // swapped: (im, re)
+            v[c].x = x.x * b.y + x.y * b.x;
+        });
+    }
+    reorder_natural<Cfg>(v, lds, t, lw, tid, Cfg::NPASS > 1);
+    if (Cfg::NPASS > 1) __syncthreads();
+    transform<Cfg>(v, lds, W, t, lw, tid);
+    if (!active) return;
+    {
+        constexpr int RL = Cfg::RLAST, S = E / RL;
+        static_for<0, E>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
+            const uint32_t k = t + k0;
+            const uint32_t kmax = A.real_mode == 1 ? NK : NL;
+            if (k < kmax) {
+                C x; x.x = v[c].y; x.y = v[c].x;       // swap back
+                const C ch = CH[k];
+                C r; r.x = x.x * ch.x - x.y * ch.y; r.y = x.x * ch.y + x.y * ch.x;
+                if (A.swap) { R tmp = r.x; r.x = r.y; r.y = tmp; }
+                if (A.real_mode == 2) rout[generic_store_offset<TL>(A, tc, k, NL)] = r.x;
+                else out[generic_store_offset<TL>(A, tc, k, kmax)] = r;
+            }
+        });
+    }
 }
 
 }  // namespace dfft

@@ -52,4 +52,16 @@ int launch_real_f32(int M, int mode, const PassArgs &A, hipStream_t stream)
     }
     return -1;
 }
+
+// Bluestein passes for arbitrary line lengths: M = power of two >= 2*NL - 1
+int launch_bluestein_f32(int M, const PassArgs &A, hipStream_t stream)
+{
+    switch (M) {
+#define X(n, v, cfg) case n: return launch_bluestein_cfg<cfg>(A, stream);
+        DFFT_F32_BASE(X)
+        X(2048, 0, F32_2048)
+#undef X
+    }
+    return -1;
+}
 }  // namespace dfft

@@ -92,7 +92,8 @@ int dfft_plan_destroy(dfft_plan *plan);
 
 /* initFFT(GlobalSize*, Partition*, bool allocate)   include/mpicufft.hpp:60,
  * src/pencil/mpicufft_pencil_opt1.cpp:46-326, src/slab/default/mpicufft_slab.cpp:97-281.
- * P1*P2 must equal the number of ranks.  c2c = 0: R2C/C2R plan (Nz_out = Nz/2+1,
+ * P1*P2 must equal the number of ranks.  Axis lengths: powers of two up to 2048 (native) or any
+ * other length up to 1024 (Bluestein).  c2c = 0: R2C/C2R plan (Nz_out = Nz/2+1,
  * include/params.hpp:30); c2c = 1: complex plan (Nz_out = Nz). */
 int dfft_init(dfft_plan *plan, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int c2c, int allocate);
 /* setWorkArea(void *device, void *host)   mpicufft_pencil_opt1.cpp:329-387.  NULL device =

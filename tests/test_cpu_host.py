@@ -38,10 +38,12 @@ def test_kernel_table():
             info = dfft.kernel_info(n, prec)
             assert info and info["threads"] <= 1024 and info["lds_bytes"] <= 160 * 1024
             assert info["lines_per_workgroup"] % (8 if prec == "double" else 16) == 0
-        assert dfft.kernel_info(3, prec) is None and dfft.kernel_info(4096, prec) is None
+        # other lengths run through Bluestein on the next power of two >= 2N-1 (N <= 1024)
+        assert dfft.kernel_info(3, prec)["points_per_thread"] == 8 and dfft.kernel_info(1000, prec)["threads"] > 0
+        assert dfft.kernel_info(4096, prec) is None and dfft.kernel_info(1025, prec) is None
 
 
-CASES = [((1024, 1024, 1024), 2, 4, False), ((1024, 1024, 1024), 2, 4, True), ((512, 512, 512), 2, 1, True),
+CASES = [((12, 10, 14), 2, 4, False), ((9, 7, 10), 3, 2, True), ((1000, 100, 30), 4, 2, False), ((1024, 1024, 1024), 2, 4, False), ((1024, 1024, 1024), 2, 4, True), ((512, 512, 512), 2, 1, True),
          ((64, 32, 16), 4, 2, False), ((16, 16, 16), 3, 2, True), ((2048, 2048, 2048), 2, 4, True),
          ((256, 256, 256), 1, 1, True), ((64, 64, 64), 3, 5, False), ((128, 64, 32), 8, 1, True)]
 
@@ -73,7 +75,7 @@ def test_init_errors():
     with pytest.raises(dfft.DfftError, match="Invalid Input Partition"):
         pl.initFFT(dfft.GlobalSize(16, 16, 16), dfft.Slab_Partition(2), allocate=False)
     with pytest.raises(dfft.DfftError, match="unsupported"):
-        pl.initFFT(dfft.GlobalSize(16, 16, 6), dfft.Slab_Partition(1), allocate=False, c2c=True)
+        pl.initFFT(dfft.GlobalSize(16, 16, 3000), dfft.Slab_Partition(1), allocate=False, c2c=True)
     world = dfft.Comm.local(4)
     ps = dfft.MPIcuFFT_Slab_Opt1(dfft.Configurations(), world, rank=0)
     with pytest.raises(dfft.DfftError, match="slab"):

@@ -229,7 +229,7 @@ def test_error_behaviour():
     with pytest.raises(dfft.DfftError, match="C2C|R2C"):
         pl.execC2C(1, 1)
     with pytest.raises(dfft.DfftError, match="unsupported"):
-        pl.initFFT(dfft.GlobalSize(12, 16, 16), dfft.Pencil_Partition(1, 1))
+        pl.initFFT(dfft.GlobalSize(5000, 16, 16), dfft.Pencil_Partition(1, 1))
 
 
 @pytest.mark.parametrize("chunks", [1, 2, 3, 5, 8])
@@ -310,3 +310,56 @@ def test_partial_dimension_transforms(shape, P1, P2, d, c2c):
     norm = float(Nz if d == 1 else Nz * Ny)
     for r in range(P):
         assert rel(backs[r].cpu().numpy() / norm, ins[r].cpu().numpy()) < 1e-10
+
+
+# ------------------------------------------------------------------------------------------
+# arbitrary lengths (the reference accepts any size through cuFFT): Bluestein passes
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["double", "float"])
+@pytest.mark.parametrize("N", [3, 5, 6, 7, 9, 10, 12, 15, 17, 30, 100, 127, 243, 250, 384, 500, 1000, 1023])
+def test_fft1d_any_length_vs_oracle(N, prec):
+    batch = 45
+    rng = np.random.default_rng(N)
+    x = (rng.uniform(0, 255, (batch, N)) + 1j * rng.uniform(0, 255, (batch, N))).astype(NPDT[prec])
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros_like(d_in)
+    for direction in (dfft.FORWARD, dfft.INVERSE):
+        torch.cuda.synchronize()
+        dfft.fft1d_batched(d_out, d_in, N, batch, direction, prec)
+        torch.cuda.synchronize()
+        want = orc.fft1d(x.astype(np.complex128), direction)
+        assert rel(d_out.cpu().numpy(), want) < (2e-11 if prec == "double" else 2e-4)
+
+
+@pytest.mark.parametrize("shape", [(12, 10, 14), (9, 7, 10), (30, 16, 50), (100, 3, 24), (5, 384, 6)])
+def test_single_rank_any_size_vs_oracle_and_golden(shape):
+    g, got, back = run_single(shape, "double", seed=20260921)
+    want = orc.fft3d_c2c(g, -1)
+    assert rel(got, want) < 2e-11
+    assert rel(back / g.size, g) < 1e-10
+    if shape == (12, 10, 14):
+        d = np.load(os.path.join(GOLD, "fft3d_small.npz"))
+        assert rel(got, d["c2c_12x10x14"]) < 2e-11
+
+
+@pytest.mark.parametrize("shape,P1,P2", [((12, 10, 14), 2, 4), ((9, 7, 10), 3, 2), ((10, 9, 12), 3, 1), ((30, 20, 18), 2, 3)])
+def test_distributed_any_size_c2c_and_r2c(shape, P1, P2):
+    """the uneven, non-power-of-two grids the survey replayed, C2C and R2C
+    (R2C with odd and even Nz: Hermitian half via the real Bluestein modes)"""
+    plans, ins, spec, backs = run_distributed(shape, P1, P2, "double")
+    want = orc.fft3d_c2c(orc.fill_block(shape, (0, 0, 0), shape, 2, seed=7), -1)
+    n3 = float(np.prod(shape))
+    for r, pl in enumerate(plans):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        ref = want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]]
+        assert np.max(np.abs(spec[r] - ref)) / np.max(np.abs(want)) < 2e-11
+        assert rel(backs[r] / n3, ins[r]) < 1e-10
+    for shp in (shape, (shape[0], shape[1], shape[2] + 1)):
+        plans, ins, spec, backs = run_distributed_real(shp, P1, P2, "double")
+        wantr = orc.fft3d_r2c(orc.fill_block(shp, (0, 0, 0), shp, 1, seed=13))
+        n3 = float(np.prod(shp))
+        for r, pl in enumerate(plans):
+            s, o = pl.getOutSize(), pl.getOutStart()
+            ref = wantr[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]]
+            assert np.max(np.abs(spec[r] - ref)) / np.max(np.abs(wantr)) < 2e-11
+            assert rel(backs[r] / n3, ins[r]) < 1e-10
