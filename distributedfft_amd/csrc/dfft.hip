@@ -551,7 +551,7 @@ static int enqueue_forward(dfft_plan *p, void *out, const void *in)
     p->nspans = 0; p->last_dir = DFFT_FORWARD;
     // event ids: [0,C) z done, [C,2C) ex1 done, [2C,3C) y done, [3C,4C) ex2 done, 4C = entry fence
     if (p->comm) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); }     // comm stream starts after prior work
-    for (int c = 0; c < C; c++) {
+    auto zpass = [&](int c) -> int {
         TRY(span_begin(p, 0, Sc));
         if (p->c2c) TRY(launch(p, pl.fz[c], p->vfwd[0], 0, I, zdst));
         else TRY(launch_real(p, pl.fz[c], 1, I, zdst));
@@ -564,8 +564,9 @@ static int enqueue_forward(dfft_plan *p, void *out, const void *in)
             TRY(span_end(p, Sm));
             EV_RECORD(C + c, Sm);
         }
-    }
-    for (int c = 0; c < C; c++) {
+        return 0;
+    };
+    auto ypass = [&](int c) -> int {
         if (p->P2 > 1) EV_WAIT(C + c, Sc);
         TRY(span_begin(p, 2, Sc));
         TRY(launch(p, pl.fy[c], p->vfwd[1], 1, ysrc, ydst));
@@ -578,6 +579,16 @@ static int enqueue_forward(dfft_plan *p, void *out, const void *in)
             TRY(span_end(p, Sm));
             EV_RECORD(3 * C + c, Sm);
         }
+        return 0;
+    };
+    if (p->P2 > 1) {
+        // pencil: all z chunks first, so that exchange 1 of chunk c overlaps z(c+1)
+        for (int c = 0; c < C; c++) TRY(zpass(c));
+        for (int c = 0; c < C; c++) TRY(ypass(c));
+    } else {
+        // slab (no exchange 1): y(c) only needs z(c); interleave so the first chunk reaches the
+        // wire after one z and one y chunk instead of after the whole z pass
+        for (int c = 0; c < C; c++) { TRY(zpass(c)); TRY(ypass(c)); }
     }
     if (p->P1 > 1) EV_WAIT(3 * C + C - 1, Sc);     // the comm stream is in order: last chunk covers all
     else if (p->P2 > 1) { /* y passes already waited for every ex1 chunk */ }
@@ -854,6 +865,10 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         PassInfo vi;
         const bool has = p->prec == DFFT_F64 && !p->ax[2].bluestein ? pass_info_f64((int)Nx, 1, &vi) : false;
         p->vinv[2] = has ? 1 : 0;
+        // passes that store long runs (tiled-transpose chunks, natural lines): nontemporal variant 3
+        auto nt = [&](const Axis &a) { return p->prec == DFFT_F64 && !a.bluestein && pass_info_f64((int)a.N, 3, &vi) ? 3 : 0; };
+        if (p->c2c) { p->vfwd[0] = nt(p->ax[0]); p->vinv[0] = nt(p->ax[0]); }
+        p->vinv[1] = nt(p->ax[1]);
     }
     // experiment hook: DFFT_VARIANTS="zyx xyz" digits = kernel variant of fwd z,y,x then inv x,y,z
     if (const char *v = getenv("DFFT_VARIANTS")) {

@@ -165,12 +165,13 @@ template <int R, int OFF, int STRIDE, typename C> struct Dif {
 // ------------------------------------------------------------------------------------------
 // TWCHAIN = 1: load only w^k per butterfly and build w^(m k) by successive multiplication
 // (2 live registers instead of RP-1 table loads in flight; error grows by ~RP ulp)
-template <typename R, int N, int E, int TL, int G, int R1, int R2, int R3, int R4, int PLANES, int TWCHAIN = 0>
+// NTMEM: bit 0 = nontemporal global loads, bit 1 = nontemporal global stores (streaming data)
+template <typename R, int N, int E, int TL, int G, int R1, int R2, int R3, int R4, int PLANES, int TWCHAIN = 0, int NTMEM = 0>
 struct PassCfg {
     using real = R;
     using C = typename Vec2<R>::type;
     static constexpr int kN = N, kE = E, kTL = TL, kG = G;
-    static constexpr int r1 = R1, r2 = R2, r3 = R3, r4 = R4, kPLANES = PLANES, kTWCHAIN = TWCHAIN;
+    static constexpr int r1 = R1, r2 = R2, r3 = R3, r4 = R4, kPLANES = PLANES, kTWCHAIN = TWCHAIN, kNTMEM = NTMEM;
     static constexpr int RLAST = R4 > 1 ? R4 : (R3 > 1 ? R3 : (R2 > 1 ? R2 : R1));
     static constexpr int NT = N / E;                 // threads per line
     static constexpr int TW = TL * G;                // lines per workgroup
@@ -308,6 +309,26 @@ __device__ __forceinline__ void transform(typename Cfg::C *v, typename Cfg::real
     }
 }
 
+template <typename Cfg, typename C> __device__ __forceinline__ C stream_load(const C *p)
+{
+    if constexpr (Cfg::kNTMEM & 1) {
+        using T = decltype(C::x);
+        typedef T native2 __attribute__((ext_vector_type(2)));
+        const native2 r = __builtin_nontemporal_load(reinterpret_cast<const native2 *>(p));
+        C v; v.x = r.x; v.y = r.y;
+        return v;
+    } else return *p;
+}
+template <typename Cfg, typename C> __device__ __forceinline__ void stream_store(C *p, C v)
+{
+    if constexpr (Cfg::kNTMEM & 2) {
+        using T = decltype(C::x);
+        typedef T native2 __attribute__((ext_vector_type(2)));
+        native2 r; r.x = v.x; r.y = v.y;
+        __builtin_nontemporal_store(r, reinterpret_cast<native2 *>(p));
+    } else *p = v;
+}
+
 template <typename Cfg>
 __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A)
 {
@@ -339,15 +360,15 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
     if (active) {
         if (A.load_kind == LOAD_LINES) {
             const C *p = in + ((uint64_t)a * A.LB + (uint64_t)b * TL + l) * N + t;
-            static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = p[NT * c]; });
+            static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = stream_load<Cfg>(p + NT * c); });
         } else if (A.load_kind == LOAD_KMAJOR) {
             const C *p = in + (uint64_t)a * A.AS_in + (uint64_t)b * TL + l + (uint64_t)t * A.KS_in;
-            static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = p[(uint64_t)(NT * c) * A.KS_in]; });
+            static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = stream_load<Cfg>(p + (uint64_t)(NT * c) * A.KS_in); });
         } else {
             if (A.lnseg == 1) {
                 const uint64_t len = A.lseg->len[0];
                 const C *p = in + A.lseg->base[0] + (uint64_t)a * len * A.LB + (uint64_t)b * TL * len + l + (uint64_t)t * tw;
-                static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = p[(uint64_t)(NT * c) * tw]; });
+                static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = stream_load<Cfg>(p + (uint64_t)(NT * c) * tw); });
             } else {
                 static_for<0, E>([&](auto cc) {
                     constexpr int c = decltype(cc)::value;
@@ -356,7 +377,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
                     uint64_t bs = A.lseg->base[0];
                     for (int s = 1; s < A.lnseg; s++)
                         if (n >= A.lseg->start[s]) { s0 = A.lseg->start[s]; ln = A.lseg->len[s]; bs = A.lseg->base[s]; }
-                    v[c] = in[bs + (uint64_t)a * ln * A.LB + (uint64_t)b * TL * ln + (uint64_t)(n - s0) * tw + l];
+                    v[c] = stream_load<Cfg>(in + bs + (uint64_t)a * ln * A.LB + (uint64_t)b * TL * ln + (uint64_t)(n - s0) * tw + l);
                 });
             }
         }
@@ -380,14 +401,14 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
-            p[k0] = v[c];
+            stream_store<Cfg>(p + k0, v[c]);
         });
     } else if (A.store_kind == STORE_KMAJOR) {
         C *p = out + (uint64_t)a * A.AS_out + (uint64_t)b * TL + l + (uint64_t)t * A.KS_out;
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
-            p[(uint64_t)k0 * A.KS_out] = v[c];
+            stream_store<Cfg>(p + (uint64_t)k0 * A.KS_out, v[c]);
         });
     } else {
         static_for<0, E>([&](auto cc) {
@@ -409,7 +430,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
                 const uint32_t tw2 = r2 < T2 ? r2 : T2;
                 off = bs + (uint64_t)a * ln * A.LB + (uint64_t)kt * T2 * A.LB + ((uint64_t)b * TL + l) * tw2 + kr;
             }
-            out[off] = v[c];
+            stream_store<Cfg>(out + off, v[c]);
         });
     }
 }
