@@ -67,6 +67,8 @@ struct PassArgs {
     int32_t load_kind, store_kind;
     int32_t swap;          // 1 = inverse transform (swap re/im on load and on store)
     int32_t a_fastest;     // workgroup -> tile order: 0: b fastest (w = a*nb + b), 1: a fastest (w = b*na + a)
+    int32_t xcd_swizzle;   // 1: consecutive tiles go to the same XCD (block b runs on XCD b % 8), so that
+                           //    neighbouring tiles that share a cache line meet in one L2
     uint32_t LA;           // STORE_TILED_SAME: extent of the a axis
     uint32_t T2shift;      // STORE_TILED_TRANSPOSE: log2 of the consumer's tile size
     uint64_t KS_in;        // LOAD_KMAJOR point stride
@@ -309,6 +311,15 @@ __device__ __forceinline__ void transform(typename Cfg::C *v, typename Cfg::real
     }
 }
 
+// logical workgroup index: identity, or the XCD-aware remap of the guide (T1, bijective form)
+__device__ __forceinline__ uint32_t logical_block(const PassArgs &A)
+{
+    const uint32_t id = blockIdx.x;
+    if (!A.xcd_swizzle) return id;
+    const uint32_t cpx = gridDim.x >> 3;
+    return id < (cpx << 3) ? (id & 7) * cpx + (id >> 3) : id;
+}
+
 template <typename Cfg, typename C> __device__ __forceinline__ C stream_load(const C *p)
 {
     if constexpr (Cfg::kNTMEM & 1) {
@@ -343,7 +354,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
     const int t = tid / TW;           // thread within the line
     const int g = lw / TL, l = lw % TL;
 
-    const uint32_t w = blockIdx.x * Cfg::kG + g;            // tile index, b fastest
+    const uint32_t w = logical_block(A) * Cfg::kG + g;      // tile index
     const bool tile_ok = w < A.ntiles;
     const uint32_t a = !tile_ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
     const uint32_t b = !tile_ok ? 0 : (A.a_fastest ? w / A.na : w % A.nb);
@@ -486,7 +497,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
     const int tid = threadIdx.x;
     const int lw = tid % TW, t = tid / TW;
     const int g = lw / TL, l = lw % TL;
-    const uint32_t w = blockIdx.x * Cfg::kG + g;
+    const uint32_t w = logical_block(A) * Cfg::kG + g;
     const bool tile_ok = w < A.ntiles;
     TileCtx<TL> tc;
     tc.a = !tile_ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
@@ -556,7 +567,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
     const int tid = threadIdx.x;
     const int lw = tid % TW, t = tid / TW;
     const int g = lw / TL, l = lw % TL;
-    const uint32_t w = blockIdx.x * Cfg::kG + g;
+    const uint32_t w = logical_block(A) * Cfg::kG + g;
     const bool tile_ok = w < A.ntiles;
     TileCtx<TL> tc;
     tc.a = !tile_ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
@@ -676,7 +687,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_bluestein_kernel(const PassA
     const int tid = threadIdx.x;
     const int lw = tid % TW, t = tid / TW;
     const int g = lw / TL, l = lw % TL;
-    const uint32_t w = blockIdx.x * Cfg::kG + g;
+    const uint32_t w = logical_block(A) * Cfg::kG + g;
     const bool tile_ok = w < A.ntiles;
     TileCtx<TL> tc;
     tc.a = !tile_ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
