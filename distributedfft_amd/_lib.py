@@ -49,6 +49,7 @@ SYMBOLS = [
     ("dfft_world_size", _i, [_vp]),
     ("dfft_get_exchange_tables", _i, [_vp, _i, _psz, _psz, _psz, _psz]),
     ("dfft_exchange", _i, [_vp, _i, _i, _vp, _vp]),
+    ("dfft_get_pipeline_tables", _i, [_vp, _i, _i, _i, _psz, _psz, _psz, _psz]),
     ("dfft_tile_lines", _i, [_vp]),
     ("dfft_get_phase_times", _i, [_vp, C.POINTER(C.c_float), _i]),
     ("dfft_phase_name", C.c_char_p, [_i, _i]),

@@ -256,6 +256,12 @@ class MPIcuFFT:
         check(lib().dfft_get_exchange_tables(self._h, which, *arrs))
         return [list(a) for a in arrs]
 
+    def getPipelineTables(self, direction, which, chunk):
+        n = self.partition.P2 if which == 1 else self.partition.P1
+        arrs = [(C.c_size_t * n)() for _ in range(4)]
+        check(lib().dfft_get_pipeline_tables(self._h, direction, which, chunk, *arrs))
+        return [list(a) for a in arrs]
+
     def getTileLines(self):
         return lib().dfft_tile_lines(self._h)
 

@@ -1075,6 +1075,19 @@ int dfft_get_exchange_tables(const dfft_plan *p, int which, size_t *sc, size_t *
     return 0;
 }
 
+int dfft_get_pipeline_tables(const dfft_plan *p, int direction, int which, int chunk, size_t *sc, size_t *sd,
+                             size_t *rc, size_t *rd)
+{
+    if (!p || !p->initialized) return fail(ERR_STATE, "plan not initialised");
+    if (which != 1 && which != 2) return fail(ERR_ARG, "which must be 1 or 2");
+    if (chunk < 0 || chunk >= p->pl.C) return fail(ERR_ARG, "chunk out of range");
+    const std::vector<A2A> &v = direction == DFFT_INVERSE ? (which == 1 ? p->pl.i1 : p->pl.i2)
+                                                          : (which == 1 ? p->pl.f1 : p->pl.f2);
+    const A2A &T = v[chunk];
+    for (size_t i = 0; i < T.sc.size(); i++) { sc[i] = T.sc[i]; sd[i] = T.sd[i]; rc[i] = T.rc[i]; rd[i] = T.rd[i]; }
+    return 0;
+}
+
 int dfft_enable_phase_timing(dfft_plan *p, int enable)
 {
     if (!p) return fail(ERR_ARG, "null plan");

@@ -153,6 +153,12 @@ int dfft_get_exchange_tables(const dfft_plan *plan, int which, size_t *sendcount
  * MPI_Alltoallv step of the reference in isolation (:784-785 / :829-830, :1297-1298 / :1341-1342);
  * used by the transport tests. */
 int dfft_exchange(dfft_plan *plan, int which, int direction, const void *sendbuf, void *recvbuf);
+/* the tables the pipelined exchanges actually use: chunk `chunk` (0 .. dfft_get_pipeline_chunks-1) of
+ * exchange `which`, for the forward or the inverse transform, in send/recv order of that direction
+ * (bytes; displacements are absolute offsets in the send resp. receive buffer).  Over all chunks
+ * the counts add up to dfft_get_exchange_tables(). */
+int dfft_get_pipeline_tables(const dfft_plan *plan, int direction, int which, int chunk, size_t *sendcounts,
+                             size_t *sdispls, size_t *recvcounts, size_t *rdispls);
 /* lines interleaved per tile in the intermediate layouts */
 int dfft_tile_lines(const dfft_plan *plan);
 

@@ -98,3 +98,50 @@ def test_product_never_touches_the_oracle():
                 if re.search(r"\boracle\b|numpy\.fft|np\.fft|hipfft|rocfft", txt, re.I):
                     bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("shape,P1,P2,c2c", [((64, 32, 16), 4, 2, False), ((16, 16, 16), 3, 2, True), ((30, 20, 18), 2, 3, False),
+                                            ((1024, 1024, 1024), 2, 4, True), ((128, 64, 32), 8, 1, True), ((9, 7, 10), 1, 3, True)])
+@pytest.mark.parametrize("chunks", [1, 3, 4])
+def test_pipeline_tables_are_consistent_across_ranks(shape, P1, P2, c2c, chunks):
+    """the chunked all-to-all tables every rank uses: (1) what rank r sends to peer q in chunk c is
+    exactly what q expects from r, (2) chunks add up to the reference's per-peer message
+    (mpicufft_pencil_opt1.cpp:269-273, 315-319), (3) blocks tile the buffers without overlap"""
+    esz = 16
+    P = P1 * P2
+    world = dfft.Comm.local(P) if P > 1 else None
+    plans = []
+    for r in range(P):
+        pl = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), world, precision="double", rank=r)
+        pl.setPipelineChunks(chunks)
+        pl.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(P1, P2), allocate=False, c2c=c2c)
+        plans.append(pl)
+    C = plans[0].getPipelineChunks()
+    assert all(pl.getPipelineChunks() == C for pl in plans) and 1 <= C <= chunks
+    for direction in (dfft.FORWARD, dfft.INVERSE):
+        for which in (1, 2):
+            n = P2 if which == 1 else P1
+            for r, pl in enumerate(plans):
+                i, j = r // P2, r % P2
+                group = [i * P2 + q for q in range(P2)] if which == 1 else [q * P2 + j for q in range(P1)]
+                me = j if which == 1 else i
+                tot_s, tot_r, spans_s, spans_r = [0] * n, [0] * n, [], []
+                for c in range(C):
+                    sc, sd, rc, rd = pl.getPipelineTables(direction, which, c)
+                    for q in range(n):
+                        psc, psd, prc, prd = plans[group[q]].getPipelineTables(direction, which, c)
+                        assert sc[q] == prc[me] and rc[q] == psc[me]
+                        tot_s[q] += sc[q]
+                        tot_r[q] += rc[q]
+                        if sc[q]:
+                            spans_s.append((sd[q], sd[q] + sc[q]))
+                        if rc[q]:
+                            spans_r.append((rd[q], rd[q] + rc[q]))
+                ref = pl.getExchangeTables(which)
+                want_s, want_r = (ref[0], ref[2]) if direction == dfft.FORWARD else (ref[2], ref[0])
+                assert tot_s == want_s and tot_r == want_r
+                for spans in (spans_s, spans_r):
+                    spans.sort()
+                    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])), "blocks overlap"
+                    assert not spans or spans[-1][1] <= pl.getDomainSize()
+                    assert sum(b - a for a, b in spans) % esz == 0
