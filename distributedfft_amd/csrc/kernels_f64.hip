@@ -48,9 +48,11 @@ bool pass_info_f64(int N, int variant, PassInfo *pi)
     return false;
 }
 
-// real-transform z passes (variant 0 configurations only); M = Nz/2
+// real-transform z passes; M = Nz/2.  512 gets its own 8-points-per-thread configuration: the
+// split/merge step needs both LDS planes, and 512 threads x 64 KiB keeps 16 waves on a CU
+using F64_R512 = PassCfg<double, 512, 8, 8, 1, 8, 8, 8, 1, 1>;
 #define DFFT_F64_BASE(X) X(2, 0, F64_2) X(4, 0, F64_4) X(8, 0, F64_8) X(16, 0, F64_16) X(32, 0, F64_32) X(64, 0, F64_64) \
-    X(128, 0, F64_128) X(256, 0, F64_256) X(512, 0, F64_512) X(1024, 0, F64_1024)
+    X(128, 0, F64_128) X(256, 0, F64_256) X(512, 0, F64_R512) X(1024, 0, F64_1024)
 int launch_real_f64(int M, int mode, const PassArgs &A, hipStream_t stream)
 {
     switch (M) {
