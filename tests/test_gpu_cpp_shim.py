@@ -1,0 +1,32 @@
+"""The C++ binding of INTEGRATION.md on hardware: a reference-style caller built against
+include/mpicufft_amd.hpp + libdfft_amd.so (g++, MPICH from /opt/conda, HIP runtime)."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MPI_INC, MPI_LIB = "/opt/conda/include", "/opt/conda/lib/libmpi.so.12"
+
+
+@pytest.mark.skipif(not (os.path.exists(MPI_LIB) and os.path.exists(os.path.join(MPI_INC, "mpi.h"))),
+                    reason="MPICH from the image is not present")
+def test_cpp_shim_round_trip(tmp_path):
+    exe = tmp_path / "shim_roundtrip"
+    libdir = tmp_path / "mpilib"     # only MPICH's own libraries, not conda's old libstdc++
+    libdir.mkdir()
+    for lib in ("libmpi.so.12", "libgfortran.so.4", "libquadmath.so.0"):
+        src = os.path.join("/opt/conda/lib", lib)
+        if os.path.exists(src):
+            os.symlink(src, libdir / lib)
+    cmd = ["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", MPI_INC, "-I", "/opt/rocm/include",
+           os.path.join(ROOT, "tests", "cpp", "shim_roundtrip.cpp"), "-o", str(exe),
+           os.path.join(ROOT, "distributedfft_amd", "libdfft_amd.so"), MPI_LIB, "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + os.path.join(ROOT, "distributedfft_amd"), "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    env = dict(os.environ, LD_LIBRARY_PATH=f"/opt/rocm/lib:{libdir}")
+    out = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "out size 64 32 25" in out.stdout and "Result (max):" in out.stdout
