@@ -284,13 +284,14 @@ static int build_pipeline(dfft_plan *p, Pipeline &pl)
         A.load_kind = lk; A.store_kind = sk; A.swap = swap; A.T2shift = T2shift;
         return A;
     };
-    std::vector<size_t> xl, x0, kl, k0, tmp_l, tmp_0;
+    std::vector<size_t> xl, x0, kl, k0;
     split(xs, C, xl, x0);       // my x range in chunks (forward z/y, inverse y/z passes)
     split(yo, C, kl, k0);       // my ky range in chunks (inverse x pass)
     // chunk c of every column peer's x / ky range (they split with the same rule)
     std::vector<std::vector<size_t>> xlq(P1), x0q(P1), klq(P1), k0q(P1);
     for (int q = 0; q < P1; q++) { split(p->xs[q], C, xlq[q], x0q[q]); split(p->yo[q], C, klq[q], k0q[q]); }
 
+    pl.fx = Launch();           // (initFFT may be called again on the same plan)
     pl.fz.assign(C, Launch()); pl.fy.assign(C, Launch()); pl.ix.assign(C, Launch());
     pl.iy.assign(C, Launch()); pl.iz.assign(C, Launch());
     pl.f1.assign(C, A2A()); pl.f2.assign(C, A2A()); pl.i2.assign(C, A2A()); pl.i1.assign(C, A2A());

@@ -363,3 +363,22 @@ def test_distributed_any_size_c2c_and_r2c(shape, P1, P2):
             ref = wantr[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]]
             assert np.max(np.abs(spec[r] - ref)) / np.max(np.abs(wantr)) < 2e-11
             assert rel(backs[r] / n3, ins[r]) < 1e-10
+
+
+def test_plan_can_be_reinitialised():
+    """initFFT twice on one object (the reference allows it: plans are rebuilt in initFFT)"""
+    plan = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), precision="double")
+    for shape, c2c in [((32, 32, 32), True), ((16, 64, 8), False), ((12, 10, 14), True), ((64, 16, 32), True)]:
+        plan.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(1, 1), True, c2c=c2c)
+        g = orc.fill_block(shape, (0, 0, 0), shape, 2 if c2c else 1, seed=3)
+        d_in = torch.from_numpy(g).cuda()
+        d_out = torch.zeros(plan.getDomainSize() // 16, dtype=torch.complex128, device="cuda")
+        torch.cuda.synchronize()
+        if c2c:
+            plan.execC2C(d_out, d_in, dfft.FORWARD)
+            want = orc.fft3d_c2c(g, -1)
+        else:
+            plan.execR2C(d_out, d_in)
+            want = orc.fft3d_r2c(g)
+        got = d_out[:want.size].cpu().numpy().reshape(want.shape)
+        assert rel(got, want) < 2e-11
