@@ -288,12 +288,25 @@ def main():
                        "decomposition": "single GPU, three local axis passes" if ngpus == 1 else
                        (f"slab P={P1}" if P2 == 1 else f"pencil {P1}x{P2}"),
                        "transport": transport, "exchange_ms_per_step": round(exch_ms / args.steps, 3),
-                       "fft_ms_per_step": round(kern_ms / args.steps, 3)},
+                       "fft_ms_per_step": round(kern_ms / args.steps, 3),
+                       "pipeline_chunks": plan.getPipelineChunks()},
             "round_trip_rel_linf": rt_err,
             "roofline": roofline,
         }
         if alt is not None:
             out["config"]["alt"] = alt
+        if ngpus > 1:
+            # bytes one GPU puts on xGMI per step (forward + inverse) and the rate the exchange phases
+            # reach (device time of the exchange spans, which overlap the kernels when pipelined)
+            vol = esz * float(N) ** 3 / ngpus
+            out_bytes = 2.0 * vol * ((P1 - 1) / P1 + (P2 - 1) / P2)
+            links = max(P1 - 1, 1) if P2 == 1 else None
+            xg = {"bytes_out_per_gpu_per_step": out_bytes,
+                  "achieved_GBps_per_gpu": round(out_bytes / (exch_ms / args.steps * 1e-3) / 1e9, 1) if exch_ms > 0 else None}
+            if links:
+                xg["links_in_use"] = links
+                xg["achieved_GBps_per_link"] = round(xg["achieved_GBps_per_gpu"] / links, 1) if xg["achieved_GBps_per_gpu"] else None
+            out["xgmi"] = xg
         if not args.no_cpu_baseline and ngpus == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_n)
         print(json.dumps(out), flush=True)
