@@ -382,3 +382,58 @@ def test_plan_can_be_reinitialised():
             want = orc.fft3d_r2c(g)
         got = d_out[:want.size].cpu().numpy().reshape(want.shape)
         assert rel(got, want) < 2e-11
+
+
+def test_randomised_sweep_of_shapes_partitions_and_depths():
+    """60 random (grid, P1 x P2, pipeline depth, R2C|C2C) combinations against the oracle: tiny and
+    odd extents, partitions as large as the extents allow, depths that do not divide anything"""
+    rng = np.random.default_rng(20260921)
+    sizes = [2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 15, 16, 18, 20, 24, 27, 30, 32, 33, 40, 48, 64]
+    done = 0
+    while done < 60:
+        shape = tuple(int(rng.choice(sizes)) for _ in range(3))
+        c2c = bool(rng.integers(0, 2))
+        Nzc = shape[2] if c2c else shape[2] // 2 + 1
+        P1 = int(rng.integers(1, 5))
+        P2 = int(rng.integers(1, 5))
+        if P1 > min(shape[0], shape[1]) or P2 > min(shape[1], Nzc):
+            continue
+        chunks = int(rng.integers(1, 6))
+        if c2c:
+            plans, ins, spec, backs = run_distributed(shape, P1, P2, "double", seed=done, chunks=chunks)
+            g = orc.fill_block(shape, (0, 0, 0), shape, 2, seed=done)
+            want = orc.fft3d_c2c(g, -1)
+        else:
+            P = P1 * P2
+            world = dfft.Comm.local(P) if P > 1 else None
+            plans, ins, outs, backs = [], [], [], []
+            for r in range(P):
+                pl = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), world, precision="double", rank=r)
+                pl.setPipelineChunks(chunks)
+                pl.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(P1, P2), True)
+                s, o = pl.getInSize(), pl.getInStart()
+                plans.append(pl)
+                ins.append(torch.from_numpy(orc.fill_block(shape, o, s, 1, seed=done)).cuda())
+                outs.append(torch.zeros(pl.getDomainSize() // 16, dtype=torch.complex128, device="cuda"))
+                backs.append(torch.zeros_like(ins[-1]))
+            torch.cuda.synchronize()
+            with ThreadPoolExecutor(P) as ex:
+                list(ex.map(lambda r: plans[r].execR2C(outs[r], ins[r]), range(P)))
+            spec = []
+            for r in range(P):
+                s = plans[r].getOutSize()
+                spec.append(outs[r][:s[0] * s[1] * s[2]].cpu().numpy().reshape(s))
+            with ThreadPoolExecutor(P) as ex:
+                list(ex.map(lambda r: plans[r].execC2R(backs[r], outs[r]), range(P)))
+            torch.cuda.synchronize()
+            ins = [t.cpu().numpy() for t in ins]
+            backs = [t.cpu().numpy() for t in backs]
+            want = orc.fft3d_r2c(orc.fill_block(shape, (0, 0, 0), shape, 1, seed=done))
+        n3 = float(np.prod(shape))
+        scale = np.max(np.abs(want))
+        for r, pl in enumerate(plans):
+            s, o = pl.getOutSize(), pl.getOutStart()
+            ref = want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]]
+            assert np.max(np.abs(spec[r] - ref)) / scale < 2e-11, (shape, P1, P2, chunks, c2c, r)
+            assert rel(backs[r] / n3, ins[r]) < 1e-10, (shape, P1, P2, chunks, c2c, r)
+        done += 1
