@@ -22,10 +22,13 @@ using F64_1024_v1 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1>;
 // variant 3 = nontemporal loads and stores, for passes whose stores come in long runs (tiled
 // 1 KiB chunks, natural lines): +2-3 %; it costs 10 % on the 128-B-run stores, so those keep 0
 using F64_1024_v3 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 3>;
+using F64_512_v1 = PassCfg<double, 512, 32, 8, 2, 32, 16, 1, 1, 1, 1>;      // strided read, 512
+using F64_512_v3 = PassCfg<double, 512, 16, 8, 1, 8, 8, 8, 1, 1, 0, 3>;       // nontemporal, 512
+using F64_2048_v3 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 3>;   // nontemporal, 2048
 // variant 2 = table-loaded twiddles (bit-for-bit the round-1 baseline), kept for A/B runs
 using F64_1024_v2 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 0>;
 
-#define DFFT_F64_LIST(X) X(1024, 1, F64_1024_v1) X(1024, 2, F64_1024_v2) X(1024, 3, F64_1024_v3) \
+#define DFFT_F64_LIST(X) X(1024, 1, F64_1024_v1) X(1024, 2, F64_1024_v2) X(1024, 3, F64_1024_v3) X(512, 1, F64_512_v1) X(512, 3, F64_512_v3) X(2048, 3, F64_2048_v3) \
     X(2, 0, F64_2) X(4, 0, F64_4) X(8, 0, F64_8) X(16, 0, F64_16) X(32, 0, F64_32) X(64, 0, F64_64) \
     X(128, 0, F64_128) X(256, 0, F64_256) X(512, 0, F64_512) X(1024, 0, F64_1024) X(2048, 0, F64_2048)
 
