@@ -365,7 +365,8 @@ static int build_pipeline(dfft_plan *p, Pipeline &pl)
             L.args.AS_in = zs;
             // aligned pitch: step along ky between neighbouring workgroups (DRAM/TLB spread);
             // odd pitch (R2C): neighbouring z' tiles on one XCD so the shared lines are read once
-            if (zs % TL == 0) { L.args.a_fastest = 1; } else { L.args.a_fastest = 0; L.args.xcd_swizzle = 1; }
+            L.args.xcd_swizzle = 1;
+            L.args.a_fastest = zs % TL == 0 ? 1 : 0;
             L.in_off = e * k0[c] * zs;
             for (int q = 0; q < P1; q++) seg_push(L.sseg, p->xstart[q], p->xs[q], S2i + p->xstart[q] * zs * kl[c]);
             L.args.LA = (uint32_t)kl[c];
