@@ -801,6 +801,7 @@ int dfft_plan_destroy(dfft_plan *p)
 int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int c2c, int allocate)
 {
     if (!p) return fail(ERR_ARG, "null plan");
+    p->initialized = false;      // a failed (re-)initialisation must not leave a half-updated plan executable
     if (!Nx || !Ny || !Nz) return fail(ERR_ARG, "GlobalSize not initialized!");
     if (P1 < 1 || P2 < 1 || P1 * P2 != p->nranks) return fail(ERR_ARG, "Invalid Input Partition!");
     if ((p->kind == DFFT_SLAB || p->kind == DFFT_SLAB_OPT1) && P2 != 1)
