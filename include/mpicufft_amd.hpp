@@ -11,9 +11,15 @@
 #pragma once
 #include <mpi.h>
 
+#include <climits>
+#include <cstring>
+#include <map>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <vector>
+
+#include <hip/hip_runtime_api.h>
 
 #include "dfft_c.h"
 
@@ -36,6 +42,67 @@ struct Configurations {
     SendMethod send_method2;
 };
 
+// Host-staged exchange = the reference's cuda_aware == false path (device -> pinned host ->
+// MPI_Alltoallv -> device, src/pencil/mpicufft_pencil_opt1.cpp:777-779, 834-836).  Works with any
+// MPI and with several ranks sharing one GPU (where RCCL cannot be used).  Plugged into the library
+// through its callback transport; sub-communicators for the row/column groups are split lazily.
+class DfftHostStagedMPI {
+public:
+    explicit DfftHostStagedMPI(MPI_Comm comm) : comm_(comm) {}
+    ~DfftHostStagedMPI()
+    {
+        for (auto &kv : groups_) MPI_Comm_free(&kv.second);
+        if (hsend_) hipHostFree(hsend_);
+        if (hrecv_) hipHostFree(hrecv_);
+    }
+    static int alltoallv(void *user, const void *sendbuf, const size_t *scounts, const size_t *sdispls, void *recvbuf,
+                         const size_t *rcounts, const size_t *rdispls, const int *group, int ngroup, int me, void *stream)
+    {
+        return static_cast<DfftHostStagedMPI *>(user)->run(sendbuf, scounts, sdispls, recvbuf, rcounts, rdispls, group, ngroup, me,
+                                                            static_cast<hipStream_t>(stream));
+    }
+
+private:
+    int run(const void *sendbuf, const size_t *sc, const size_t *sd, void *recvbuf, const size_t *rc, const size_t *rd,
+            const int *group, int ng, int me, hipStream_t stream)
+    {
+        auto key = std::make_tuple(group[0], ng > 1 ? group[1] - group[0] : 0, ng);
+        auto it = groups_.find(key);
+        if (it == groups_.end()) {
+            MPI_Comm sub;
+            // collective over the parent: every rank is in exactly one group of this exchange
+            MPI_Comm_split(comm_, group[0], me, &sub);
+            it = groups_.emplace(key, sub).first;
+        }
+        size_t stot = 0, rtot = 0;
+        std::vector<int> isc(ng), isd(ng), irc(ng), ird(ng);
+        for (int q = 0; q < ng; q++) {
+            if (sc[q] > (size_t)INT_MAX || rc[q] > (size_t)INT_MAX || stot > (size_t)INT_MAX || rtot > (size_t)INT_MAX) return 2;
+            isc[q] = (int)sc[q]; isd[q] = (int)stot; stot += sc[q];
+            irc[q] = (int)rc[q]; ird[q] = (int)rtot; rtot += rc[q];
+        }
+        if (stot > hcap_s_) { if (hsend_) hipHostFree(hsend_); if (hipHostMalloc(&hsend_, stot) != hipSuccess) return 3; hcap_s_ = stot; }
+        if (rtot > hcap_r_) { if (hrecv_) hipHostFree(hrecv_); if (hipHostMalloc(&hrecv_, rtot) != hipSuccess) return 3; hcap_r_ = rtot; }
+        for (int q = 0; q < ng; q++)
+            if (sc[q] && hipMemcpyAsync(static_cast<char *>(hsend_) + isd[q], static_cast<const char *>(sendbuf) + sd[q], sc[q],
+                                        hipMemcpyDeviceToHost, stream) != hipSuccess) return 4;
+        if (hipStreamSynchronize(stream) != hipSuccess) return 4;
+        if (MPI_Alltoallv(hsend_, isc.data(), isd.data(), MPI_BYTE, hrecv_, irc.data(), ird.data(), MPI_BYTE, it->second) != MPI_SUCCESS)
+            return 5;
+        for (int q = 0; q < ng; q++)
+            if (rc[q] && hipMemcpyAsync(static_cast<char *>(recvbuf) + rd[q], static_cast<const char *>(hrecv_) + ird[q], rc[q],
+                                        hipMemcpyHostToDevice, stream) != hipSuccess) return 4;
+        // peers may overwrite nothing of mine (everything went through host copies), but my own next
+        // exchange reuses the staging buffers: drain before returning
+        if (hipStreamSynchronize(stream) != hipSuccess) return 4;
+        return 0;
+    }
+    MPI_Comm comm_;
+    std::map<std::tuple<int, int, int>, MPI_Comm> groups_;
+    void *hsend_ = nullptr, *hrecv_ = nullptr;
+    size_t hcap_s_ = 0, hcap_r_ = 0;
+};
+
 template <typename T> class MPIcuFFT {
 public:
     MPIcuFFT(Configurations config, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1, int kind = DFFT_PENCIL_OPT1)
@@ -45,13 +112,16 @@ public:
         if (max_world_size > 0 && max_world_size < pcnt) pcnt = max_world_size;   // src/mpicufft.cpp:46-51
         if (pidx >= pcnt) return;                                                 // not part of the FFT world
         if (pcnt > 1) {
-            char id[128];
-            if (pidx == 0) check(dfft_rccl_unique_id(id));
-            MPI_Comm sub;
-            MPI_Comm_split(comm, 0, pidx, &sub);
-            MPI_Bcast(id, 128, MPI_BYTE, 0, sub);
-            MPI_Comm_free(&sub);
-            check(dfft_comm_create_rccl(id, pcnt, pidx, &comm_));
+            MPI_Comm_split(comm, 0, pidx, &sub_);      // the first pcnt ranks (src/mpicufft.cpp:46-51)
+            if (config.cuda_aware) {                   // device path: RCCL over xGMI, one rank per GPU
+                char id[128];
+                if (pidx == 0) check(dfft_rccl_unique_id(id));
+                MPI_Bcast(id, 128, MPI_BYTE, 0, sub_);
+                check(dfft_comm_create_rccl(id, pcnt, pidx, &comm_));
+            } else {                                   // host-staged MPI, ranks may share a GPU
+                staged_ = new DfftHostStagedMPI(sub_);
+                check(dfft_comm_create_callback(pcnt, pidx, &DfftHostStagedMPI::alltoallv, staged_, &comm_));
+            }
         }
         dfft_config c{config.cuda_aware, config.warmup_rounds, (int)config.comm_method, (int)config.send_method,
                       (int)config.comm_method2, (int)config.send_method2};
@@ -61,6 +131,8 @@ public:
     {
         dfft_plan_destroy(plan_);
         if (comm_) dfft_comm_destroy(comm_);
+        delete staged_;
+        if (sub_ != MPI_COMM_NULL) MPI_Comm_free(&sub_);
     }
     virtual void initFFT(GlobalSize *global_size, Partition *partition, bool allocate = true)
     {
@@ -96,6 +168,8 @@ protected:
     }
     dfft_plan *plan_ = nullptr;
     dfft_comm *comm_ = nullptr;
+    DfftHostStagedMPI *staged_ = nullptr;
+    MPI_Comm sub_ = MPI_COMM_NULL;
     int pidx = 0, pcnt = 1;
 };
 

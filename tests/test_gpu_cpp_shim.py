@@ -11,22 +11,44 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MPI_INC, MPI_LIB = "/opt/conda/include", "/opt/conda/lib/libmpi.so.12"
 
 
-@pytest.mark.skipif(not (os.path.exists(MPI_LIB) and os.path.exists(os.path.join(MPI_INC, "mpi.h"))),
-                    reason="MPICH from the image is not present")
-def test_cpp_shim_round_trip(tmp_path):
-    exe = tmp_path / "shim_roundtrip"
+needs_mpich = pytest.mark.skipif(not (os.path.exists(MPI_LIB) and os.path.exists(os.path.join(MPI_INC, "mpi.h"))),
+                                 reason="MPICH from the image is not present")
+
+
+def build(tmp_path, source):
+    exe = tmp_path / source.replace(".cpp", "")
     libdir = tmp_path / "mpilib"     # only MPICH's own libraries, not conda's old libstdc++
-    libdir.mkdir()
+    libdir.mkdir(exist_ok=True)
     for lib in ("libmpi.so.12", "libgfortran.so.4", "libquadmath.so.0"):
         src = os.path.join("/opt/conda/lib", lib)
-        if os.path.exists(src):
+        if os.path.exists(src) and not os.path.exists(libdir / lib):
             os.symlink(src, libdir / lib)
-    cmd = ["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", MPI_INC, "-I", "/opt/rocm/include",
-           os.path.join(ROOT, "tests", "cpp", "shim_roundtrip.cpp"), "-o", str(exe),
+    cmd = ["g++", "-std=c++17", "-O1", "-w", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", MPI_INC, "-I", "/opt/rocm/include",
+           os.path.join(ROOT, "tests", "cpp", source), "-o", str(exe),
            os.path.join(ROOT, "distributedfft_amd", "libdfft_amd.so"), MPI_LIB, "-L/opt/rocm/lib", "-lamdhip64",
            "-Wl,-rpath," + os.path.join(ROOT, "distributedfft_amd"), "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
     subprocess.check_call(cmd)
-    env = dict(os.environ, LD_LIBRARY_PATH=f"/opt/rocm/lib:{libdir}")
+    return exe, dict(os.environ, LD_LIBRARY_PATH=f"/opt/rocm/lib:{libdir}")
+
+
+@needs_mpich
+def test_cpp_shim_round_trip(tmp_path):
+    exe, env = build(tmp_path, "shim_roundtrip.cpp")
     out = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "out size 64 32 25" in out.stdout and "Result (max):" in out.stdout
+
+
+@needs_mpich
+@pytest.mark.parametrize("P1,P2", [(2, 1), (2, 2), (3, 2)])
+def test_cpp_shim_mpi_ranks_sharing_the_gpu(tmp_path, P1, P2):
+    """mpiexec -n P: real MPI ranks (one process each) share GPU 0 and exchange through the shim's
+    host-staged MPI transport = the reference's cuda_aware = false path"""
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not os.path.exists(mpiexec):
+        pytest.skip("no mpiexec")
+    exe, env = build(tmp_path, "shim_mpi_multirank.cpp")
+    out = subprocess.run([mpiexec, "-n", str(P1 * P2), str(exe), str(P1), str(P2)], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert f"ranks {P1 * P2} grid {P1}x{P2}" in out.stdout
