@@ -877,6 +877,11 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         auto nt = [&](const Axis &a) { return p->prec == DFFT_F64 && !a.bluestein && pass_info_f64((int)a.N, 3, &vi) ? 3 : 0; };
         if (p->c2c) { p->vfwd[0] = nt(p->ax[0]); p->vinv[0] = nt(p->ax[0]); }
         p->vinv[1] = nt(p->ax[1]);
+        // fp32: point-fastest lane mappings for the natural-line passes (variants 4 / 5, PassCfg::MAP)
+        if (p->prec == DFFT_F32 && p->c2c && !p->ax[0].bluestein) {
+            if (pass_info_f32((int)p->ax[0].N, 4, &vi)) p->vfwd[0] = 4;
+            if (pass_info_f32((int)p->ax[0].N, 5, &vi)) p->vinv[0] = 5;
+        }
     }
     if (const char *v = getenv("DFFT_ORDER")) {   // experiment hook: per pass digit = a_fastest + 2*xcd_swizzle (fwd z,y,x then inv x,y,z)
         int k = 0;

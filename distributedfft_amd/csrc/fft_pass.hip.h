@@ -168,12 +168,18 @@ template <int R, int OFF, int STRIDE, typename C> struct Dif {
 // TWCHAIN = 1: load only w^k per butterfly and build w^(m k) by successive multiplication
 // (2 live registers instead of RP-1 table loads in flight; error grows by ~RP ulp)
 // NTMEM: bit 0 = nontemporal global loads, bit 1 = nontemporal global stores (streaming data)
-template <typename R, int N, int E, int TL, int G, int R1, int R2, int R3, int R4, int PLANES, int TWCHAIN = 0, int NTMEM = 0>
+// MAP: thread <-> (line, point) mapping.  0 = line fastest in every pass (lane = line + TW*t).
+//      1 = point fastest (16 adjacent points of one line in adjacent lanes) in every pass,
+//      2 = line fastest for the first pass (its loads), point fastest afterwards (its stores).
+//      The point-fastest forms exist for fp32: with 8-byte points and 16-line tiles a line-fastest
+//      wave touches natural lines and transposed tiles in 32-byte pieces; point fastest makes
+//      those accesses 128-byte runs.  The LDS exchange between passes does the re-mapping for free.
+template <typename R, int N, int E, int TL, int G, int R1, int R2, int R3, int R4, int PLANES, int TWCHAIN = 0, int NTMEM = 0, int MAP = 0>
 struct PassCfg {
     using real = R;
     using C = typename Vec2<R>::type;
     static constexpr int kN = N, kE = E, kTL = TL, kG = G;
-    static constexpr int r1 = R1, r2 = R2, r3 = R3, r4 = R4, kPLANES = PLANES, kTWCHAIN = TWCHAIN, kNTMEM = NTMEM;
+    static constexpr int r1 = R1, r2 = R2, r3 = R3, r4 = R4, kPLANES = PLANES, kTWCHAIN = TWCHAIN, kNTMEM = NTMEM, kMAP = MAP;
     static constexpr int RLAST = R4 > 1 ? R4 : (R3 > 1 ? R3 : (R2 > 1 ? R2 : R1));
     static constexpr int NT = N / E;                 // threads per line
     static constexpr int TW = TL * G;                // lines per workgroup
@@ -182,7 +188,14 @@ struct PassCfg {
     static constexpr int PS = ilog2(R1 * TW);        // pad once per first-pass scatter stride ...
     static constexpr int PWS = ilog2(TW) > 4 ? 4 : ilog2(TW);   // ... by min(TW,16) slots
     static constexpr int SLOTS = N * TW;
-    static constexpr int PLANE_SLOTS = SLOTS + ((SLOTS >> PS) << PWS);
+    // MAP != 0: line-major LDS plane [line][n + n/32] with a pitch that keeps the 16-point groups
+    // of the lines sharing a 32-lane LDS group on different banks
+    static constexpr int PGRP = 16;
+    static constexpr int PITCH_BASE = N + N / 32;
+    static constexpr int PITCH_WANT = MAP == 2 ? 17 : 16;
+    static constexpr int PITCH = PITCH_BASE + ((PITCH_WANT - PITCH_BASE % 32 + 32) % 32);
+    static constexpr int PLANE_SLOTS = MAP == 0 ? SLOTS + ((SLOTS >> PS) << PWS) : TW * PITCH;
+    static_assert(MAP == 0 || ((N / E) % 16 == 0 && G == 1), "point-fastest mapping needs >= 16 threads per line");
     static constexpr size_t LDS_BYTES = NPASS > 1 ? (size_t)PLANES * PLANE_SLOTS * sizeof(R) : 0;
     static_assert((R1 > 1 ? R1 : 1) * (R2 > 1 ? R2 : 1) * (R3 > 1 ? R3 : 1) * (R4 > 1 ? R4 : 1) == N, "radices must multiply to N");
     static_assert(E % R1 == 0 && (R2 <= 1 || E % R2 == 0) && (R3 <= 1 || E % R3 == 0) && (R4 <= 1 || E % R4 == 0), "radix must divide E");
@@ -238,6 +251,26 @@ __device__ __forceinline__ void pass_compute(typename Cfg::C *v, int t, const ty
     });
 }
 
+
+// thread -> (line within workgroup, thread within line)
+template <typename Cfg, bool POINT_FASTEST> __device__ __forceinline__ void thread_map(int tid, int &lw, int &t)
+{
+    if constexpr (!POINT_FASTEST) {
+        lw = tid % Cfg::TW;
+        t = tid / Cfg::TW;
+    } else {
+        constexpr int PG = Cfg::PGRP;
+        lw = (tid / PG) % Cfg::TW;
+        t = (tid % PG) + PG * (tid / (PG * Cfg::TW));
+    }
+}
+// LDS slot of point n of line lw
+template <typename Cfg> __device__ __forceinline__ int lds_slot(int lw, int n)
+{
+    if constexpr (Cfg::kMAP == 0) return lds_pad<Cfg>(n * Cfg::TW + lw);
+    else return lw * Cfg::PITCH + n + (n >> 5);
+}
+
 // scatter the outputs of pass (RP, NS) to LDS plane, Stockham output index
 template <typename Cfg, int RP, int NS, int COMP>
 __device__ __forceinline__ void lds_scatter(const typename Cfg::C *v, typename Cfg::real *plane, int t, int lw)
@@ -251,23 +284,25 @@ __device__ __forceinline__ void lds_scatter(const typename Cfg::C *v, typename C
         static_for<0, RP>([&](auto mc) {
             constexpr int mr = decltype(mc)::value;          // register slot
             constexpr int m = brev(mr, RP);                  // output index of that slot
-            const int idx = lds_pad<Cfg>((nbase + m * NS) * Cfg::TW + lw);
+            const int idx = lds_slot<Cfg>(lw, nbase + m * NS);
             plane[idx] = COMP == 0 ? v[i + mr * S].x : v[i + mr * S].y;
         });
     });
 }
 template <typename Cfg, int COMP>
-__device__ __forceinline__ void lds_gather(typename Cfg::C *v, const typename Cfg::real *plane, int tid)
+__device__ __forceinline__ void lds_gather(typename Cfg::C *v, const typename Cfg::real *plane, int t, int lw)
 {
     static_for<0, Cfg::kE>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
-        const int idx = lds_pad<Cfg>(tid + Cfg::NT * Cfg::TW * c);   // (t + NT*c)*TW + lw
+        const int idx = lds_slot<Cfg>(lw, t + Cfg::NT * c);
         if (COMP == 0) v[c].x = plane[idx]; else v[c].y = plane[idx];
     });
 }
 
+// producer thread coordinates (t, lw), consumer coordinates (t2, lw2): they differ only across the
+// first exchange of a MAP == 2 kernel
 template <typename Cfg, int RP, int NS>
-__device__ __forceinline__ void exchange(typename Cfg::C *v, typename Cfg::real *lds, int t, int lw, int tid, bool first)
+__device__ __forceinline__ void exchange(typename Cfg::C *v, typename Cfg::real *lds, int t, int lw, int t2, int lw2, bool first)
 {
     using R = typename Cfg::real;
     if constexpr (Cfg::kPLANES == 2) {
@@ -276,39 +311,47 @@ __device__ __forceinline__ void exchange(typename Cfg::C *v, typename Cfg::real 
         lds_scatter<Cfg, RP, NS, 0>(v, p0, t, lw);
         lds_scatter<Cfg, RP, NS, 1>(v, p1, t, lw);
         __syncthreads();
-        lds_gather<Cfg, 0>(v, p0, tid);
-        lds_gather<Cfg, 1>(v, p1, tid);
+        lds_gather<Cfg, 0>(v, p0, t2, lw2);
+        lds_gather<Cfg, 1>(v, p1, t2, lw2);
     } else {
         if (!first) __syncthreads();
         lds_scatter<Cfg, RP, NS, 0>(v, lds, t, lw);     // old re -> LDS
         __syncthreads();
-        lds_gather<Cfg, 0>(v, lds, tid);                // new re (old im still live in v[].y)
+        lds_gather<Cfg, 0>(v, lds, t2, lw2);            // new re (old im still live in v[].y)
         __syncthreads();
         lds_scatter<Cfg, RP, NS, 1>(v, lds, t, lw);
         __syncthreads();
-        lds_gather<Cfg, 1>(v, lds, tid);
+        lds_gather<Cfg, 1>(v, lds, t2, lw2);
     }
 }
 
-// the whole Stockham chain on the registers of one thread
+// the whole Stockham chain on the registers of one thread.  (t, lw): coordinates during the first
+// pass; (t2, lw2): coordinates from the first exchange on (identical unless MAP == 2)
 template <typename Cfg>
 __device__ __forceinline__ void transform(typename Cfg::C *v, typename Cfg::real *lds,
-                                          const typename Cfg::C *__restrict__ W, int t, int lw, int tid)
+                                          const typename Cfg::C *__restrict__ W, int t, int lw, int t2, int lw2)
 {
     constexpr int R1 = Cfg::r1, R2 = Cfg::r2, R3 = Cfg::r3, R4 = Cfg::r4;
     pass_compute<Cfg, R1, 1>(v, t, W);
     if constexpr (R2 > 1) {
-        exchange<Cfg, R1, 1>(v, lds, t, lw, tid, true);
-        pass_compute<Cfg, R2, R1>(v, t, W);
+        exchange<Cfg, R1, 1>(v, lds, t, lw, t2, lw2, true);
+        pass_compute<Cfg, R2, R1>(v, t2, W);
     }
     if constexpr (R3 > 1) {
-        exchange<Cfg, R2, R1>(v, lds, t, lw, tid, false);
-        pass_compute<Cfg, R3, R1 * R2>(v, t, W);
+        exchange<Cfg, R2, R1>(v, lds, t2, lw2, t2, lw2, false);
+        pass_compute<Cfg, R3, R1 * R2>(v, t2, W);
     }
     if constexpr (R4 > 1) {
-        exchange<Cfg, R3, R1 * R2>(v, lds, t, lw, tid, false);
-        pass_compute<Cfg, R4, R1 * R2 * R3>(v, t, W);
+        exchange<Cfg, R3, R1 * R2>(v, lds, t2, lw2, t2, lw2, false);
+        pass_compute<Cfg, R4, R1 * R2 * R3>(v, t2, W);
     }
+}
+// line-fastest kernels (r2c / c2r / Bluestein): one coordinate set
+template <typename Cfg>
+__device__ __forceinline__ void transform(typename Cfg::C *v, typename Cfg::real *lds,
+                                          const typename Cfg::C *__restrict__ W, int t, int lw, int /*tid*/)
+{
+    transform<Cfg>(v, lds, W, t, lw, t, lw);
 }
 
 // logical workgroup index: identity, or the XCD-aware remap of the guide (T1, bijective form)
@@ -345,22 +388,33 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
 {
     using C = typename Cfg::C;
     using R = typename Cfg::real;
-    constexpr int N = Cfg::kN, E = Cfg::kE, TL = Cfg::kTL, NT = Cfg::NT, TW = Cfg::TW;
+    constexpr int N = Cfg::kN, E = Cfg::kE, TL = Cfg::kTL, NT = Cfg::NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     R *lds = reinterpret_cast<R *>(smem);
 
     const int tid = threadIdx.x;
-    const int lw = tid % TW;          // line within the workgroup
-    const int t = tid / TW;           // thread within the line
-    const int g = lw / TL, l = lw % TL;
+    // coordinates for the load / first pass, and for the later passes / the store
+    constexpr bool PF_FIRST = Cfg::kMAP == 1, PF_REST = Cfg::kMAP != 0 && Cfg::NPASS > 1 ? true : Cfg::kMAP == 1;
+    int lw, t, lw2, t2;
+    thread_map<Cfg, PF_FIRST>(tid, lw, t);
+    thread_map<Cfg, PF_REST>(tid, lw2, t2);
 
-    const uint32_t w = logical_block(A) * Cfg::kG + g;      // tile index
-    const bool tile_ok = w < A.ntiles;
-    const uint32_t a = !tile_ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
-    const uint32_t b = !tile_ok ? 0 : (A.a_fastest ? w / A.na : w % A.nb);
-    const uint32_t rem = A.LB - b * TL;
-    const uint32_t tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;   // valid lines of this tile
-    const bool active = tile_ok && (uint32_t)l < tw;
+    // tile of a line (workgroup index, b fastest or a fastest, optionally XCD-remapped)
+    const uint32_t blk = logical_block(A);
+    auto tile_of = [&](int lwx, uint32_t &a, uint32_t &b, uint32_t &tw, int &l) -> bool {
+        const int g = lwx / TL;
+        l = lwx % TL;
+        const uint32_t w = blk * Cfg::kG + g;
+        const bool ok = w < A.ntiles;
+        a = !ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
+        b = !ok ? 0 : (A.a_fastest ? w / A.na : w % A.nb);
+        const uint32_t rem = A.LB - b * TL;
+        tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;     // valid lines of this tile
+        return ok && (uint32_t)l < tw;
+    };
+    uint32_t a, b, tw;
+    int l;
+    const bool active = tile_of(lw, a, b, tw, l);
 
     const C *__restrict__ in = reinterpret_cast<const C *>(A.in);
     C *__restrict__ out = reinterpret_cast<C *>(A.out);
@@ -398,24 +452,26 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
     if (A.swap) static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; R tmp = v[c].x; v[c].x = v[c].y; v[c].y = tmp; });
 
     // ------------------------------------------------------------------ passes
-    transform<Cfg>(v, lds, W, t, lw, tid);
+    transform<Cfg>(v, lds, W, t, lw, t2, lw2);
 
     if (A.swap) static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; R tmp = v[c].x; v[c].x = v[c].y; v[c].y = tmp; });
 
-    // ------------------------------------------------------------------ store
-    if (!active) return;
+    // ------------------------------------------------------------------ store (coordinates of the later passes)
+    uint32_t a2, b2, tws;
+    int l2;
+    if (!tile_of(lw2, a2, b2, tws, l2)) return;
     constexpr int RL = Cfg::RLAST;     // radix of the last pass
     constexpr int S = E / RL;
-    // register c = i + mr*S holds output k = t + NT*i + brev(mr)*(N/RL)
+    // register c = i + mr*S holds output k = t2 + NT*i + brev(mr)*(N/RL)
     if (A.store_kind == STORE_LINES) {
-        C *p = out + ((uint64_t)a * A.LB + (uint64_t)b * TL + l) * N + t;
+        C *p = out + ((uint64_t)a2 * A.LB + (uint64_t)b2 * TL + l2) * N + t2;
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
             stream_store<Cfg>(p + k0, v[c]);
         });
     } else if (A.store_kind == STORE_KMAJOR) {
-        C *p = out + (uint64_t)a * A.AS_out + (uint64_t)b * TL + l + (uint64_t)t * A.KS_out;
+        C *p = out + (uint64_t)a2 * A.AS_out + (uint64_t)b2 * TL + l2 + (uint64_t)t2 * A.KS_out;
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
@@ -425,7 +481,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
-            const uint32_t k = t + k0;
+            const uint32_t k = t2 + k0;
             uint32_t s0 = A.sseg->start[0], ln = A.sseg->len[0];
             uint64_t bs = A.sseg->base[0];
             for (int s = 1; s < A.snseg; s++)
@@ -433,19 +489,18 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
             const uint32_t kl = k - s0;
             uint64_t off;
             if (A.store_kind == STORE_TILED_SAME) {
-                off = bs + (uint64_t)kl * A.LB * A.LA + (uint64_t)b * TL * A.LA + (uint64_t)a * tw + l;
+                off = bs + (uint64_t)kl * A.LB * A.LA + (uint64_t)b2 * TL * A.LA + (uint64_t)a2 * tws + l2;
             } else {
                 const uint32_t T2 = 1u << A.T2shift;
                 const uint32_t kt = kl >> A.T2shift, kr = kl & (T2 - 1);
                 const uint32_t r2 = ln - kt * T2;
                 const uint32_t tw2 = r2 < T2 ? r2 : T2;
-                off = bs + (uint64_t)a * ln * A.LB + (uint64_t)kt * T2 * A.LB + ((uint64_t)b * TL + l) * tw2 + kr;
+                off = bs + (uint64_t)a2 * ln * A.LB + (uint64_t)kt * T2 * A.LB + ((uint64_t)b2 * TL + l2) * tw2 + kr;
             }
             stream_store<Cfg>(out + off, v[c]);
         });
     }
 }
-
 
 // ------------------------------------------------------------------------------------------
 // Real transforms on the z axis (the reference's cufftExecD2Z / cufftExecZ2D plans,
