@@ -141,11 +141,15 @@ def main():
         kind = dfft.MPIcuFFT_Slab_Opt1 if P2 == 1 and ngpus > 1 else dfft.MPIcuFFT_Pencil_Opt1
         plan = kind(dfft.Configurations(), comm, precision=prec, rank=rank)
         plan.initFFT(dfft.GlobalSize(N, N, N), dfft.Partition(P1, P2), allocate=False, c2c=True)
-        work = torch.empty(plan.getWorkSizeDevice(), dtype=torch.uint8, device="cuda")
         plan.setStream(stream)
-        plan.setWorkArea(work)
         if comm is not None and transport == "torch":
+            # the torch transport maps raw pointers back to tensors, so the work area must be one
+            work = torch.empty(plan.getWorkSizeDevice(), dtype=torch.uint8, device="cuda")
+            plan.setWorkArea(work)
             comm.register(work)
+        else:
+            work = None
+            plan.setWorkArea(None)       # library-owned (hipMalloc), like the reference's allocate = true
         return plan, comm, transport, work
 
     plan, comm, transport, work = make_plan(P1, P2)
