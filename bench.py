@@ -45,7 +45,7 @@ def parse():
                     help="auto = slab on one xGMI node (every GPU pair has its own link), pencil = BASELINE 2x4 / 2x2")
     ap.add_argument("--no-alt", action="store_true", help="skip the alternative-decomposition measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=256, help="cube edge of the CPU-baseline sample")
+    ap.add_argument("--cpu-n", type=int, default=512, help="cube edge of the CPU-baseline sample")
     return ap.parse_args()
 
 
@@ -85,7 +85,7 @@ def cpu_baseline(n):
         g /= float(n) ** 3
         iters += 1
         dt = time.perf_counter() - t0
-        if dt > 10.0 or iters >= 20:
+        if dt > 12.0 or iters >= 20:
             break
     flops = 2 * 5.0 * n ** 3 * math.log2(float(n) ** 3)
     return {"value": round(flops * iters / dt / 1e9, 3), "unit": "GFLOP/s", "cores": orc.num_threads(),

@@ -437,3 +437,16 @@ def test_randomised_sweep_of_shapes_partitions_and_depths():
             assert np.max(np.abs(spec[r] - ref)) / scale < 2e-11, (shape, P1, P2, chunks, c2c, r)
             assert rel(backs[r] / n3, ins[r]) < 1e-10, (shape, P1, P2, chunks, c2c, r)
         done += 1
+
+
+@pytest.mark.parametrize("shape,P1,P2", [((64, 64, 64), 4, 4), ((64, 32, 16), 16, 1), ((16, 64, 64), 1, 16), ((48, 48, 20), 6, 3)])
+def test_sixteen_and_eighteen_ranks(shape, P1, P2):
+    """two-node sized grids (the reference ran 4x4 on 16 GPUs, results_16.csv) as virtual ranks"""
+    plans, ins, spec, backs = run_distributed(shape, P1, P2, "double")
+    want = orc.fft3d_c2c(orc.fill_block(shape, (0, 0, 0), shape, 2, seed=7), -1)
+    n3 = float(np.prod(shape))
+    for r, pl in enumerate(plans):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        ref = want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]]
+        assert np.max(np.abs(spec[r] - ref)) / np.max(np.abs(want)) < 2e-11
+        assert rel(backs[r] / n3, ins[r]) < 1e-10
