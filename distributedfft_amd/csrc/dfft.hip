@@ -619,6 +619,22 @@ static int enqueue_inverse(dfft_plan *p, void *out, void *in)
     char *zsrc = p->P2 > 1 ? (p->P1 > 1 ? W0 : W1) : I;   // W0 is still read by y^-1 when there is no exchange 2
     hipStream_t Sc = p->stream, Sm = pl.comm_stream;
     p->nspans = 0; p->last_dir = DFFT_INVERSE;
+    if (p->nranks == 1 && p->c2c) {
+        // single rank, complex: input and output are both natural [x][y][z], so the inverse may use
+        // the forward pass order (z, y, x) with conjugation -- it avoids the strided *read* of the
+        // x-first order (the fft3d branch of the reference is one cuFFT plan, order is not observable)
+        auto conj_launch = [&](const Launch &L, int variant, int axis, const char *src, char *dst) -> int {
+            Launch M = L;
+            M.args.swap = 1;
+            return launch(p, M, variant, axis, src, dst);
+        };
+        for (int c = 0; c < C; c++) { TRY(span_begin(p, 4, Sc)); TRY(conj_launch(pl.fz[c], p->vfwd[0], 0, I, W0)); TRY(span_end(p, Sc)); }
+        for (int c = 0; c < C; c++) { TRY(span_begin(p, 2, Sc)); TRY(conj_launch(pl.fy[c], p->vfwd[1], 1, W0, I)); TRY(span_end(p, Sc)); }
+        TRY(span_begin(p, 0, Sc));
+        TRY(conj_launch(pl.fx, p->vfwd[2], 2, I, O));
+        TRY(span_end(p, Sc));
+        return 0;
+    }
     if (p->comm) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); }
     for (int c = 0; c < C; c++) {
         TRY(span_begin(p, 0, Sc));

@@ -107,7 +107,9 @@ int dfft_set_work_area(dfft_plan *plan, void *device, void *host);
  * plan has an exchange, else 1), 1 = no pipelining = the reference's exact message sizes. */
 int dfft_set_pipeline_chunks(dfft_plan *plan, int chunks);
 int dfft_get_pipeline_chunks(const dfft_plan *plan);
-/* HIP stream all kernels/exchanges are enqueued on (default: a stream owned by the plan) */
+/* HIP stream all kernels/exchanges are enqueued on (default: a non-blocking stream owned by the
+ * plan).  exec orders itself only against this stream: work that produces `in` or initialises
+ * `out` on another stream must be complete (or that stream handed over here) before exec. */
 int dfft_set_stream(dfft_plan *plan, void *hip_stream);
 
 /* execR2C(void *out, const void *in)   include/mpicufft.hpp:63; mpicufft_pencil_opt1.cpp:1422-1519.

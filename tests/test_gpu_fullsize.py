@@ -95,6 +95,7 @@ def test_c2_256_single_gpu_every_point_vs_oracle():
     got = d_out[:g.size].cpu().numpy().reshape(shape)
     assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-11
     back = torch.zeros_like(d_in)
+    torch.cuda.synchronize()
     plan.execC2C(back, d_out, dfft.INVERSE)
     assert np.max(np.abs(back.cpu().numpy() / g.size - g)) / 255 < 1e-10
 

@@ -55,6 +55,7 @@ def run_single(shape, prec, seed=5):
     got = d_out[:g.size].cpu().numpy().reshape(shape)
     assert np.array_equal(d_in.cpu().numpy(), g), "forward must not modify its input"
     d_back = torch.zeros_like(d_in)
+    torch.cuda.synchronize()      # the fill runs on torch's stream, the plan on its own
     plan.execC2C(d_back, d_out, dfft.INVERSE)
     return g, got, d_back.cpu().numpy()
 
