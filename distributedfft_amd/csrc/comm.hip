@@ -4,6 +4,7 @@
 #include "../../include/dfft_c.h"
 
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 #include <condition_variable>
 #include <mutex>
@@ -105,6 +106,7 @@ struct RcclApi {
     int (*GetUniqueId)(void *) = nullptr;
     int (*CommInitRank)(void **, int, /*ncclUniqueId by value: 128 bytes*/ Id128, int) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommSplit)(void *, int, int, void **, void *) = nullptr;
     int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
@@ -126,6 +128,7 @@ static RcclApi *rccl()
         api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.h, "ncclGetUniqueId");
         api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.h, "ncclCommInitRank");
         api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.h, "ncclCommDestroy");
+        api.CommSplit = (decltype(api.CommSplit))dlsym(api.h, "ncclCommSplit");
         api.Send = (decltype(api.Send))dlsym(api.h, "ncclSend");
         api.Recv = (decltype(api.Recv))dlsym(api.h, "ncclRecv");
         api.GroupStart = (decltype(api.GroupStart))dlsym(api.h, "ncclGroupStart");
@@ -149,11 +152,15 @@ static RcclApi *rccl()
 
 struct RcclComm : dfft_comm {
     void *comm = nullptr;
+    void *comm2 = nullptr;     // duplicate communicator (ncclCommSplit, colour 0) for channel 1
     int rank = 0;
     int fixed_rank() const override { return rank; }
+    // one ncclComm serialises its operations: only a duplicated communicator allows overlap
+    bool concurrent_channels() const override { return comm2 != nullptr; }
     ~RcclComm() override
     {
         RcclApi *R = rccl();
+        if (R && comm2 && R->CommDestroy) R->CommDestroy(comm2);
         if (R && comm && R->CommDestroy) R->CommDestroy(comm);
     }
     int alltoallv(int myrank, const void *send, const size_t *scount, const size_t *sdispl, void *recv,
@@ -164,6 +171,7 @@ struct RcclComm : dfft_comm {
         if (!R) { set_error("librccl not available"); return 1; }
         const char *s = static_cast<const char *>(send);
         char *r = static_cast<char *>(recv);
+        void *use = (channel == 1 && comm2) ? comm2 : comm;
         // self block: plain device copy, never goes through RCCL
         // (the reference skips self in its send tables, src/pencil/mpicufft_pencil.cpp:282-289)
         if (rcount[me])
@@ -172,8 +180,8 @@ struct RcclComm : dfft_comm {
         for (int i = 1; i < ngroup; i++) {
             // ring order (me+i)%P like the reference's comm_order (mpicufft_pencil_opt1.cpp:107-113)
             const int to = (me + i) % ngroup, from = (me - i + ngroup) % ngroup;
-            if (scount[to]) NCCL_TRY(R->Send(s + sdispl[to], scount[to], /*ncclInt8*/ 0, group[to], comm, stream));
-            if (rcount[from]) NCCL_TRY(R->Recv(r + rdispl[from], rcount[from], 0, group[from], comm, stream));
+            if (scount[to]) NCCL_TRY(R->Send(s + sdispl[to], scount[to], /*ncclInt8*/ 0, group[to], use, stream));
+            if (rcount[from]) NCCL_TRY(R->Recv(r + rdispl[from], rcount[from], 0, group[from], use, stream));
         }
         NCCL_TRY(R->GroupEnd());
         (void)myrank;
@@ -204,6 +212,12 @@ dfft_comm *make_rccl_comm(const void *id128, int nranks, int rank)
         c->comm = nullptr;
         delete c;
         return nullptr;
+    }
+    // second communicator over the same ranks for the second exchange of pencil plans (collective;
+    // every rank constructs its RcclComm at the same point).  Optional: without it both exchanges
+    // share one communicator and RCCL serialises them.
+    if (R->CommSplit && getenv("DFFT_RCCL_DUP") && std::string(getenv("DFFT_RCCL_DUP")) == "1") {
+        if (R->CommSplit(c->comm, 0, rank, &c->comm2, nullptr) != 0) c->comm2 = nullptr;
     }
     return c;
 }

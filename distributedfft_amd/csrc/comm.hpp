@@ -14,7 +14,12 @@ struct dfft_comm {
     virtual ~dfft_comm() {}
     // rank of the caller if the transport knows it (RCCL, callback), -1 for a local world
     virtual int fixed_rank() const { return -1; }
-    // counts/displacements in bytes; group = global ranks, me = my index in group
+    // counts/displacements in bytes; group = global ranks, me = my index in group.
+    // `channel` (0 or 1) lets a transport keep independent resources per exchange so that the two
+    // exchanges of a pencil plan, which use disjoint links, may be in flight at the same time.
+    int channel = 0;
+    // true if exchanges issued on channel 0 and channel 1 may run concurrently on two streams
+    virtual bool concurrent_channels() const { return true; }
     virtual int alltoallv(int myrank, const void *send, const size_t *scount, const size_t *sdispl,
                           void *recv, const size_t *rcount, const size_t *rdispl, const int *group,
                           int ngroup, int me, hipStream_t stream) = 0;

@@ -211,6 +211,7 @@ struct Pipeline {
     std::vector<A2A> f1, f2, i2, i1;          // per chunk exchange tables
     std::vector<hipEvent_t> ev;               // reusable events
     hipStream_t comm_stream = nullptr;
+    hipStream_t comm_stream2 = nullptr;       // second exchange of a pencil plan (disjoint links: may overlap the first)
 };
 
 struct TimedSpan { hipEvent_t a = nullptr, b = nullptr; int phase = 0; bool used = false; };
@@ -491,6 +492,7 @@ static int exchange_tables(dfft_plan *p, int which, const A2A &T, bool forward, 
     const std::vector<int> &grp = first ? p->group1 : p->group2;
     const int me = first ? p->pj : p->pi;
     if (!p->comm) return fail(ERR_STATE, "exchange without a communicator");
+    p->comm->channel = (which == 2 && p->pl.comm_stream2 && stream == p->pl.comm_stream2) ? 1 : 0;
     // the inverse all-to-all swaps the send and receive tables (mpicufft_pencil_opt1.cpp:829-830)
     if (forward)
         return p->comm->alltoallv(p->rank, send, T.sc.data(), T.sd.data(), recv, T.rc.data(), T.rd.data(), grp.data(),
@@ -555,9 +557,11 @@ static int enqueue_forward(dfft_plan *p, void *out, const void *in)
     char *ydst = next_work();
     char *xsrc = p->P1 > 1 ? next_work() : ydst;
     hipStream_t Sc = p->stream, Sm = pl.comm_stream;
+    // exchange 2 of a pencil plan runs on its own stream (row and column groups use disjoint links)
+    hipStream_t Sm2 = (pl.comm_stream2 && p->comm && p->comm->concurrent_channels()) ? pl.comm_stream2 : Sm;
     p->nspans = 0; p->last_dir = DFFT_FORWARD;
     // event ids: [0,C) z done, [C,2C) ex1 done, [2C,3C) y done, [3C,4C) ex2 done, 4C = entry fence
-    if (p->comm) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); }     // comm stream starts after prior work
+    if (p->comm) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); if (Sm2 != Sm) EV_WAIT(4 * C, Sm2); }   // comm streams start after prior work
     auto zpass = [&](int c) -> int {
         TRY(span_begin(p, 0, Sc));
         if (p->c2c) TRY(launch(p, pl.fz[c], p->vfwd[0], 0, I, zdst));
@@ -580,11 +584,11 @@ static int enqueue_forward(dfft_plan *p, void *out, const void *in)
         TRY(span_end(p, Sc));
         if (p->P1 > 1) {
             EV_RECORD(2 * C + c, Sc);
-            EV_WAIT(2 * C + c, Sm);
-            TRY(span_begin(p, 3, Sm));
-            TRY(exchange_tables(p, 2, pl.f2[c], true, ydst, xsrc, Sm));
-            TRY(span_end(p, Sm));
-            EV_RECORD(3 * C + c, Sm);
+            EV_WAIT(2 * C + c, Sm2);
+            TRY(span_begin(p, 3, Sm2));
+            TRY(exchange_tables(p, 2, pl.f2[c], true, ydst, xsrc, Sm2));
+            TRY(span_end(p, Sm2));
+            EV_RECORD(3 * C + c, Sm2);
         }
         return 0;
     };
@@ -618,6 +622,7 @@ static int enqueue_inverse(dfft_plan *p, void *out, void *in)
     char *ydst = I;
     char *zsrc = p->P2 > 1 ? (p->P1 > 1 ? W0 : W1) : I;   // W0 is still read by y^-1 when there is no exchange 2
     hipStream_t Sc = p->stream, Sm = pl.comm_stream;
+    hipStream_t Sm2 = (pl.comm_stream2 && p->comm && p->comm->concurrent_channels()) ? pl.comm_stream2 : Sm;
     p->nspans = 0; p->last_dir = DFFT_INVERSE;
     if (p->nranks == 1 && p->c2c) {
         // single rank, complex: input and output are both natural [x][y][z], so the inverse may use
@@ -635,18 +640,18 @@ static int enqueue_inverse(dfft_plan *p, void *out, void *in)
         TRY(span_end(p, Sc));
         return 0;
     }
-    if (p->comm) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); }
+    if (p->comm) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); if (Sm2 != Sm) EV_WAIT(4 * C, Sm2); }
     for (int c = 0; c < C; c++) {
         TRY(span_begin(p, 0, Sc));
         TRY(launch(p, pl.ix[c], p->vinv[2], 2, I, xdst));
         TRY(span_end(p, Sc));
         if (p->P1 > 1) {
             EV_RECORD(c, Sc);
-            EV_WAIT(c, Sm);
-            TRY(span_begin(p, 1, Sm));
-            TRY(exchange_tables(p, 2, pl.i2[c], true, xdst, ysrc, Sm));    // i2/i1 tables are already in send/recv order
-            TRY(span_end(p, Sm));
-            EV_RECORD(C + c, Sm);
+            EV_WAIT(c, Sm2);
+            TRY(span_begin(p, 1, Sm2));
+            TRY(exchange_tables(p, 2, pl.i2[c], true, xdst, ysrc, Sm2));    // i2/i1 tables are already in send/recv order
+            TRY(span_end(p, Sm2));
+            EV_RECORD(C + c, Sm2);
         }
     }
     // y^-1 needs complete ky lines: every chunk of exchange 2 must have landed.  It also
@@ -809,6 +814,7 @@ int dfft_plan_destroy(dfft_plan *p)
     for (auto &t : p->spans) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
     for (auto &e : p->pl.ev) if (e) (void)hipEventDestroy(e);
     if (p->pl.comm_stream) (void)hipStreamDestroy(p->pl.comm_stream);
+    if (p->pl.comm_stream2) (void)hipStreamDestroy(p->pl.comm_stream2);
     if (p->stream_owned && p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
     return 0;
@@ -961,6 +967,8 @@ static int ensure_device_state(dfft_plan *p)
         p->stream_owned = true;
     }
     if (p->comm && !p->pl.comm_stream) HIP_TRY(hipStreamCreateWithFlags(&p->pl.comm_stream, hipStreamNonBlocking));
+    if (p->comm && p->P1 > 1 && p->P2 > 1 && !p->pl.comm_stream2)
+        HIP_TRY(hipStreamCreateWithFlags(&p->pl.comm_stream2, hipStreamNonBlocking));
     return 0;
 }
 
