@@ -120,8 +120,16 @@ def make_comm(dist, rank, world, P1, P2, mode="auto"):
             ok.zero_()
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if ok.item() > 0:
-            err = _selftest(dist, comm, rank, world, P1, P2)
-            if err < 1e-10:
+            try:
+                err = _selftest(dist, comm, rank, world, P1, P2)
+            except Exception as e:   # noqa: BLE001  (a rank-local failure; the others learn it below)
+                if mode == "rccl":
+                    raise
+                print(f"[rank {rank}] native RCCL self-test raised {e!r}", flush=True)
+                err = float("inf")
+            good = torch.tensor([1.0 if err < 1e-10 else 0.0], device="cuda")
+            dist.all_reduce(good, op=dist.ReduceOp.MIN)
+            if good.item() > 0:
                 return comm, "rccl (native grouped send/recv)"
             if mode == "rccl":
                 raise RuntimeError(f"native RCCL transport failed its self-test: round trip {err}")
