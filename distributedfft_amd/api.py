@@ -282,6 +282,15 @@ class MPIcuFFT_Slab_Opt1(MPIcuFFT):
     _kind = 1
 
 
+class MPIcuFFT_Slab_Z_Then_YX(MPIcuFFT):
+    """include/mpicufft_slab_z_then_yx.hpp: input split along x, output [Nx][Ny][Nzc/P] split along z"""
+    _kind = 4
+
+
+class MPIcuFFT_Slab_Z_Then_YX_Opt1(MPIcuFFT):
+    _kind = 5
+
+
 class MPIcuFFT_Pencil(MPIcuFFT):
     _kind = 2
 

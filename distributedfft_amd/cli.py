@@ -53,6 +53,8 @@ def parse(argv):
     ap.add_argument("--cuda_aware", "-c", action="store_true")
     ap.add_argument("--double_prec", "-d", action="store_true")
     ap.add_argument("--benchmark_dir", "-b", default="../benchmarks")
+    ap.add_argument("--sequence", "-s", default="ZY_Then_X", choices=["ZY_Then_X", "Z_Then_YX", "Y_Then_ZX"],
+                    help="slab only (tests/src/slab/main.cpp:138-140)")
     ap.add_argument("--complex", action="store_true", help="extension: complex-to-complex instead of R2C/C2R")
     return ap.parse_args(argv)
 
@@ -71,6 +73,8 @@ class Rank:
                                   args.benchmark_dir, COMM[args.comm_method2], SEND[args.send_method2])
         kind = {("pencil", 0): dfft.MPIcuFFT_Pencil, ("pencil", 1): dfft.MPIcuFFT_Pencil_Opt1,
                 ("slab", 0): dfft.MPIcuFFT_Slab, ("slab", 1): dfft.MPIcuFFT_Slab_Opt1}[(args.mode, args.opt)]
+        if args.mode == "slab" and args.sequence == "Z_Then_YX":
+            kind = dfft.MPIcuFFT_Slab_Z_Then_YX if args.opt == 0 else dfft.MPIcuFFT_Slab_Z_Then_YX_Opt1
         self.plan = kind(cfg, comm, precision=prec, rank=rank)
         t0 = time.perf_counter()
         self.N = (args.input_dim_x, args.input_dim_y, args.input_dim_z)
@@ -137,7 +141,7 @@ class Rank:
 
 
 def write_csv(args, ranks, P1, P2):
-    sub = "pencil" if args.mode == "pencil" else ("slab_default" if args.opt == 0 else "slab_default")
+    sub = "pencil" if args.mode == "pencil" else ("slab_z_then_yx" if args.sequence == "Z_Then_YX" else "slab_default")
     d = os.path.join(args.benchmark_dir, sub)
     os.makedirs(d, exist_ok=True)
     if args.mode == "pencil":
@@ -167,6 +171,12 @@ def write_csv(args, ranks, P1, P2):
 
 def run(argv=None):
     args = parse(argv if argv is not None else sys.argv[1:])
+    if args.sequence != "ZY_Then_X" and args.mode != "slab":
+        raise SystemExit("--sequence applies to the slab decomposition")
+    if args.sequence == "Y_Then_ZX":
+        raise SystemExit("sequence Y_Then_ZX (forward-only, Hermitian axis y) is not provided; see DESIGN.md 7")
+    if args.sequence == "Z_Then_YX" and args.fft_dim != 3:
+        raise SystemExit("--fft-dim 1|2 is defined for the pencil classes only")
     import torch
 
     import distributedfft_amd as dfft

@@ -208,6 +208,10 @@ struct Pipeline {
     // partial transforms (reference: execR2C/C2R(out, in, d), src/pencil/mpicufft_pencil.cpp:1644-1839)
     Launch pz1, qz1;                           // d = 1: z pass natural -> natural [xs][ys][Nzc] and back
     std::vector<Launch> py2, qy2;              // d = 2: y pass chunk -> [xs][Ny][zs] and back
+    // slab sequence Z_Then_YX (src/slab/z_then_yx/): y passes per (chunk, source peer) block and one
+    // unchunked inverse x pass; the exchange tables live in f2 / i2
+    std::vector<Launch> zy, ziy;
+    Launch zix;
     std::vector<A2A> f1, f2, i2, i1;          // per chunk exchange tables
     std::vector<hipEvent_t> ev;               // reusable events
     hipStream_t comm_stream = nullptr;
@@ -222,6 +226,7 @@ struct dfft_plan {
     dfft_comm *comm = nullptr;
     int rank = 0, nranks = 1;
     bool initialized = false, c2c = false;
+    bool zyx = false;            // slab sequence Z_Then_YX: input split along x, output split along z
     size_t Nx = 0, Ny = 0, Nz = 0, Nzc = 0;
     int P1 = 1, P2 = 1, pi = 0, pj = 0;
     int TL = 8;
@@ -441,6 +446,117 @@ static int build_pipeline(dfft_plan *p, Pipeline &pl)
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Slab sequence Z_Then_YX (src/slab/z_then_yx/mpicufft_slab_z_then_yx.cpp:74-200): the input is
+// split along x, [xs][Ny][Nz]; after the z pass ONE all-to-all over all P ranks sends the slice
+// kz in zs[p] to rank p (counts :190-196), and the (y, x) transform runs on [Nx][Ny][zs].  Here:
+//   z pass chunk c      natural lines -> block (c,p) = [x][kz/TL][y][kz%TL]           (send)
+//   exchange chunk c    receive block (c,q) = [x in chunk c of xs[q]][kz/TL][y][kz%TL]
+//   y pass per (c,q)    -> block (c,q) = [ky][kz/TL][x][kz%TL]        (same offsets, other buffer)
+//   x pass              lines along x gathered from the P*C blocks -> API layout [kx][ky][kz']
+// and the mirror image for the inverse.  Uses p->xs (x split), p->zs (z split over P1 = P ranks).
+// ------------------------------------------------------------------------------------------
+static int build_pipeline_zyx(dfft_plan *p, Pipeline &pl)
+{
+    const int TL = p->TL, P = p->P1, C = pl.C, r = p->pi;
+    const uint32_t T2shift = ilog2(TL);
+    const size_t xs = p->xs[r], zs = p->zs[r];
+    const size_t Ny = p->Ny, Nzc = p->Nzc, e = p->esz;
+    const size_t zline_bytes = p->c2c ? p->Nz * e : p->Nz * (e / 2);
+    auto base = [&](size_t na, size_t LB, int lk, int sk, int swap) {
+        PassArgs A;
+        memset(&A, 0, sizeof(A));
+        A.na = (uint32_t)na; A.LB = (uint32_t)LB; A.nb = (uint32_t)((LB + TL - 1) / TL); A.ntiles = A.na * A.nb;
+        A.load_kind = lk; A.store_kind = sk; A.swap = swap; A.T2shift = T2shift;
+        return A;
+    };
+    std::vector<size_t> xl, x0;
+    split(xs, C, xl, x0);
+    std::vector<std::vector<size_t>> xlq(P), x0q(P);
+    for (int q = 0; q < P; q++) split(p->xs[q], C, xlq[q], x0q[q]);
+    // element offset of block (c,q) on the z-split side, chunk outermost
+    std::vector<std::vector<size_t>> blk(C, std::vector<size_t>(P, 0));
+    { size_t acc = 0; for (int c = 0; c < C; c++) for (int q = 0; q < P; q++) { blk[c][q] = acc; acc += xlq[q][c] * Ny * zs; } }
+
+    pl.fx = Launch(); pl.zix = Launch();
+    pl.fz.assign(C, Launch()); pl.iz.assign(C, Launch());
+    pl.zy.assign((size_t)C * P, Launch()); pl.ziy.assign((size_t)C * P, Launch());
+    pl.f2.assign(C, A2A()); pl.i2.assign(C, A2A());
+    pl.fy.clear(); pl.ix.clear(); pl.iy.clear(); pl.f1.clear(); pl.i1.clear(); pl.py2.clear(); pl.qy2.clear();
+    pl.pz1 = Launch(); pl.qz1 = Launch();
+
+    for (int c = 0; c < C; c++) {
+        const size_t S1c = x0[c] * Nzc * Ny;     // send side: my x chunk, every kz
+        {   // z pass chunk
+            Launch &L = pl.fz[c];
+            L.args = base(xl[c], Ny, LOAD_LINES, STORE_TILED_TRANSPOSE, 0);
+            L.in_off = x0[c] * Ny * zline_bytes;
+            for (int q = 0; q < P; q++) seg_push(L.sseg, p->zstart[q], p->zs[q], S1c + xl[c] * p->zstart[q] * Ny);
+        }
+        {   // forward exchange (:190-196 restricted to the chunk)
+            A2A &T = pl.f2[c];
+            for (int q = 0; q < P; q++) {
+                T.sc.push_back(e * xl[c] * p->zs[q] * Ny);
+                T.sd.push_back(e * (S1c + xl[c] * p->zstart[q] * Ny));
+                T.rc.push_back(e * xlq[q][c] * Ny * zs);
+                T.rd.push_back(e * blk[c][q]);
+            }
+        }
+        for (int q = 0; q < P; q++) {   // y pass on the block received from q
+            Launch &L = pl.zy[(size_t)c * P + q];
+            L.args = base(xlq[q][c], zs, LOAD_TILED, STORE_TILED_SAME, 0);
+            seg_push(L.lseg, 0, Ny, blk[c][q]);
+            seg_push(L.sseg, 0, Ny, blk[c][q]);
+            L.args.LA = (uint32_t)xlq[q][c];
+        }
+    }
+    {   // x pass: lines along x from the P*C blocks -> [kx][ky][kz']
+        PassArgs X = base(Ny, zs, LOAD_TILED, STORE_KMAJOR, 0);
+        X.KS_out = (uint64_t)Ny * zs; X.AS_out = zs; X.xcd_swizzle = 1;
+        pl.fx.args = X;
+        for (int q = 0; q < P; q++)
+            for (int c = 0; c < C; c++)
+                if (xlq[q][c]) seg_push(pl.fx.lseg, p->xstart[q] + x0q[q][c], xlq[q][c], blk[c][q]);
+    }
+    // ---------------- inverse ----------------
+    {   // x^-1: API layout -> blocks (c,q) = [x][kz/TL][ky][kz%TL]
+        Launch &L = pl.zix;
+        L.args = base(Ny, zs, LOAD_KMAJOR, STORE_TILED_SAME, 1);
+        L.args.KS_in = (uint64_t)Ny * zs; L.args.AS_in = zs;
+        L.args.xcd_swizzle = 1; L.args.a_fastest = zs % TL == 0 ? 1 : 0;
+        L.args.LA = (uint32_t)Ny;
+        for (int q = 0; q < P; q++)
+            for (int c = 0; c < C; c++)
+                if (xlq[q][c]) seg_push(L.sseg, p->xstart[q] + x0q[q][c], xlq[q][c], blk[c][q]);
+    }
+    for (int c = 0; c < C; c++) {
+        const size_t R1i = x0[c] * Ny * Nzc;
+        for (int q = 0; q < P; q++) {   // y^-1 on block (c,q) -> send block [x][y/TL][kz'][y%TL]
+            Launch &L = pl.ziy[(size_t)c * P + q];
+            L.args = base(xlq[q][c], zs, LOAD_TILED, STORE_TILED_TRANSPOSE, 1);
+            seg_push(L.lseg, 0, Ny, blk[c][q]);
+            seg_push(L.sseg, 0, Ny, blk[c][q]);
+        }
+        {   // inverse exchange, already in send/receive order
+            A2A &T = pl.i2[c];
+            for (int q = 0; q < P; q++) {
+                T.sc.push_back(e * xlq[q][c] * Ny * zs);
+                T.sd.push_back(e * blk[c][q]);
+                T.rc.push_back(e * xl[c] * Ny * p->zs[q]);
+                T.rd.push_back(e * (R1i + xl[c] * Ny * p->zstart[q]));
+            }
+        }
+        {   // z^-1 chunk: lines along kz from the P blocks -> natural [x][y][z]
+            Launch &L = pl.iz[c];
+            L.args = base(xl[c], Ny, LOAD_TILED, STORE_LINES, 1);
+            L.args.xcd_swizzle = 1;
+            for (int q = 0; q < P; q++) seg_push(L.lseg, p->zstart[q], p->zs[q], R1i + xl[c] * Ny * p->zstart[q]);
+            L.out_off = x0[c] * Ny * zline_bytes;
+        }
+    }
+    return 0;
+}
+
 static void fill_tables(dfft_plan *p, const Launch &L, PassArgs &A)
 {
     A.lseg = reinterpret_cast<const SegTable *>(static_cast<const char *>(p->tables_d) + L.ltab);
@@ -544,8 +660,12 @@ static hipEvent_t pipe_event(dfft_plan *p, size_t i)
 
 // forward chain.  Buffers: A = caller's out, W0..W2 = work area slices (one per exchange + 1).
 //   z: in -> A   [ex1: A -> W0]   y: -> next   [ex2: -> next]   x: -> A
+static int enqueue_forward_zyx(dfft_plan *p, void *out, const void *in);
+static int enqueue_inverse_zyx(dfft_plan *p, void *out, void *in);
+
 static int enqueue_forward(dfft_plan *p, void *out, const void *in)
 {
+    if (p->zyx) return enqueue_forward_zyx(p, out, in);
     Pipeline &pl = p->pl;
     const int C = pl.C;
     char *A = static_cast<char *>(out), *W = static_cast<char *>(p->work_d);
@@ -613,6 +733,7 @@ static int enqueue_forward(dfft_plan *p, void *out, const void *in)
 //   x^-1: I -> W0   [ex2: W0 -> W1]   y^-1: -> I   [ex1: I -> W0]   z^-1: -> out
 static int enqueue_inverse(dfft_plan *p, void *out, void *in)
 {
+    if (p->zyx) return enqueue_inverse_zyx(p, out, in);
     Pipeline &pl = p->pl;
     const int C = pl.C;
     char *I = static_cast<char *>(in), *W = static_cast<char *>(p->work_d), *O = static_cast<char *>(out);
@@ -680,6 +801,81 @@ static int enqueue_inverse(dfft_plan *p, void *out, void *in)
     return 0;
 }
 
+
+// Z_Then_YX forward:  z: in -> A   [ex: A -> W0]   y: W0 -> W1   x: W1 -> A
+// (src/slab/z_then_yx/mpicufft_slab_z_then_yx.cpp execR2C: 1-D R2C, all-to-all, 2-D C2C)
+static int enqueue_forward_zyx(dfft_plan *p, void *out, const void *in)
+{
+    Pipeline &pl = p->pl;
+    const int C = pl.C, P = p->P1;
+    char *A = static_cast<char *>(out), *W = static_cast<char *>(p->work_d);
+    const char *I = static_cast<const char *>(in);
+    char *ysrc = P > 1 ? W : A;
+    char *ydst = P > 1 ? W + p->domainsize : W;
+    hipStream_t Sc = p->stream, Sm = pl.comm_stream;
+    p->nspans = 0; p->last_dir = DFFT_FORWARD;
+    if (p->comm && P > 1) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); }
+    for (int c = 0; c < C; c++) {
+        TRY(span_begin(p, 0, Sc));
+        if (p->c2c) TRY(launch(p, pl.fz[c], p->vfwd[0], 0, I, A));
+        else TRY(launch_real(p, pl.fz[c], 1, I, A));
+        TRY(span_end(p, Sc));
+        if (P > 1) {
+            EV_RECORD(c, Sc);
+            EV_WAIT(c, Sm);
+            TRY(span_begin(p, 1, Sm));
+            TRY(exchange_tables(p, 2, pl.f2[c], true, A, ysrc, Sm));
+            TRY(span_end(p, Sm));
+            EV_RECORD(C + c, Sm);
+        }
+    }
+    for (int c = 0; c < C; c++) {
+        if (P > 1) EV_WAIT(C + c, Sc);
+        TRY(span_begin(p, 2, Sc));
+        for (int q = 0; q < P; q++) TRY(launch(p, pl.zy[(size_t)c * P + q], p->vfwd[1], 1, ysrc, ydst));
+        TRY(span_end(p, Sc));
+    }
+    TRY(span_begin(p, 4, Sc));
+    TRY(launch(p, pl.fx, p->vfwd[2], 2, ydst, A));
+    TRY(span_end(p, Sc));
+    return 0;
+}
+
+// Z_Then_YX inverse:  x^-1: I -> W0   y^-1: W0 -> I   [ex: I -> W1]   z^-1: -> out
+static int enqueue_inverse_zyx(dfft_plan *p, void *out, void *in)
+{
+    Pipeline &pl = p->pl;
+    const int C = pl.C, P = p->P1;
+    char *I = static_cast<char *>(in), *W = static_cast<char *>(p->work_d), *O = static_cast<char *>(out);
+    char *zsrc = P > 1 ? W + p->domainsize : I;
+    hipStream_t Sc = p->stream, Sm = pl.comm_stream;
+    p->nspans = 0; p->last_dir = DFFT_INVERSE;
+    if (p->comm && P > 1) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); }
+    TRY(span_begin(p, 0, Sc));
+    TRY(launch(p, pl.zix, p->vinv[2], 2, I, W));
+    TRY(span_end(p, Sc));
+    for (int c = 0; c < C; c++) {
+        TRY(span_begin(p, 2, Sc));
+        for (int q = 0; q < P; q++) TRY(launch(p, pl.ziy[(size_t)c * P + q], p->vinv[1], 1, W, I));
+        TRY(span_end(p, Sc));
+        if (P > 1) {
+            EV_RECORD(c, Sc);
+            EV_WAIT(c, Sm);
+            TRY(span_begin(p, 3, Sm));
+            TRY(exchange_tables(p, 2, pl.i2[c], true, I, zsrc, Sm));
+            TRY(span_end(p, Sm));
+            EV_RECORD(C + c, Sm);
+        }
+    }
+    for (int c = 0; c < C; c++) {
+        if (P > 1) EV_WAIT(C + c, Sc);
+        TRY(span_begin(p, 4, Sc));
+        if (p->c2c) TRY(launch(p, pl.iz[c], p->vinv[0], 0, zsrc, O));
+        else TRY(launch_real(p, pl.iz[c], 2, zsrc, O));
+        TRY(span_end(p, Sc));
+    }
+    return 0;
+}
 
 // partial transforms of the reference's MPIcuFFT_Pencil::execR2C/execC2R(out, in, d)
 // (src/pencil/mpicufft_pencil.cpp:1644-1839): d = 1 stops after the z pass with the natural
@@ -787,7 +983,7 @@ int dfft_plan_create(dfft_plan **plan, int kind, int precision, const dfft_confi
                      int rank, int max_world_size)
 {
     if (!plan) return fail(ERR_ARG, "null plan pointer");
-    if (kind < DFFT_SLAB || kind > DFFT_PENCIL_OPT1) return fail(ERR_ARG, "unknown plan kind");
+    if (kind < DFFT_SLAB || kind > DFFT_SLAB_Z_THEN_YX_OPT1) return fail(ERR_ARG, "unknown plan kind");
     if (precision != DFFT_F32 && precision != DFFT_F64) return fail(ERR_ARG, "unknown precision");
     dfft_plan *p = new dfft_plan;
     p->kind = kind; p->prec = precision;
@@ -826,10 +1022,13 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
     p->initialized = false;      // a failed (re-)initialisation must not leave a half-updated plan executable
     if (!Nx || !Ny || !Nz) return fail(ERR_ARG, "GlobalSize not initialized!");
     if (P1 < 1 || P2 < 1 || P1 * P2 != p->nranks) return fail(ERR_ARG, "Invalid Input Partition!");
-    if ((p->kind == DFFT_SLAB || p->kind == DFFT_SLAB_OPT1) && P2 != 1)
+    const bool zyx_kind = p->kind == DFFT_SLAB_Z_THEN_YX || p->kind == DFFT_SLAB_Z_THEN_YX_OPT1;
+    if ((p->kind == DFFT_SLAB || p->kind == DFFT_SLAB_OPT1 || zyx_kind) && P2 != 1)
         return fail(ERR_ARG, "slab decomposition needs P2 == 1");
+    // one rank: every class is the same local 3-D transform (fft3d branch, mpicufft_slab_z_then_yx.cpp:118-122)
+    const bool zyx = zyx_kind && P1 > 1;
     if (P1 > MAXSEG || P2 > MAXSEG) return fail(ERR_UNSUPPORTED, "more than 32 ranks per exchange group");
-    if ((size_t)P1 > Nx || (size_t)P1 > Ny || (size_t)P2 > Ny) return fail(ERR_ARG, "partition larger than the grid");
+    if ((size_t)P1 > Nx || (!zyx && (size_t)P1 > Ny) || (size_t)P2 > Ny) return fail(ERR_ARG, "partition larger than the grid");
     // axis plans: native power-of-two chain (2..2048) or Bluestein (any length with 2N-1 <= 2048)
     {
         Axis az, ay, axx;
@@ -843,16 +1042,18 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
     }
     p->Nx = Nx; p->Ny = Ny; p->Nz = Nz; p->c2c = c2c != 0;
     p->Nzc = c2c ? Nz : Nz / 2 + 1;
-    if ((size_t)P2 > p->Nzc) return fail(ERR_ARG, "partition larger than the grid");
+    if ((size_t)P2 > p->Nzc || (zyx && (size_t)P1 > p->Nzc)) return fail(ERR_ARG, "partition larger than the grid");
+    p->zyx = zyx;
     p->P1 = P1; p->P2 = P2;
     p->pi = p->rank / P2; p->pj = p->rank % P2;       // pidx = pidx_i * P2 + pidx_j (:67-68)
     split(Nx, P1, p->xs, p->xstart);
     split(Ny, P2, p->ys, p->ystart);
-    split(p->Nzc, P2, p->zs, p->zstart);
+    // Z_Then_YX: the output is split along z over all ranks (mpicufft_slab_z_then_yx.cpp:96-103)
+    split(p->Nzc, zyx ? P1 : P2, p->zs, p->zstart);
     split(Ny, P1, p->yo, p->yostart);
-    const size_t xs = p->xs[p->pi], ys = p->ys[p->pj], zs = p->zs[p->pj], yo = p->yo[p->pi];
+    const size_t xs = p->xs[p->pi], ys = p->ys[p->pj], zs = p->zs[zyx ? p->pi : p->pj], yo = p->yo[p->pi];
     // domainsize = largest stage (:203-209)
-    p->domain_elems = std::max({xs * ys * p->Nzc, xs * Ny * zs, Nx * yo * zs});
+    p->domain_elems = zyx ? std::max(xs * Ny * p->Nzc, Nx * Ny * zs) : std::max({xs * ys * p->Nzc, xs * Ny * zs, Nx * yo * zs});
     p->domainsize = p->domain_elems * p->esz;
     p->domainsize = (p->domainsize + 255) & ~(size_t)255;
     const int nexch = (P1 > 1) + (P2 > 1);
@@ -871,10 +1072,17 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
     p->sc2.assign(P1, 0); p->sd2.assign(P1, 0); p->rc2.assign(P1, 0); p->rd2.assign(P1, 0);
     p->group2.assign(P1, 0);
     for (int q = 0; q < P1; q++) {
-        p->sc2[q] = e * xs * zs * p->yo[q];
-        p->sd2[q] = e * xs * zs * p->yostart[q];
-        p->rc2[q] = e * p->xs[q] * yo * zs;
-        p->rd2[q] = e * p->xstart[q] * yo * zs;
+        if (zyx) {      // mpicufft_slab_z_then_yx.cpp:190-196
+            p->sc2[q] = e * p->zs[q] * Ny * xs;
+            p->sd2[q] = e * p->zstart[q] * Ny * xs;
+            p->rc2[q] = e * zs * Ny * p->xs[q];
+            p->rd2[q] = e * zs * Ny * p->xstart[q];
+        } else {
+            p->sc2[q] = e * xs * zs * p->yo[q];
+            p->sd2[q] = e * xs * zs * p->yostart[q];
+            p->rc2[q] = e * p->xs[q] * yo * zs;
+            p->rd2[q] = e * p->xstart[q] * yo * zs;
+        }
         p->group2[q] = q * P2 + p->pj;
     }
     // pipeline depth: chunks of the outer axis exchanged while the next chunk is transformed
@@ -883,12 +1091,12 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         if (C <= 0) if (const char *v = getenv("DFFT_CHUNKS")) C = atoi(v);
         if (C <= 0) C = nexch ? 4 : 1;
         size_t lim = (size_t)MAXSEG / (size_t)P1;            // segments of the x / ky axis = P1 * C
-        for (int q = 0; q < P1; q++) lim = std::min({lim, p->xs[q], p->yo[q]});
+        for (int q = 0; q < P1; q++) lim = std::min({lim, p->xs[q], zyx ? p->xs[q] : p->yo[q]});
         if ((size_t)C > lim) C = (int)lim;
         if (C < 1) C = 1;
         p->pl.C = C;
     }
-    TRY(build_pipeline(p, p->pl));
+    TRY(zyx ? build_pipeline_zyx(p, p->pl) : build_pipeline(p, p->pl));
     // the inverse x pass reads the point-major API layout: use the strided-read configuration
     // (variant 1) where one exists for this length
     {
@@ -943,8 +1151,8 @@ static int upload_tables(dfft_plan *p)
 {
     Pipeline &pl = p->pl;
     std::vector<Launch *> all;
-    for (auto *v : {&pl.fz, &pl.fy, &pl.ix, &pl.iy, &pl.iz, &pl.py2, &pl.qy2}) for (auto &L : *v) all.push_back(&L);
-    all.push_back(&pl.fx); all.push_back(&pl.pz1); all.push_back(&pl.qz1);
+    for (auto *v : {&pl.fz, &pl.fy, &pl.ix, &pl.iy, &pl.iz, &pl.py2, &pl.qy2, &pl.zy, &pl.ziy}) for (auto &L : *v) all.push_back(&L);
+    all.push_back(&pl.fx); all.push_back(&pl.pz1); all.push_back(&pl.qz1); all.push_back(&pl.zix);
     std::vector<char> host(all.size() * 2 * sizeof(SegTable));
     size_t off = 0;
     for (Launch *L : all) {
@@ -1031,6 +1239,7 @@ int dfft_exec_dim(dfft_plan *p, void *out, void *in, int direction, int d)
     if (!out || !in) return fail(ERR_ARG, "null buffer");
     if (d < 1 || d > 3) return fail(ERR_ARG, "d must be 1, 2 or 3");
     if (direction != DFFT_FORWARD && direction != DFFT_INVERSE) return fail(ERR_ARG, "bad direction");
+    if (p->zyx && d != 3) return fail(ERR_UNSUPPORTED, "partial transforms are not defined for the Z_Then_YX sequence");
     if (d == 3) TRY(direction == DFFT_FORWARD ? enqueue_forward(p, out, in) : enqueue_inverse(p, out, in));
     else TRY(direction == DFFT_FORWARD ? enqueue_partial_forward(p, out, in, d) : enqueue_partial_inverse(p, out, in, d));
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -1081,12 +1290,14 @@ int dfft_get_out_size(const dfft_plan *p, size_t s[3])
 {
     if (!p || !p->initialized) return fail(ERR_STATE, "plan not initialised");
     s[0] = p->Nx; s[1] = p->yo[p->pi]; s[2] = p->zs[p->pj];
+    if (p->zyx) { s[1] = p->Ny; s[2] = p->zs[p->pi]; }      // include/mpicufft_slab_z_then_yx.hpp:43-44
     return 0;
 }
 int dfft_get_out_start(const dfft_plan *p, size_t s[3])
 {
     if (!p || !p->initialized) return fail(ERR_STATE, "plan not initialised");
     s[0] = 0; s[1] = p->yostart[p->pi]; s[2] = p->zstart[p->pj];
+    if (p->zyx) { s[1] = 0; s[2] = p->zstart[p->pi]; }
     return 0;
 }
 size_t dfft_domain_size(const dfft_plan *p) { return p ? p->domainsize : 0; }
@@ -1115,6 +1326,7 @@ int dfft_get_pipeline_tables(const dfft_plan *p, int direction, int which, int c
     if (chunk < 0 || chunk >= p->pl.C) return fail(ERR_ARG, "chunk out of range");
     const std::vector<A2A> &v = direction == DFFT_INVERSE ? (which == 1 ? p->pl.i1 : p->pl.i2)
                                                           : (which == 1 ? p->pl.f1 : p->pl.f2);
+    if ((size_t)chunk >= v.size()) return fail(ERR_ARG, "this plan has no such exchange");
     const A2A &T = v[chunk];
     for (size_t i = 0; i < T.sc.size(); i++) { sc[i] = T.sc[i]; sd[i] = T.sd[i]; rc[i] = T.rc[i]; rd[i] = T.rd[i]; }
     return 0;

@@ -43,7 +43,11 @@ enum dfft_kind {
     DFFT_SLAB = 0,         /* MPIcuFFT_Slab       include/mpicufft_slab.hpp          */
     DFFT_SLAB_OPT1 = 1,    /* MPIcuFFT_Slab_Opt1  include/mpicufft_slab_opt1.hpp     */
     DFFT_PENCIL = 2,       /* MPIcuFFT_Pencil     include/mpicufft_pencil.hpp        */
-    DFFT_PENCIL_OPT1 = 3   /* MPIcuFFT_Pencil_Opt1 include/mpicufft_pencil_opt1.hpp  */
+    DFFT_PENCIL_OPT1 = 3,  /* MPIcuFFT_Pencil_Opt1 include/mpicufft_pencil_opt1.hpp  */
+    /* alternative slab sequence: 1-D z pass, one all-to-all, 2-D (y,x) pass.  Input split along x,
+     * OUTPUT split along z: [Nx][Ny][Nzc/P] (include/mpicufft_slab_z_then_yx.hpp:41-44).  P2 must be 1. */
+    DFFT_SLAB_Z_THEN_YX = 4,       /* MPIcuFFT_Slab_Z_Then_YX      include/mpicufft_slab_z_then_yx.hpp      */
+    DFFT_SLAB_Z_THEN_YX_OPT1 = 5   /* MPIcuFFT_Slab_Z_Then_YX_Opt1 include/mpicufft_slab_z_then_yx_opt1.hpp */
 };
 enum dfft_precision { DFFT_F32 = 0, DFFT_F64 = 1 };   /* template parameter T = float|double */
 enum dfft_direction { DFFT_FORWARD = -1, DFFT_INVERSE = 1 };

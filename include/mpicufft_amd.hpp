@@ -185,6 +185,21 @@ template <typename T> struct MPIcuFFT_Slab : MPIcuFFT<T> {
 template <typename T> struct MPIcuFFT_Slab_Opt1 : MPIcuFFT<T> {
     MPIcuFFT_Slab_Opt1(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1) : MPIcuFFT<T>(c, comm, max_world_size, DFFT_SLAB_OPT1) {}
 };
+// alternative slab sequence (include/mpicufft_slab_z_then_yx.hpp, _opt1.hpp): output [Nx][Ny][Nzc/P]
+template <typename T> struct MPIcuFFT_Slab_Z_Then_YX : MPIcuFFT<T> {
+    MPIcuFFT_Slab_Z_Then_YX(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1, int kind = DFFT_SLAB_Z_THEN_YX)
+        : MPIcuFFT<T>(c, comm, max_world_size, kind) {}
+    using MPIcuFFT<T>::initFFT;
+    void initFFT(GlobalSize *g, bool allocate = true)     // include/mpicufft_slab_z_then_yx.hpp:33-37
+    {
+        Slab_Partition p(this->getWorldSize());
+        MPIcuFFT<T>::initFFT(g, &p, allocate);
+    }
+};
+template <typename T> struct MPIcuFFT_Slab_Z_Then_YX_Opt1 : MPIcuFFT_Slab_Z_Then_YX<T> {
+    MPIcuFFT_Slab_Z_Then_YX_Opt1(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1)
+        : MPIcuFFT_Slab_Z_Then_YX<T>(c, comm, max_world_size, DFFT_SLAB_Z_THEN_YX_OPT1) {}
+};
 // partial transforms execR2C/execC2R(out, in, d), include/mpicufft_pencil.hpp:101-111
 template <typename T> struct MPIcuFFT_PencilBase : MPIcuFFT<T> {
     using MPIcuFFT<T>::MPIcuFFT;

@@ -145,3 +145,61 @@ def test_pipeline_tables_are_consistent_across_ranks(shape, P1, P2, c2c, chunks)
                     assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])), "blocks overlap"
                     assert not spans or spans[-1][1] <= pl.getDomainSize()
                     assert sum(b - a for a, b in spans) % esz == 0
+
+
+@pytest.mark.parametrize("shape,P,c2c", [((16, 8, 16), 2, True), ((30, 20, 18), 3, False), ((64, 6, 32), 8, True),
+                                         ((1024, 1024, 1024), 8, False)])
+@pytest.mark.parametrize("chunks", [1, 3, 4])
+def test_z_then_yx_plan_algebra_and_tables(shape, P, c2c, chunks):
+    """slab sequence Z_Then_YX: sizes/offsets (mpicufft_slab_z_then_yx.cpp:85-106, hpp:41-44), the
+    per-peer byte counts (:190-196) and the chunked tables built from them"""
+    Nx, Ny, Nz = shape
+    Nzc = Nz if c2c else Nz // 2 + 1
+    esz = 16
+    world = dfft.Comm.local(P)
+    plans = []
+    for r in range(P):
+        pl = dfft.MPIcuFFT_Slab_Z_Then_YX(dfft.Configurations(), world, precision="double", rank=r)
+        pl.setPipelineChunks(chunks)
+        pl.initFFT(dfft.GlobalSize(*shape), dfft.Slab_Partition(P), allocate=False, c2c=c2c)
+        plans.append(pl)
+
+    def split(n):
+        return [n // P + (1 if q < n % P else 0) for q in range(P)]
+
+    xs, zs = split(Nx), split(Nzc)
+    x0 = [sum(xs[:q]) for q in range(P)]
+    z0 = [sum(zs[:q]) for q in range(P)]
+    C = plans[0].getPipelineChunks()
+    for r, pl in enumerate(plans):
+        assert list(pl.getInSize()) == [xs[r], Ny, Nz] and list(pl.getInStart()) == [x0[r], 0, 0]
+        assert list(pl.getOutSize()) == [Nx, Ny, zs[r]] and list(pl.getOutStart()) == [0, 0, z0[r]]
+        assert pl.getDomainSize() >= esz * max(xs[r] * Ny * Nzc, Nx * Ny * zs[r])
+        assert pl.getWorkSizeDevice() == 2 * pl.getDomainSize()
+        sc, sd, rc, rd = pl.getExchangeTables(2)
+        assert sc == [esz * zs[q] * Ny * xs[r] for q in range(P)]
+        assert sd == [esz * z0[q] * Ny * xs[r] for q in range(P)]
+        assert rc == [esz * zs[r] * Ny * xs[q] for q in range(P)]
+        assert rd == [esz * zs[r] * Ny * x0[q] for q in range(P)]
+        for direction in (dfft.FORWARD, dfft.INVERSE):
+            tot_s, tot_r, spans_s, spans_r = [0] * P, [0] * P, [], []
+            for c in range(C):
+                tsc, tsd, trc, trd = pl.getPipelineTables(direction, 2, c)
+                for q in range(P):
+                    psc, _, prc, _ = plans[q].getPipelineTables(direction, 2, c)
+                    assert tsc[q] == prc[r] and trc[q] == psc[r]
+                    tot_s[q] += tsc[q]
+                    tot_r[q] += trc[q]
+                    if tsc[q]:
+                        spans_s.append((tsd[q], tsd[q] + tsc[q]))
+                    if trc[q]:
+                        spans_r.append((trd[q], trd[q] + trc[q]))
+            assert (tot_s, tot_r) == ((sc, rc) if direction == dfft.FORWARD else (rc, sc))
+            for spans in (spans_s, spans_r):
+                spans.sort()
+                assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])), "blocks overlap"
+                assert spans[-1][1] <= pl.getDomainSize()
+    # a single rank is the local 3-D transform with the usual output block
+    one = dfft.MPIcuFFT_Slab_Z_Then_YX(dfft.Configurations(), precision="double")
+    one.initFFT(dfft.GlobalSize(*shape), dfft.Slab_Partition(1), allocate=False, c2c=c2c)
+    assert list(one.getOutSize()) == [Nx, Ny, Nzc]

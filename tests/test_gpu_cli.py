@@ -48,3 +48,16 @@ def test_testcase1_distributed_vs_single_and_benchmarks(tmp_path, capsys):
     r = cli.run(["pencil", "-nx", "64", "-ny", "64", "-nz", "64", "-p1", "2", "-p2", "2", "-t", "0", "-f", "2", "-d", "--complex",
                  "-b", str(tmp_path)])
     assert os.path.exists(r["csv"])
+
+
+def test_slab_sequence_z_then_yx_testcases(tmp_path):
+    """`slab -s Z_Then_YX` (tests/src/slab/main.cpp:193-201): testcases 1, 3 and 4 on the z-split output"""
+    base = ["slab", "-nx", "32", "-ny", "16", "-nz", "64", "-p", "3", "-s", "Z_Then_YX", "-d", "-b", str(tmp_path)]
+    assert cli.run(base + ["-t", "1"])["sum"] < 1e-6
+    r = cli.run(base + ["-t", "3", "-o", "1"])
+    assert r["max"] < 1e-6
+    assert os.path.basename(r["csv"]) == "test_1_1_0_32_16_64_0_3.csv" and os.path.dirname(r["csv"]).endswith("slab_z_then_yx")
+    r = cli.run(["slab", "-nx", "32", "-ny", "32", "-nz", "32", "-p", "4", "-s", "Z_Then_YX", "-t", "4", "-d", "-b", str(tmp_path)])
+    assert r["max"] < 1e-9 * math.sqrt(32.0 ** 3) * 3
+    with pytest.raises(SystemExit):
+        cli.run(base + ["-s", "Y_Then_ZX"])

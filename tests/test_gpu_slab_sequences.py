@@ -1,0 +1,156 @@
+"""Alternative slab sequence Z_Then_YX (reference: src/slab/z_then_yx/, include/mpicufft_slab_z_then_yx.hpp):
+input split along x, ONE all-to-all over all ranks after the z pass, output [Nx][Ny][Nzc/P] split
+along z.  Checked like the reference's slab testcases: distributed == single-device transform
+(testcase 1), round trip (testcase 3), analytic Laplacian (testcase 4).  Tolerances as in
+test_gpu_parity.py."""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import distributedfft_amd as dfft  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+TOL_FWD = {"double": 1e-11, "float": 1e-4}
+TOL_RT = {"double": 1e-10, "float": 5e-5}
+CDT = {"double": torch.complex128, "float": torch.complex64}
+NPC = {"double": np.complex128, "float": np.complex64}
+NPR = {"double": np.float64, "float": np.float32}
+
+
+def run(cls, shape, P, prec, c2c, chunks=None, field=None, modify=None, seed=21):
+    world = dfft.Comm.local(P) if P > 1 else None
+    esz = 16 if prec == "double" else 8
+    plans, ins, outs, backs, host_ins = [], [], [], [], []
+    for r in range(P):
+        pl = cls(dfft.Configurations(), world, precision=prec, rank=r)
+        if chunks is not None:
+            pl.setPipelineChunks(chunks)
+        pl.initFFT(dfft.GlobalSize(*shape), dfft.Slab_Partition(P), True, c2c=c2c)
+        size, start = pl.getInSize(), pl.getInStart()
+        assert tuple(size[1:]) == tuple(shape[1:]) and tuple(start[1:]) == (0, 0)
+        if field is not None:
+            blk = np.ascontiguousarray(field[start[0]:start[0] + size[0]]).astype(NPR[prec])
+        elif c2c:
+            blk = orc.fill_block(shape, start, size, 2, seed=seed).astype(NPC[prec])
+        else:
+            blk = orc.fill_block(shape, start, size, 1, seed=seed).astype(NPR[prec])
+        plans.append(pl)
+        host_ins.append(blk.copy())
+        ins.append(torch.from_numpy(blk).cuda())
+        outs.append(torch.zeros(pl.getDomainSize() // esz, dtype=CDT[prec], device="cuda"))
+        backs.append(torch.zeros_like(ins[-1]))
+    torch.cuda.synchronize()
+    fwd = (lambda r: plans[r].execC2C(outs[r], ins[r], dfft.FORWARD)) if c2c else (lambda r: plans[r].execR2C(outs[r], ins[r]))
+    inv = (lambda r: plans[r].execC2C(backs[r], outs[r], dfft.INVERSE)) if c2c else (lambda r: plans[r].execC2R(backs[r], outs[r]))
+    with ThreadPoolExecutor(P) as ex:
+        list(ex.map(fwd, range(P)))
+    torch.cuda.synchronize()
+    spec = []
+    for r in range(P):
+        s = plans[r].getOutSize()
+        spec.append(outs[r][:s[0] * s[1] * s[2]].cpu().numpy().reshape(s))
+    if modify is not None:
+        for r in range(P):
+            s, o = plans[r].getOutSize(), plans[r].getOutStart()
+            blk = np.ascontiguousarray(spec[r].astype(np.complex128))
+            modify(blk, s, o)
+            outs[r][:blk.size] = torch.from_numpy(blk.astype(NPC[prec]).ravel()).cuda()
+    torch.cuda.synchronize()
+    for r in range(P):
+        assert np.array_equal(ins[r].cpu().numpy(), host_ins[r]), "forward must not modify its input"
+    with ThreadPoolExecutor(P) as ex:
+        list(ex.map(inv, range(P)))
+    torch.cuda.synchronize()
+    return plans, [t.cpu().numpy() for t in ins], spec, [t.cpu().numpy() for t in backs]
+
+
+def global_input(shape, c2c, prec, seed=21):
+    g = orc.fill_block(shape, (0, 0, 0), shape, 2 if c2c else 1, seed=seed)
+    return g.astype(NPC[prec]).astype(np.complex128) if c2c else g.astype(NPR[prec]).astype(np.float64)
+
+
+CASES = [((16, 16, 16), 2), ((32, 16, 64), 3), ((64, 32, 16), 8), ((8, 4, 16), 2), ((33, 20, 18), 4),
+         ((24, 10, 20), 4), ((128, 64, 32), 5)]
+
+
+@pytest.mark.parametrize("prec", ["double", "float"])
+@pytest.mark.parametrize("c2c", [True, False])
+@pytest.mark.parametrize("shape,P", CASES)
+def test_z_then_yx_vs_oracle(shape, P, c2c, prec):
+    cls = dfft.MPIcuFFT_Slab_Z_Then_YX
+    plans, ins, spec, backs = run(cls, shape, P, prec, c2c)
+    g = global_input(shape, c2c, prec)
+    want = orc.fft3d_c2c(g, -1) if c2c else orc.fft3d_r2c(g)
+    Nzc = want.shape[2]
+    n3 = float(np.prod(shape))
+    scale = np.max(np.abs(want))
+    cover = np.zeros(Nzc, dtype=int)
+    for r, pl in enumerate(plans):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        assert tuple(s[:2]) == tuple(shape[:2]) and tuple(o[:2]) == (0, 0)
+        cover[o[2]:o[2] + s[2]] += 1
+        ref = want[:, :, o[2]:o[2] + s[2]]
+        assert np.max(np.abs(spec[r] - ref)) / scale < TOL_FWD[prec]
+        assert np.max(np.abs(backs[r] / n3 - ins[r])) / 255.0 < TOL_RT[prec]
+    assert np.all(cover == 1)
+
+
+@pytest.mark.parametrize("chunks", [1, 2, 3, 8])
+@pytest.mark.parametrize("shape,P", [((32, 16, 64), 3), ((64, 32, 16), 4)])
+def test_z_then_yx_pipeline_depths_and_opt1_class(shape, P, chunks):
+    plans, ins, spec, backs = run(dfft.MPIcuFFT_Slab_Z_Then_YX_Opt1, shape, P, "double", False, chunks=chunks)
+    assert 1 <= plans[0].getPipelineChunks() <= chunks
+    want = orc.fft3d_r2c(global_input(shape, False, "double"))
+    n3 = float(np.prod(shape))
+    for r, pl in enumerate(plans):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        assert np.max(np.abs(spec[r] - want[:, :, o[2]:o[2] + s[2]])) / np.max(np.abs(want)) < 1e-11
+        assert np.max(np.abs(backs[r] / n3 - ins[r])) / 255.0 < 1e-10
+
+
+def test_z_then_yx_laplacian_known_answer():
+    """reference testcase 4 on the z-split output (tests/src/slab/random_dist_z_then_yx.cu)"""
+    shape, P = (32, 32, 32), 4
+    Nx, Ny, Nz = shape
+    x, y, z = np.meshgrid(np.arange(Nx), np.arange(Ny), np.arange(Nz), indexing="ij")
+    u = np.sin(2 * np.pi * x / Nx) * np.sin(2 * np.pi * y / Ny) * np.sin(2 * np.pi * z / Nz)
+
+    def modify(blk, s, o):
+        orc.derivative_coefficients(blk, shape, o[2], o[1], half=True)
+
+    plans, ins, spec, backs = run(dfft.MPIcuFFT_Slab_Z_Then_YX, shape, P, "double", False, field=u, modify=modify)
+    n3 = float(Nx * Ny * Nz)
+    for r in range(P):
+        assert np.max(np.abs(backs[r] - (-3.0 * np.sqrt(n3) * ins[r]))) < 1e-9 * np.sqrt(n3)
+
+
+def test_z_then_yx_256_cube_four_ranks_every_point():
+    shape, P = (256, 256, 256), 4
+    plans, ins, spec, backs = run(dfft.MPIcuFFT_Slab_Z_Then_YX, shape, P, "double", True)
+    want = orc.fft3d_c2c(global_input(shape, True, "double"), -1)
+    scale = np.max(np.abs(want))
+    for r, pl in enumerate(plans):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        assert np.max(np.abs(spec[r] - want[:, :, o[2]:o[2] + s[2]])) / scale < 1e-11
+        assert np.max(np.abs(backs[r] / float(np.prod(shape)) - ins[r])) / 255.0 < 1e-10
+
+
+def test_z_then_yx_errors_and_single_rank():
+    world = dfft.Comm.local(4)
+    pl = dfft.MPIcuFFT_Slab_Z_Then_YX(dfft.Configurations(), world, rank=0)
+    with pytest.raises(dfft.DfftError, match="partition larger"):
+        pl.initFFT(dfft.GlobalSize(16, 16, 4), dfft.Slab_Partition(4), True)     # Nz/2+1 = 3 < 4 ranks
+    with pytest.raises(dfft.DfftError, match="P2 == 1"):
+        pl.initFFT(dfft.GlobalSize(16, 16, 16), dfft.Pencil_Partition(2, 2), True)
+    pl.initFFT(dfft.GlobalSize(16, 16, 16), dfft.Slab_Partition(4), True)
+    with pytest.raises(dfft.DfftError, match="Z_Then_YX"):
+        pl.execR2C(1, 1, d=1)
+    # one rank: the plain local 3-D transform (fft3d branch)
+    plans, ins, spec, backs = run(dfft.MPIcuFFT_Slab_Z_Then_YX, (16, 8, 32), 1, "double", False)
+    want = orc.fft3d_r2c(global_input((16, 8, 32), False, "double"))
+    assert np.max(np.abs(spec[0] - want)) / np.max(np.abs(want)) < 1e-11
