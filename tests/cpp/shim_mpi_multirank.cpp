@@ -1,10 +1,12 @@
-// Multi-rank reference-style caller: mpiexec -n P1*P2 ./shim_mpi_multirank P1 P2
+// Multi-rank reference-style caller: mpiexec -n P1*P2 ./shim_mpi_multirank P1 P2 [zyx]
+// ("zyx": the slab sequence Z_Then_YX, P2 = 1, output split along z)
 // All ranks share GPU 0 (cudaSetDevice(rank % dev_count) in the reference,
 // tests/src/pencil/random_dist_3D.cu:175-177) and exchange through host-staged MPI
 // (Configurations::cuda_aware = false).  Testcase 3 (round trip) + the DC coefficient.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "mpicufft_amd.hpp"
@@ -21,13 +23,16 @@ int main(int argc, char **argv)
     hipGetDeviceCount(&ndev);
     hipSetDevice(rank % ndev);
     Configurations config{false, 0, All2All, Sync, "../benchmarks", All2All, Sync};
-    MPIcuFFT_Pencil_Opt1<double> *fftp = new MPIcuFFT_Pencil_Opt1<double>(config, MPI_COMM_WORLD, world_size);
-    MPIcuFFT_Pencil_Opt1<double> &fft = *fftp;
+    const bool zyx = argc > 3 && std::string(argv[3]) == "zyx";
+    MPIcuFFT<double> *fftp = zyx ? static_cast<MPIcuFFT<double> *>(new MPIcuFFT_Slab_Z_Then_YX<double>(config, MPI_COMM_WORLD, world_size))
+                                 : static_cast<MPIcuFFT<double> *>(new MPIcuFFT_Pencil_Opt1<double>(config, MPI_COMM_WORLD, world_size));
+    MPIcuFFT<double> &fft = *fftp;
     Pencil_Partition partition(P1, P2);
     GlobalSize global_size(Nx, Ny, Nz);
     fft.initFFT(&global_size, &partition, true);
     size_t isz[3], ist[3], osz[3], ost[3];
     fft.getInSize(isz); fft.getInStart(ist); fft.getOutSize(osz); fft.getOutStart(ost);
+    if (zyx && (osz[0] != Nx || osz[1] != Ny || ost[0] != 0 || ost[1] != 0)) { printf("bad Z_Then_YX output block\n"); MPI_Abort(MPI_COMM_WORLD, 2); }
     const size_t n = isz[0] * isz[1] * isz[2];
     std::vector<double> in_h(n), inv_h(n);
     double sum = 0;

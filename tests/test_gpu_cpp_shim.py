@@ -40,15 +40,15 @@ def test_cpp_shim_round_trip(tmp_path):
 
 
 @needs_mpich
-@pytest.mark.parametrize("P1,P2", [(2, 1), (2, 2), (3, 2)])
-def test_cpp_shim_mpi_ranks_sharing_the_gpu(tmp_path, P1, P2):
+@pytest.mark.parametrize("P1,P2,mode", [(2, 1, ""), (2, 2, ""), (3, 2, ""), (3, 1, "zyx")])
+def test_cpp_shim_mpi_ranks_sharing_the_gpu(tmp_path, P1, P2, mode):
     """mpiexec -n P: real MPI ranks (one process each) share GPU 0 and exchange through the shim's
     host-staged MPI transport = the reference's cuda_aware = false path"""
     mpiexec = "/opt/conda/bin/mpiexec"
     if not os.path.exists(mpiexec):
         pytest.skip("no mpiexec")
     exe, env = build(tmp_path, "shim_mpi_multirank.cpp")
-    out = subprocess.run([mpiexec, "-n", str(P1 * P2), str(exe), str(P1), str(P2)], env=env, capture_output=True, text=True,
+    out = subprocess.run([mpiexec, "-n", str(P1 * P2), str(exe), str(P1), str(P2)] + ([mode] if mode else []), env=env, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert f"ranks {P1 * P2} grid {P1}x{P2}" in out.stdout
