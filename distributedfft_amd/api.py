@@ -291,6 +291,11 @@ class MPIcuFFT_Slab_Z_Then_YX_Opt1(MPIcuFFT):
     _kind = 5
 
 
+class MPIcuFFT_Slab_Y_Then_ZX(MPIcuFFT):
+    """include/mpicufft_slab_y_then_zx.hpp: forward only; R2C along y, output [Nx][(Ny/2+1)/P][Nz]"""
+    _kind = 6
+
+
 class MPIcuFFT_Pencil(MPIcuFFT):
     _kind = 2
 

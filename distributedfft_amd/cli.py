@@ -75,6 +75,8 @@ class Rank:
                 ("slab", 0): dfft.MPIcuFFT_Slab, ("slab", 1): dfft.MPIcuFFT_Slab_Opt1}[(args.mode, args.opt)]
         if args.mode == "slab" and args.sequence == "Z_Then_YX":
             kind = dfft.MPIcuFFT_Slab_Z_Then_YX if args.opt == 0 else dfft.MPIcuFFT_Slab_Z_Then_YX_Opt1
+        if args.mode == "slab" and args.sequence == "Y_Then_ZX":
+            kind = dfft.MPIcuFFT_Slab_Y_Then_ZX
         self.plan = kind(cfg, comm, precision=prec, rank=rank)
         t0 = time.perf_counter()
         self.N = (args.input_dim_x, args.input_dim_y, args.input_dim_z)
@@ -113,6 +115,11 @@ class Rank:
     def record(self, direction):
         ph = self.plan.getPhaseTimes(direction)
         names = SECTIONS_F if direction == self.dfft.FORWARD else SECTIONS_B
+        if self.args.sequence == "Y_Then_ZX":      # phases: y pass, exchange, x pass, -, z pass
+            names = ["1D FFT Y-Direction", "Transpose (Finished Receive)", "1D FFT X-Direction", "-", "1D FFT Z-Direction"]
+        elif self.args.sequence == "Z_Then_YX":    # one exchange only (phase 1 forward, phase 3 inverse)
+            names = [n.replace("First Transpose (Finished All2All)", "Transpose (Finished Receive)")
+                      .replace("Second Transpose (Finished All2All)", "Transpose (Finished Receive)") for n in names]
         cum, rows = 0.0, []
         for (_, ms), name in zip(ph, names):
             cum += ms
@@ -141,7 +148,7 @@ class Rank:
 
 
 def write_csv(args, ranks, P1, P2):
-    sub = "pencil" if args.mode == "pencil" else ("slab_z_then_yx" if args.sequence == "Z_Then_YX" else "slab_default")
+    sub = "pencil" if args.mode == "pencil" else ({"Z_Then_YX": "slab_z_then_yx", "Y_Then_ZX": "slab_y_then_zx"}.get(args.sequence, "slab_default"))
     d = os.path.join(args.benchmark_dir, sub)
     os.makedirs(d, exist_ok=True)
     if args.mode == "pencil":
@@ -173,9 +180,9 @@ def run(argv=None):
     args = parse(argv if argv is not None else sys.argv[1:])
     if args.sequence != "ZY_Then_X" and args.mode != "slab":
         raise SystemExit("--sequence applies to the slab decomposition")
-    if args.sequence == "Y_Then_ZX":
-        raise SystemExit("sequence Y_Then_ZX (forward-only, Hermitian axis y) is not provided; see DESIGN.md 7")
-    if args.sequence == "Z_Then_YX" and args.fft_dim != 3:
+    if args.sequence == "Y_Then_ZX" and args.testcase not in (0, 1):
+        raise SystemExit("sequence Y_Then_ZX is forward only (testcases 0 and 1), as in the reference")
+    if args.sequence != "ZY_Then_X" and args.fft_dim != 3:
         raise SystemExit("--fft-dim 1|2 is defined for the pencil classes only")
     import torch
 

@@ -164,6 +164,17 @@ static bool axis_plan(int prec, size_t N, Axis &a)
     return true;
 }
 
+// Bluestein even for a power of two: its kernel is the one with a strided real-line load (Y_Then_ZX)
+static bool axis_plan_bluestein(int prec, size_t N, Axis &a)
+{
+    PassInfo pi;
+    a.N = N;
+    const size_t M = next_pow2(2 * N - 1);
+    if (N < 2 || !pass_info(prec, (int)M, &pi)) return false;
+    a.bluestein = true; a.M = M;
+    return true;
+}
+
 static int axis_upload(int prec, Axis &a)
 {
     const long double PI = 3.141592653589793238462643383279502884L;
@@ -212,6 +223,7 @@ struct Pipeline {
     // unchunked inverse x pass; the exchange tables live in f2 / i2
     std::vector<Launch> zy, ziy;
     Launch zix;
+    Launch yz;                                 // Y_Then_ZX: final z pass (x pass = fx, y chunks = fy)
     std::vector<A2A> f1, f2, i2, i1;          // per chunk exchange tables
     std::vector<hipEvent_t> ev;               // reusable events
     hipStream_t comm_stream = nullptr;
@@ -227,6 +239,8 @@ struct dfft_plan {
     int rank = 0, nranks = 1;
     bool initialized = false, c2c = false;
     bool zyx = false;            // slab sequence Z_Then_YX: input split along x, output split along z
+    bool yzx = false;            // slab sequence Y_Then_ZX: R2C along y, output [Nx][(Ny/2+1)/P][Nz], forward only
+    size_t Nyc = 0;              // y extent of the spectrum (Ny/2+1 for a Y_Then_ZX R2C plan, else Ny)
     size_t Nx = 0, Ny = 0, Nz = 0, Nzc = 0;
     int P1 = 1, P2 = 1, pi = 0, pj = 0;
     int TL = 8;
@@ -557,6 +571,79 @@ static int build_pipeline_zyx(dfft_plan *p, Pipeline &pl)
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Slab sequence Y_Then_ZX (src/slab/y_then_zx/mpicufft_slab_y_then_zx.cpp:71-175, 268-378; the
+// reference provides the forward direction only).  The real-to-complex transform runs along y, the
+// output [Nx][(Ny/2+1)/P][Nz] keeps z contiguous:
+//   y pass chunk c   real lines along y read in place (lanes along z) -> send block (c,p) =
+//                    [ky in yo[p]][z/TL][x][z%TL]
+//   exchange chunk c (counts :309-319)  -> recv block (c,q), x in chunk c of xs[q]
+//   x pass           lines along x gathered from the P*C blocks -> [ky][kx/TL][z][kx%TL]
+//   z pass           -> rows (kx*yo + ky)*Nz of the API layout (strided-lines store)
+// ------------------------------------------------------------------------------------------
+static int build_pipeline_yzx(dfft_plan *p, Pipeline &pl)
+{
+    const int TL = p->TL, P = p->P1, C = pl.C, r = p->pi;
+    const uint32_t T2shift = ilog2(TL);
+    const size_t xs = p->xs[r], yo = p->yo[r];
+    const size_t Nx = p->Nx, Ny = p->Ny, Nz = p->Nz, e = p->esz;
+    auto base = [&](size_t na, size_t LB, int lk, int sk) {
+        PassArgs A;
+        memset(&A, 0, sizeof(A));
+        A.na = (uint32_t)na; A.LB = (uint32_t)LB; A.nb = (uint32_t)((LB + TL - 1) / TL); A.ntiles = A.na * A.nb;
+        A.load_kind = lk; A.store_kind = sk; A.T2shift = T2shift;
+        return A;
+    };
+    std::vector<size_t> xl, x0;
+    split(xs, C, xl, x0);
+    std::vector<std::vector<size_t>> xlq(P), x0q(P);
+    for (int q = 0; q < P; q++) split(p->xs[q], C, xlq[q], x0q[q]);
+    std::vector<std::vector<size_t>> blk(C, std::vector<size_t>(P, 0));
+    { size_t acc = 0; for (int c = 0; c < C; c++) for (int q = 0; q < P; q++) { blk[c][q] = acc; acc += xlq[q][c] * yo * Nz; } }
+
+    pl.fx = Launch(); pl.yz = Launch(); pl.zix = Launch(); pl.pz1 = Launch(); pl.qz1 = Launch();
+    pl.fy.assign(C, Launch()); pl.f2.assign(C, A2A());
+    pl.fz.clear(); pl.iz.clear(); pl.ix.clear(); pl.iy.clear(); pl.zy.clear(); pl.ziy.clear();
+    pl.f1.clear(); pl.i1.clear(); pl.i2.clear(); pl.py2.clear(); pl.qy2.clear();
+    // in-place input lines: element (x, y, z) at (x*Ny + y)*Nz + z, in reals (R2C) or complex (C2C)
+    const size_t in_elem = p->c2c ? e : e / 2;
+    for (int c = 0; c < C; c++) {
+        const size_t S1c = x0[c] * p->Nyc * Nz;
+        {
+            Launch &L = pl.fy[c];
+            L.args = base(xl[c], Nz, LOAD_KMAJOR, STORE_TILED_SAME);
+            L.args.KS_in = Nz; L.args.AS_in = (uint64_t)Ny * Nz;
+            L.args.LA = (uint32_t)xl[c];
+            L.in_off = x0[c] * Ny * Nz * in_elem;
+            for (int q = 0; q < P; q++) seg_push(L.sseg, p->yostart[q], p->yo[q], S1c + xl[c] * Nz * p->yostart[q]);
+        }
+        {
+            A2A &T = pl.f2[c];
+            for (int q = 0; q < P; q++) {
+                T.sc.push_back(e * xl[c] * Nz * p->yo[q]);
+                T.sd.push_back(e * (S1c + xl[c] * Nz * p->yostart[q]));
+                T.rc.push_back(e * xlq[q][c] * Nz * yo);
+                T.rd.push_back(e * blk[c][q]);
+            }
+        }
+    }
+    {   // x pass: [ky][z/TL][x][z%TL] blocks -> [ky][kx/TL][z][kx%TL]
+        PassArgs X = base(yo, Nz, LOAD_TILED, STORE_TILED_TRANSPOSE);
+        pl.fx.args = X;
+        for (int q = 0; q < P; q++)
+            for (int c = 0; c < C; c++)
+                if (xlq[q][c]) seg_push(pl.fx.lseg, p->xstart[q] + x0q[q][c], xlq[q][c], blk[c][q]);
+        seg_push(pl.fx.sseg, 0, Nx, 0);
+    }
+    {   // z pass: lines along z, lanes along kx -> out[(kx*yo + ky)*Nz + kz]
+        PassArgs Z = base(yo, Nx, LOAD_TILED, STORE_LINES);
+        Z.KS_out = (uint64_t)yo * Nz; Z.AS_out = Nz;
+        pl.yz.args = Z;
+        seg_push(pl.yz.lseg, 0, Nz, 0);
+    }
+    return 0;
+}
+
 static void fill_tables(dfft_plan *p, const Launch &L, PassArgs &A)
 {
     A.lseg = reinterpret_cast<const SegTable *>(static_cast<const char *>(p->tables_d) + L.ltab);
@@ -565,7 +652,7 @@ static void fill_tables(dfft_plan *p, const Launch &L, PassArgs &A)
 }
 
 // complex axis pass on axis `axis` (0 = z, 1 = y, 2 = x)
-static int launch(dfft_plan *p, const Launch &L, int variant, int axis, const char *in, char *out)
+static int launch(dfft_plan *p, const Launch &L, int variant, int axis, const char *in, char *out, bool real_lines = false)
 {
     if (L.args.ntiles == 0) return 0;
     const Axis &ax = p->ax[axis];
@@ -574,6 +661,7 @@ static int launch(dfft_plan *p, const Launch &L, int variant, int axis, const ch
     fill_tables(p, L, A);
     if (!ax.bluestein) return launch_pass(p->prec, (int)ax.N, variant, A, p->stream);
     A.tw2 = ax.chirp; A.tw3 = ax.bhat; A.NL = (uint32_t)ax.N; A.NK = (uint32_t)ax.N; A.real_mode = 0;
+    if (real_lines) { A.real_mode = 1; A.NK = (uint32_t)(ax.N / 2 + 1); }     // real in, Hermitian half out
     int r = p->prec == DFFT_F64 ? launch_bluestein_f64((int)ax.M, A, p->stream) : launch_bluestein_f32((int)ax.M, A, p->stream);
     if (r != 0) return fail(r == -1 ? ERR_UNSUPPORTED : r, "Bluestein pass launch failed for length " + std::to_string(ax.N));
     return 0;
@@ -661,11 +749,13 @@ static hipEvent_t pipe_event(dfft_plan *p, size_t i)
 // forward chain.  Buffers: A = caller's out, W0..W2 = work area slices (one per exchange + 1).
 //   z: in -> A   [ex1: A -> W0]   y: -> next   [ex2: -> next]   x: -> A
 static int enqueue_forward_zyx(dfft_plan *p, void *out, const void *in);
+static int enqueue_forward_yzx(dfft_plan *p, void *out, const void *in);
 static int enqueue_inverse_zyx(dfft_plan *p, void *out, void *in);
 
 static int enqueue_forward(dfft_plan *p, void *out, const void *in)
 {
     if (p->zyx) return enqueue_forward_zyx(p, out, in);
+    if (p->yzx) return enqueue_forward_yzx(p, out, in);
     Pipeline &pl = p->pl;
     const int C = pl.C;
     char *A = static_cast<char *>(out), *W = static_cast<char *>(p->work_d);
@@ -734,6 +824,7 @@ static int enqueue_forward(dfft_plan *p, void *out, const void *in)
 static int enqueue_inverse(dfft_plan *p, void *out, void *in)
 {
     if (p->zyx) return enqueue_inverse_zyx(p, out, in);
+    if (p->yzx) return fail(ERR_UNSUPPORTED, "the Y_Then_ZX sequence is forward only (as in the reference)");
     Pipeline &pl = p->pl;
     const int C = pl.C;
     char *I = static_cast<char *>(in), *W = static_cast<char *>(p->work_d), *O = static_cast<char *>(out);
@@ -877,6 +968,41 @@ static int enqueue_inverse_zyx(dfft_plan *p, void *out, void *in)
     return 0;
 }
 
+// Y_Then_ZX forward:  y: in -> A   [ex: A -> W0]   x: W0 -> W1   z: W1 -> A
+static int enqueue_forward_yzx(dfft_plan *p, void *out, const void *in)
+{
+    Pipeline &pl = p->pl;
+    const int C = pl.C, P = p->P1;
+    char *A = static_cast<char *>(out), *W = static_cast<char *>(p->work_d);
+    const char *I = static_cast<const char *>(in);
+    char *xsrc = P > 1 ? W : A;
+    char *xdst = P > 1 ? W + p->domainsize : W;
+    hipStream_t Sc = p->stream, Sm = pl.comm_stream;
+    p->nspans = 0; p->last_dir = DFFT_FORWARD;
+    if (p->comm && P > 1) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); }
+    for (int c = 0; c < C; c++) {
+        TRY(span_begin(p, 0, Sc));
+        TRY(launch(p, pl.fy[c], p->vfwd[1], 1, I, A, !p->c2c));
+        TRY(span_end(p, Sc));
+        if (P > 1) {
+            EV_RECORD(c, Sc);
+            EV_WAIT(c, Sm);
+            TRY(span_begin(p, 1, Sm));
+            TRY(exchange_tables(p, 2, pl.f2[c], true, A, xsrc, Sm));
+            TRY(span_end(p, Sm));
+            EV_RECORD(C + c, Sm);
+        }
+    }
+    if (P > 1) EV_WAIT(C + C - 1, Sc);
+    TRY(span_begin(p, 2, Sc));
+    TRY(launch(p, pl.fx, p->vfwd[2], 2, xsrc, xdst));
+    TRY(span_end(p, Sc));
+    TRY(span_begin(p, 4, Sc));
+    TRY(launch(p, pl.yz, 0, 0, xdst, A));
+    TRY(span_end(p, Sc));
+    return 0;
+}
+
 // partial transforms of the reference's MPIcuFFT_Pencil::execR2C/execC2R(out, in, d)
 // (src/pencil/mpicufft_pencil.cpp:1644-1839): d = 1 stops after the z pass with the natural
 // stage layout [xs][ys][Nzc]; d = 2 stops after the y pass with [xs][Ny][zs] (z contiguous).
@@ -983,7 +1109,7 @@ int dfft_plan_create(dfft_plan **plan, int kind, int precision, const dfft_confi
                      int rank, int max_world_size)
 {
     if (!plan) return fail(ERR_ARG, "null plan pointer");
-    if (kind < DFFT_SLAB || kind > DFFT_SLAB_Z_THEN_YX_OPT1) return fail(ERR_ARG, "unknown plan kind");
+    if (kind < DFFT_SLAB || kind > DFFT_SLAB_Y_THEN_ZX) return fail(ERR_ARG, "unknown plan kind");
     if (precision != DFFT_F32 && precision != DFFT_F64) return fail(ERR_ARG, "unknown precision");
     dfft_plan *p = new dfft_plan;
     p->kind = kind; p->prec = precision;
@@ -1023,7 +1149,8 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
     if (!Nx || !Ny || !Nz) return fail(ERR_ARG, "GlobalSize not initialized!");
     if (P1 < 1 || P2 < 1 || P1 * P2 != p->nranks) return fail(ERR_ARG, "Invalid Input Partition!");
     const bool zyx_kind = p->kind == DFFT_SLAB_Z_THEN_YX || p->kind == DFFT_SLAB_Z_THEN_YX_OPT1;
-    if ((p->kind == DFFT_SLAB || p->kind == DFFT_SLAB_OPT1 || zyx_kind) && P2 != 1)
+    const bool yzx = p->kind == DFFT_SLAB_Y_THEN_ZX;
+    if ((p->kind == DFFT_SLAB || p->kind == DFFT_SLAB_OPT1 || zyx_kind || yzx) && P2 != 1)
         return fail(ERR_ARG, "slab decomposition needs P2 == 1");
     // one rank: every class is the same local 3-D transform (fft3d branch, mpicufft_slab_z_then_yx.cpp:118-122)
     const bool zyx = zyx_kind && P1 > 1;
@@ -1032,28 +1159,35 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
     // axis plans: native power-of-two chain (2..2048) or Bluestein (any length with 2N-1 <= 2048)
     {
         Axis az, ay, axx;
-        const bool zr_native = !c2c && is_pow2(Nz) && Nz >= 4 && Nz <= 2048;
+        const bool zr_native = !yzx && !c2c && is_pow2(Nz) && Nz >= 4 && Nz <= 2048;
         const size_t zlen = zr_native ? Nz / 2 : Nz;
-        if (!axis_plan(p->prec, zlen, az) || !axis_plan(p->prec, Ny, ay) || !axis_plan(p->prec, Nx, axx))
-            return fail(ERR_UNSUPPORTED, "unsupported axis length (powers of two up to 2048, any other length up to 1024)");
+        // Y_Then_ZX, R2C: the y pass reads real lines in place, which only the Bluestein kernel does
+        const bool yok = yzx && !c2c ? axis_plan_bluestein(p->prec, Ny, ay) : axis_plan(p->prec, Ny, ay);
+        if (!axis_plan(p->prec, zlen, az) || !yok || !axis_plan(p->prec, Nx, axx))
+            return fail(ERR_UNSUPPORTED, yzx && !c2c && Ny > 1024 ? "unsupported axis length (Y_Then_ZX R2C: Ny up to 1024)"
+                        : "unsupported axis length (powers of two up to 2048, any other length up to 1024)");
         for (auto &a : p->ax) axis_free(a);
         p->ax[0] = az; p->ax[1] = ay; p->ax[2] = axx;
         p->zreal_native = zr_native;
     }
     p->Nx = Nx; p->Ny = Ny; p->Nz = Nz; p->c2c = c2c != 0;
-    p->Nzc = c2c ? Nz : Nz / 2 + 1;
+    p->Nzc = (c2c || yzx) ? Nz : Nz / 2 + 1;
+    p->Nyc = (yzx && !c2c) ? Ny / 2 + 1 : Ny;      // Hermitian axis y (mpicufft_slab_y_then_zx.cpp:96-104)
     if ((size_t)P2 > p->Nzc || (zyx && (size_t)P1 > p->Nzc)) return fail(ERR_ARG, "partition larger than the grid");
-    p->zyx = zyx;
+    p->zyx = zyx; p->yzx = yzx;
+    if (yzx && (size_t)P1 > p->Nyc) return fail(ERR_ARG, "partition larger than the grid");
     p->P1 = P1; p->P2 = P2;
     p->pi = p->rank / P2; p->pj = p->rank % P2;       // pidx = pidx_i * P2 + pidx_j (:67-68)
     split(Nx, P1, p->xs, p->xstart);
     split(Ny, P2, p->ys, p->ystart);
     // Z_Then_YX: the output is split along z over all ranks (mpicufft_slab_z_then_yx.cpp:96-103)
     split(p->Nzc, zyx ? P1 : P2, p->zs, p->zstart);
-    split(Ny, P1, p->yo, p->yostart);
+    split(p->Nyc, P1, p->yo, p->yostart);
     const size_t xs = p->xs[p->pi], ys = p->ys[p->pj], zs = p->zs[zyx ? p->pi : p->pj], yo = p->yo[p->pi];
     // domainsize = largest stage (:203-209)
-    p->domain_elems = zyx ? std::max(xs * Ny * p->Nzc, Nx * Ny * zs) : std::max({xs * ys * p->Nzc, xs * Ny * zs, Nx * yo * zs});
+    p->domain_elems = zyx ? std::max(xs * Ny * p->Nzc, Nx * Ny * zs)
+                      : yzx ? std::max(xs * p->Nyc * Nz, Nx * yo * Nz)
+                            : std::max({xs * ys * p->Nzc, xs * Ny * zs, Nx * yo * zs});
     p->domainsize = p->domain_elems * p->esz;
     p->domainsize = (p->domainsize + 255) & ~(size_t)255;
     const int nexch = (P1 > 1) + (P2 > 1);
@@ -1096,7 +1230,7 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         if (C < 1) C = 1;
         p->pl.C = C;
     }
-    TRY(zyx ? build_pipeline_zyx(p, p->pl) : build_pipeline(p, p->pl));
+    TRY(zyx ? build_pipeline_zyx(p, p->pl) : yzx ? build_pipeline_yzx(p, p->pl) : build_pipeline(p, p->pl));
     // the inverse x pass reads the point-major API layout: use the strided-read configuration
     // (variant 1) where one exists for this length
     {
@@ -1152,7 +1286,7 @@ static int upload_tables(dfft_plan *p)
     Pipeline &pl = p->pl;
     std::vector<Launch *> all;
     for (auto *v : {&pl.fz, &pl.fy, &pl.ix, &pl.iy, &pl.iz, &pl.py2, &pl.qy2, &pl.zy, &pl.ziy}) for (auto &L : *v) all.push_back(&L);
-    all.push_back(&pl.fx); all.push_back(&pl.pz1); all.push_back(&pl.qz1); all.push_back(&pl.zix);
+    all.push_back(&pl.fx); all.push_back(&pl.pz1); all.push_back(&pl.qz1); all.push_back(&pl.zix); all.push_back(&pl.yz);
     std::vector<char> host(all.size() * 2 * sizeof(SegTable));
     size_t off = 0;
     for (Launch *L : all) {
@@ -1239,7 +1373,7 @@ int dfft_exec_dim(dfft_plan *p, void *out, void *in, int direction, int d)
     if (!out || !in) return fail(ERR_ARG, "null buffer");
     if (d < 1 || d > 3) return fail(ERR_ARG, "d must be 1, 2 or 3");
     if (direction != DFFT_FORWARD && direction != DFFT_INVERSE) return fail(ERR_ARG, "bad direction");
-    if (p->zyx && d != 3) return fail(ERR_UNSUPPORTED, "partial transforms are not defined for the Z_Then_YX sequence");
+    if ((p->zyx || p->yzx) && d != 3) return fail(ERR_UNSUPPORTED, "partial transforms are not defined for the Z_Then_YX / Y_Then_ZX sequences");
     if (d == 3) TRY(direction == DFFT_FORWARD ? enqueue_forward(p, out, in) : enqueue_inverse(p, out, in));
     else TRY(direction == DFFT_FORWARD ? enqueue_partial_forward(p, out, in, d) : enqueue_partial_inverse(p, out, in, d));
     HIP_TRY(hipStreamSynchronize(p->stream));

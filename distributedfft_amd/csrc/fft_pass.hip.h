@@ -464,7 +464,10 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
     constexpr int S = E / RL;
     // register c = i + mr*S holds output k = t2 + NT*i + brev(mr)*(N/RL)
     if (A.store_kind == STORE_LINES) {
-        C *p = out + ((uint64_t)a2 * A.LB + (uint64_t)b2 * TL + l2) * N + t2;
+        // natural lines, or (KS_out != 0) rows at a*AS_out + line*KS_out: the z pass of the Y_Then_ZX sequence
+        const uint64_t row = A.KS_out ? (uint64_t)a2 * A.AS_out + ((uint64_t)b2 * TL + l2) * A.KS_out
+                                      : ((uint64_t)a2 * A.LB + (uint64_t)b2 * TL + l2) * N;
+        C *p = out + row + t2;
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
@@ -689,7 +692,9 @@ __device__ __forceinline__ uint64_t generic_load_offset(const PassArgs &A, const
 template <int TL>
 __device__ __forceinline__ uint64_t generic_store_offset(const PassArgs &A, const TileCtx<TL> &c, uint32_t k, uint32_t NP)
 {
-    if (A.store_kind == STORE_LINES) return ((uint64_t)c.a * A.LB + (uint64_t)c.b * TL + c.l) * NP + k;
+    if (A.store_kind == STORE_LINES)
+        return (A.KS_out ? (uint64_t)c.a * A.AS_out + ((uint64_t)c.b * TL + c.l) * A.KS_out
+                         : ((uint64_t)c.a * A.LB + (uint64_t)c.b * TL + c.l) * NP) + k;
     if (A.store_kind == STORE_KMAJOR) return (uint64_t)k * A.KS_out + (uint64_t)c.a * A.AS_out + (uint64_t)c.b * TL + c.l;
     if (A.store_kind == STORE_TILED_TRANSPOSE) return tiled_transpose_store_offset<TL>(A, c, k);
     uint32_t s0 = A.sseg->start[0], ln = A.sseg->len[0];

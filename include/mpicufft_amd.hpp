@@ -200,6 +200,17 @@ template <typename T> struct MPIcuFFT_Slab_Z_Then_YX_Opt1 : MPIcuFFT_Slab_Z_Then
     MPIcuFFT_Slab_Z_Then_YX_Opt1(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1)
         : MPIcuFFT_Slab_Z_Then_YX<T>(c, comm, max_world_size, DFFT_SLAB_Z_THEN_YX_OPT1) {}
 };
+// forward-only sequence with the Hermitian axis in y (include/mpicufft_slab_y_then_zx.hpp): output [Nx][(Ny/2+1)/P][Nz]
+template <typename T> struct MPIcuFFT_Slab_Y_Then_ZX : MPIcuFFT<T> {
+    MPIcuFFT_Slab_Y_Then_ZX(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1)
+        : MPIcuFFT<T>(c, comm, max_world_size, DFFT_SLAB_Y_THEN_ZX) {}
+    using MPIcuFFT<T>::initFFT;
+    void initFFT(GlobalSize *g, bool allocate = true)     // include/mpicufft_slab_y_then_zx.hpp:34-35
+    {
+        Slab_Partition p(this->getWorldSize());
+        MPIcuFFT<T>::initFFT(g, &p, allocate);
+    }
+};
 // partial transforms execR2C/execC2R(out, in, d), include/mpicufft_pencil.hpp:101-111
 template <typename T> struct MPIcuFFT_PencilBase : MPIcuFFT<T> {
     using MPIcuFFT<T>::MPIcuFFT;

@@ -203,3 +203,42 @@ def test_z_then_yx_plan_algebra_and_tables(shape, P, c2c, chunks):
     one = dfft.MPIcuFFT_Slab_Z_Then_YX(dfft.Configurations(), precision="double")
     one.initFFT(dfft.GlobalSize(*shape), dfft.Slab_Partition(1), allocate=False, c2c=c2c)
     assert list(one.getOutSize()) == [Nx, Ny, Nzc]
+
+
+@pytest.mark.parametrize("shape,P,c2c", [((16, 8, 16), 2, False), ((30, 20, 18), 3, False), ((64, 16, 32), 8, True),
+                                         ((1024, 1024, 1024), 8, False)])
+def test_y_then_zx_plan_algebra_and_tables(shape, P, c2c):
+    """slab sequence Y_Then_ZX: Hermitian axis y, output [Nx][(Ny/2+1)/P][Nz]
+    (mpicufft_slab_y_then_zx.cpp:84-108, hpp:40-43), exchange counts (:309-319)"""
+    Nx, Ny, Nz = shape
+    Nyc = Ny if c2c else Ny // 2 + 1
+    esz = 16
+    world = dfft.Comm.local(P)
+    plans = []
+    for r in range(P):
+        pl = dfft.MPIcuFFT_Slab_Y_Then_ZX(dfft.Configurations(), world, precision="double", rank=r)
+        pl.initFFT(dfft.GlobalSize(*shape), dfft.Slab_Partition(P), allocate=False, c2c=c2c)
+        plans.append(pl)
+
+    def split(n):
+        return [n // P + (1 if q < n % P else 0) for q in range(P)]
+
+    xs, yo = split(Nx), split(Nyc)
+    C = plans[0].getPipelineChunks()
+    for r, pl in enumerate(plans):
+        assert list(pl.getInSize()) == [xs[r], Ny, Nz] and list(pl.getInStart()) == [sum(xs[:r]), 0, 0]
+        assert list(pl.getOutSize()) == [Nx, yo[r], Nz] and list(pl.getOutStart()) == [0, sum(yo[:r]), 0]
+        assert pl.getDomainSize() >= esz * max(xs[r] * Nyc * Nz, Nx * yo[r] * Nz)
+        sc, sd, rc, rd = pl.getExchangeTables(2)
+        assert sc == [esz * Nz * yo[q] * xs[r] for q in range(P)] and rd == [esz * Nz * yo[r] * sum(xs[:q]) for q in range(P)]
+        tot_s, tot_r = [0] * P, [0] * P
+        for c in range(C):
+            tsc, tsd, trc, trd = pl.getPipelineTables(dfft.FORWARD, 2, c)
+            for q in range(P):
+                psc, _, prc, _ = plans[q].getPipelineTables(dfft.FORWARD, 2, c)
+                assert tsc[q] == prc[r] and trc[q] == psc[r]
+                tot_s[q] += tsc[q]
+                tot_r[q] += trc[q]
+        assert tot_s == sc and tot_r == rc
+        with pytest.raises(dfft.DfftError):
+            pl.getPipelineTables(dfft.INVERSE, 2, 0)

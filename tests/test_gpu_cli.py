@@ -59,5 +59,9 @@ def test_slab_sequence_z_then_yx_testcases(tmp_path):
     assert os.path.basename(r["csv"]) == "test_1_1_0_32_16_64_0_3.csv" and os.path.dirname(r["csv"]).endswith("slab_z_then_yx")
     r = cli.run(["slab", "-nx", "32", "-ny", "32", "-nz", "32", "-p", "4", "-s", "Z_Then_YX", "-t", "4", "-d", "-b", str(tmp_path)])
     assert r["max"] < 1e-9 * math.sqrt(32.0 ** 3) * 3
+    # Y_Then_ZX: forward only (testcases 0, 1)
+    assert cli.run(base + ["-s", "Y_Then_ZX", "-t", "1"])["sum"] < 1e-6
+    r = cli.run(base + ["-s", "Y_Then_ZX", "-t", "0", "-i", "2"])
+    assert os.path.dirname(r["csv"]).endswith("slab_y_then_zx")
     with pytest.raises(SystemExit):
-        cli.run(base + ["-s", "Y_Then_ZX"])
+        cli.run(base + ["-s", "Y_Then_ZX", "-t", "3"])

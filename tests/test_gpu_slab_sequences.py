@@ -154,3 +154,86 @@ def test_z_then_yx_errors_and_single_rank():
     plans, ins, spec, backs = run(dfft.MPIcuFFT_Slab_Z_Then_YX, (16, 8, 32), 1, "double", False)
     want = orc.fft3d_r2c(global_input((16, 8, 32), False, "double"))
     assert np.max(np.abs(spec[0] - want)) / np.max(np.abs(want)) < 1e-11
+
+
+# ------------------------------------------------------------------------------------------
+# Y_Then_ZX (src/slab/y_then_zx/): R2C along y, output [Nx][(Ny/2+1)/P][Nz], forward only
+# ------------------------------------------------------------------------------------------
+def run_yzx(shape, P, prec, c2c, chunks=None, seed=33):
+    world = dfft.Comm.local(P) if P > 1 else None
+    esz = 16 if prec == "double" else 8
+    plans, ins, outs, host_ins = [], [], [], []
+    for r in range(P):
+        pl = dfft.MPIcuFFT_Slab_Y_Then_ZX(dfft.Configurations(), world, precision=prec, rank=r)
+        if chunks is not None:
+            pl.setPipelineChunks(chunks)
+        pl.initFFT(dfft.GlobalSize(*shape), dfft.Slab_Partition(P), True, c2c=c2c)
+        size, start = pl.getInSize(), pl.getInStart()
+        blk = orc.fill_block(shape, start, size, 2 if c2c else 1, seed=seed).astype(NPC[prec] if c2c else NPR[prec])
+        plans.append(pl)
+        host_ins.append(blk)
+        ins.append(torch.from_numpy(blk).cuda())
+        outs.append(torch.zeros(pl.getDomainSize() // esz, dtype=CDT[prec], device="cuda"))
+    torch.cuda.synchronize()
+    fwd = (lambda r: plans[r].execC2C(outs[r], ins[r], dfft.FORWARD)) if c2c else (lambda r: plans[r].execR2C(outs[r], ins[r]))
+    with ThreadPoolExecutor(P) as ex:
+        list(ex.map(fwd, range(P)))
+    torch.cuda.synchronize()
+    spec = []
+    for r in range(P):
+        s = plans[r].getOutSize()
+        spec.append(outs[r][:s[0] * s[1] * s[2]].cpu().numpy().reshape(s))
+        assert np.array_equal(ins[r].cpu().numpy(), host_ins[r])
+    return plans, spec
+
+
+@pytest.mark.parametrize("prec", ["double", "float"])
+@pytest.mark.parametrize("c2c", [False, True])
+@pytest.mark.parametrize("shape,P", [((16, 16, 16), 1), ((16, 16, 16), 2), ((32, 16, 64), 3), ((64, 32, 16), 8),
+                                     ((33, 20, 18), 4), ((24, 10, 20), 4), ((128, 64, 32), 5), ((8, 6, 4), 2)])
+def test_y_then_zx_vs_oracle(shape, P, c2c, prec):
+    plans, spec = run_yzx(shape, P, prec, c2c)
+    g = global_input(shape, c2c, prec, seed=33)
+    want = orc.fft3d_c2c(np.ascontiguousarray(g.astype(np.complex128)), -1)
+    Nyc = shape[1] if c2c else shape[1] // 2 + 1
+    want = want[:, :Nyc, :]
+    scale = np.max(np.abs(want))
+    cover = np.zeros(Nyc, dtype=int)
+    for r, pl in enumerate(plans):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        assert (s[0], s[2]) == (shape[0], shape[2]) and (o[0], o[2]) == (0, 0)
+        cover[o[1]:o[1] + s[1]] += 1
+        assert np.max(np.abs(spec[r] - want[:, o[1]:o[1] + s[1], :])) / scale < TOL_FWD[prec]
+    assert np.all(cover == 1)
+
+
+@pytest.mark.parametrize("chunks", [1, 2, 5])
+def test_y_then_zx_pipeline_depths_tables_and_errors(chunks):
+    shape, P = (32, 16, 64), 3
+    plans, spec = run_yzx(shape, P, "double", False, chunks=chunks)
+    Nx, Ny, Nz = shape
+    want = orc.fft3d_c2c(np.ascontiguousarray(global_input(shape, False, "double", seed=33).astype(np.complex128)), -1)[:, :Ny // 2 + 1, :]
+    xs = [Nx // P + (1 if q < Nx % P else 0) for q in range(P)]
+    yo = [(Ny // 2 + 1) // P + (1 if q < (Ny // 2 + 1) % P else 0) for q in range(P)]
+    for r, pl in enumerate(plans):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        assert np.max(np.abs(spec[r] - want[:, o[1]:o[1] + s[1], :])) / np.max(np.abs(want)) < 1e-11
+        # byte counts of mpicufft_slab_y_then_zx.cpp:309-319
+        sc, sd, rc, rd = pl.getExchangeTables(2)
+        assert sc == [16 * Nz * yo[q] * xs[r] for q in range(P)] and rc == [16 * Nz * yo[r] * xs[q] for q in range(P)]
+        assert sd == [16 * Nz * sum(yo[:q]) * xs[r] for q in range(P)] and rd == [16 * Nz * yo[r] * sum(xs[:q]) for q in range(P)]
+    with pytest.raises(dfft.DfftError, match="forward only"):
+        plans[0].execC2R(1, 1)
+    one = dfft.MPIcuFFT_Slab_Y_Then_ZX(dfft.Configurations())
+    with pytest.raises(dfft.DfftError, match="Ny up to 1024"):
+        one.initFFT(dfft.GlobalSize(16, 2048, 16), dfft.Slab_Partition(1), True)
+
+
+def test_y_then_zx_256_cube_four_ranks_every_point():
+    shape, P = (256, 256, 256), 4
+    plans, spec = run_yzx(shape, P, "double", False)
+    want = orc.fft3d_c2c(np.ascontiguousarray(global_input(shape, False, "double", seed=33).astype(np.complex128)), -1)[:, :129, :]
+    scale = np.max(np.abs(want))
+    for r, pl in enumerate(plans):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        assert np.max(np.abs(spec[r] - want[:, o[1]:o[1] + s[1], :])) / scale < 1e-11
