@@ -10,13 +10,20 @@ pidx = pidx_i*P2 + pidx_j, src/pencil/mpicufft_pencil_opt1.cpp:67-68):
                transport.  Buffers the library exchanges must be registered so raw pointers
                can be mapped back to tensors.
   * "auto"  -- rccl if it can be created and passes a small round-trip self-test on every
-               rank, otherwise torch.
+               rank, otherwise torch.  With more than one rank the native transport is first
+               tried in a short-lived child process per rank (`_probe_native`), so that a hang
+               inside a collective -- which no exception handler can catch -- costs a timeout
+               instead of the job.
 
 Stream contract: the plan must run on torch's *current* stream while the callback executes, i.e.
 create `side = torch.cuda.Stream()`, `plan.setStream(side.cuda_stream)` and call exec inside
 `with torch.cuda.stream(side):`.  (Launching on the legacy null stream next to torch's default
 stream was observed to race with gloo's staging copies on ROCm; a dedicated stream is exact.)
 """
+import os
+import subprocess
+import sys
+
 import torch
 
 from . import api
@@ -105,7 +112,57 @@ def _selftest(dist, comm, rank, world, P1, P2):
     return float(err.item())
 
 
-def make_comm(dist, rank, world, P1, P2, mode="auto"):
+_PROBED = {}
+
+
+def _probe_native(P1, P2, timeout=None, cmd=None):
+    """Create the native RCCL transport and run its self-test in a child process that joins the
+    other ranks' children on its own rendezvous port.  Returns True only if the child exits
+    cleanly within `timeout` seconds; a child that hangs is killed (by pid)."""
+    timeout = float(os.environ.get("DFFT_PROBE_TIMEOUT", "150")) if timeout is None else timeout
+    env = dict(os.environ)
+    port = int(env.get("MASTER_PORT", "29500"))
+    env["MASTER_PORT"] = str(port + 23 if port + 23 < 65536 else port - 23)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    if cmd is None:
+        cmd = [sys.executable, "-m", "distributedfft_amd.torch_transport", "--probe", str(P1), str(P2)]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    try:
+        _, err = child.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        child.kill()
+        child.communicate()
+        print(f"[rank {env.get('RANK', '0')}] native RCCL probe did not finish in {timeout:.0f} s", flush=True)
+        return False
+    if child.returncode != 0:
+        tail = err.decode(errors="replace").strip().splitlines()[-1:] if err else []
+        print(f"[rank {env.get('RANK', '0')}] native RCCL probe failed (rc {child.returncode}) {' '.join(tail)}", flush=True)
+    return child.returncode == 0
+
+
+def _probe_main(argv):
+    """child side of _probe_native: its own process group, the native transport, the self-test"""
+    import torch.distributed as dist
+    P1, P2 = int(argv[0]), int(argv[1])
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    make_comm(dist, rank, world, P1, P2, mode="rccl", probe=False)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
+def make_comm(dist, rank, world, P1, P2, mode="auto", probe=None):
+    if mode == "auto" and (probe if probe is not None else (world > 1 and os.environ.get("DFFT_TRANSPORT_PROBE", "1") != "0")):
+        if world not in _PROBED:      # once per process: later plans (other grids) reuse the verdict
+            fine = torch.tensor([1.0 if _probe_native(P1, P2) else 0.0], device="cuda")
+            dist.all_reduce(fine, op=dist.ReduceOp.MIN)
+            _PROBED[world] = fine.item() > 0
+        if not _PROBED[world]:
+            mode = "torch"
     if mode in ("auto", "rccl"):
         ok = torch.ones(1, device="cuda")
         comm = None
@@ -135,3 +192,9 @@ def make_comm(dist, rank, world, P1, P2, mode="auto"):
                 raise RuntimeError(f"native RCCL transport failed its self-test: round trip {err}")
     tc = TorchComm(dist, rank, world, P1, P2)
     return tc, "torch"
+
+
+if __name__ == "__main__":
+    if len(sys.argv) >= 4 and sys.argv[1] == "--probe":
+        sys.exit(_probe_main(sys.argv[2:]))
+    sys.exit("usage: python -m distributedfft_amd.torch_transport --probe P1 P2")

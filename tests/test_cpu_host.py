@@ -242,3 +242,16 @@ def test_y_then_zx_plan_algebra_and_tables(shape, P, c2c):
         assert tot_s == sc and tot_r == rc
         with pytest.raises(dfft.DfftError):
             pl.getPipelineTables(dfft.INVERSE, 2, 0)
+
+
+def test_transport_probe_failure_paths_without_a_gpu():
+    """the child-process probe of the native RCCL transport: a hang is cut off by the timeout, an
+    error is reported as failure (here: no GPU), and only a clean exit counts as success"""
+    import sys as _sys
+
+    from distributedfft_amd import torch_transport as tt
+    assert tt._probe_native(1, 1, timeout=1, cmd=[_sys.executable, "-c", "import time; time.sleep(30)"]) is False
+    assert tt._probe_native(1, 1, timeout=60, cmd=[_sys.executable, "-c", "raise SystemExit(0)"]) is True
+    import torch
+    if not torch.cuda.is_available():
+        assert tt._probe_native(1, 1, timeout=120) is False
