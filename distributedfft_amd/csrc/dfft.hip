@@ -281,6 +281,16 @@ struct dfft_plan {
 // chunk instead of whole-peer granularity.  C = 1 reproduces the reference's message sizes and
 // displacements exactly (mpicufft_pencil_opt1.cpp:269-273, 315-319).
 // ------------------------------------------------------------------------------------------
+// descriptor of one axis pass over `na` outer slices of `LB` lines each (tiles of TL lines)
+static PassArgs pass_args(int TL, size_t na, size_t LB, int load_kind, int store_kind, int swap)
+{
+    PassArgs A;
+    memset(&A, 0, sizeof(A));
+    A.na = (uint32_t)na; A.LB = (uint32_t)LB; A.nb = (uint32_t)((LB + TL - 1) / TL); A.ntiles = A.na * A.nb;
+    A.load_kind = load_kind; A.store_kind = store_kind; A.swap = swap; A.T2shift = ilog2(TL);
+    return A;
+}
+
 static void seg_push(SegTable &t, size_t start, size_t len, size_t base_elems)
 {
     int s = t.nseg++;
@@ -292,18 +302,11 @@ static void seg_push(SegTable &t, size_t start, size_t len, size_t base_elems)
 static int build_pipeline(dfft_plan *p, Pipeline &pl)
 {
     const int TL = p->TL, P1 = p->P1, P2 = p->P2, C = pl.C;
-    const uint32_t T2shift = ilog2(TL);
     const size_t xs = p->xs[p->pi], ys = p->ys[p->pj], zs = p->zs[p->pj], yo = p->yo[p->pi];
     const size_t Nx = p->Nx, Ny = p->Ny, Nzc = p->Nzc, e = p->esz;
     // bytes per input/output LINE of the z pass as the caller sees it (real lines in R2C mode)
     const size_t zline_bytes = p->c2c ? p->Nz * e : p->Nz * (e / 2);
-    auto base = [&](size_t na, size_t LB, int lk, int sk, int swap) {
-        PassArgs A;
-        memset(&A, 0, sizeof(A));
-        A.na = (uint32_t)na; A.LB = (uint32_t)LB; A.nb = (uint32_t)((LB + TL - 1) / TL); A.ntiles = A.na * A.nb;
-        A.load_kind = lk; A.store_kind = sk; A.swap = swap; A.T2shift = T2shift;
-        return A;
-    };
+    auto base = [&](size_t na, size_t LB, int lk, int sk, int swap) { return pass_args(TL, na, LB, lk, sk, swap); };
     std::vector<size_t> xl, x0, kl, k0;
     split(xs, C, xl, x0);       // my x range in chunks (forward z/y, inverse y/z passes)
     split(yo, C, kl, k0);       // my ky range in chunks (inverse x pass)
@@ -473,17 +476,10 @@ static int build_pipeline(dfft_plan *p, Pipeline &pl)
 static int build_pipeline_zyx(dfft_plan *p, Pipeline &pl)
 {
     const int TL = p->TL, P = p->P1, C = pl.C, r = p->pi;
-    const uint32_t T2shift = ilog2(TL);
     const size_t xs = p->xs[r], zs = p->zs[r];
     const size_t Ny = p->Ny, Nzc = p->Nzc, e = p->esz;
     const size_t zline_bytes = p->c2c ? p->Nz * e : p->Nz * (e / 2);
-    auto base = [&](size_t na, size_t LB, int lk, int sk, int swap) {
-        PassArgs A;
-        memset(&A, 0, sizeof(A));
-        A.na = (uint32_t)na; A.LB = (uint32_t)LB; A.nb = (uint32_t)((LB + TL - 1) / TL); A.ntiles = A.na * A.nb;
-        A.load_kind = lk; A.store_kind = sk; A.swap = swap; A.T2shift = T2shift;
-        return A;
-    };
+    auto base = [&](size_t na, size_t LB, int lk, int sk, int swap) { return pass_args(TL, na, LB, lk, sk, swap); };
     std::vector<size_t> xl, x0;
     split(xs, C, xl, x0);
     std::vector<std::vector<size_t>> xlq(P), x0q(P);
@@ -584,16 +580,9 @@ static int build_pipeline_zyx(dfft_plan *p, Pipeline &pl)
 static int build_pipeline_yzx(dfft_plan *p, Pipeline &pl)
 {
     const int TL = p->TL, P = p->P1, C = pl.C, r = p->pi;
-    const uint32_t T2shift = ilog2(TL);
     const size_t xs = p->xs[r], yo = p->yo[r];
     const size_t Nx = p->Nx, Ny = p->Ny, Nz = p->Nz, e = p->esz;
-    auto base = [&](size_t na, size_t LB, int lk, int sk) {
-        PassArgs A;
-        memset(&A, 0, sizeof(A));
-        A.na = (uint32_t)na; A.LB = (uint32_t)LB; A.nb = (uint32_t)((LB + TL - 1) / TL); A.ntiles = A.na * A.nb;
-        A.load_kind = lk; A.store_kind = sk; A.T2shift = T2shift;
-        return A;
-    };
+    auto base = [&](size_t na, size_t LB, int lk, int sk) { return pass_args(TL, na, LB, lk, sk, 0); };
     std::vector<size_t> xl, x0;
     split(xs, C, xl, x0);
     std::vector<std::vector<size_t>> xlq(P), x0q(P);

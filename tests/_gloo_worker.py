@@ -21,11 +21,73 @@ from distributedfft_amd.torch_transport import TorchComm  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 
+def sequence_main(seq, rank, world, shape):
+    """Z_Then_YX / Y_Then_ZX with the reference's opt0 buffer layouts (src/slab/z_then_yx/
+    mpicufft_slab_z_then_yx.cpp:190-196, src/slab/y_then_zx/mpicufft_slab_y_then_zx.cpp:309-319):
+    oracle 1-D FFTs, the product's plan tables and exchange over gloo"""
+    P = world
+    tc = TorchComm(dist, rank, world, P, 1)
+    cls = dfft.MPIcuFFT_Slab_Z_Then_YX if seq == "zyx" else dfft.MPIcuFFT_Slab_Y_Then_ZX
+    plan = cls(dfft.Configurations(), tc, precision="double", rank=rank)
+    plan.initFFT(dfft.GlobalSize(*shape), dfft.Slab_Partition(P), allocate=False, c2c=True)
+    Nx, Ny, Nz = shape
+    isz, ist, osz, ost = plan.getInSize(), plan.getInStart(), plan.getOutSize(), plan.getOutStart()
+    xs = isz[0]
+    nel = plan.getDomainSize() // 16
+    A, B = torch.zeros(nel, dtype=torch.complex128), torch.zeros(nel, dtype=torch.complex128)
+    tc.register(A)
+    tc.register(B)
+    a, b = A.numpy(), B.numpy()
+    blk = orc.fill_block(shape, ist, isz, 2, seed=21)
+    sc, sd, rc, rd = plan.getExchangeTables(2)
+    if seq == "zyx":
+        first = orc.fft1d(blk.reshape(xs * Ny, Nz), -1).reshape(xs, Ny, Nz)                 # z pass
+        cut = [sum(v // (16 * Ny * xs) for v in sc[:q]) for q in range(P + 1)]              # z split
+        for q in range(P):      # pack [xs][Ny][zs[q]]
+            a[sd[q] // 16: (sd[q] + sc[q]) // 16] = first[:, :, cut[q]:cut[q + 1]].ravel()
+    else:
+        first = orc.fft1d(np.ascontiguousarray(blk.transpose(0, 2, 1)).reshape(xs * Nz, Ny), -1).reshape(xs, Nz, Ny).transpose(0, 2, 1)   # y pass
+        cut = [sum(v // (16 * Nz * xs) for v in sc[:q]) for q in range(P + 1)]              # y split
+        for q in range(P):      # pack [xs][yo[q]][Nz]
+            a[sd[q] // 16: (sd[q] + sc[q]) // 16] = first[:, cut[q]:cut[q + 1], :].ravel()
+    send_copy = a.copy()
+    plan.exchange(2, dfft.FORWARD, A, B)
+    # the received blocks stack along x: [Nx][Ny][zs] resp. [Nx][yo][Nz]
+    mid = np.zeros(osz, dtype=np.complex128)
+    x0 = 0
+    for q in range(P):
+        n = rc[q] // 16
+        xq = n // (osz[1] * osz[2])
+        mid[x0:x0 + xq] = b[rd[q] // 16: rd[q] // 16 + n].reshape(xq, osz[1], osz[2])
+        x0 += xq
+    assert x0 == Nx
+    A.zero_()
+    plan.exchange(2, dfft.INVERSE, B, A)
+    assert np.array_equal(a, send_copy), "the inverse exchange is not the mirror"
+    other = 1 if seq == "zyx" else 2       # remaining axes: (y, x) resp. (z, x)
+    t = np.moveaxis(mid, other, -1)
+    t = orc.fft1d(np.ascontiguousarray(t).reshape(-1, shape[other]), -1).reshape(t.shape)
+    mid = np.moveaxis(t, -1, other)
+    t = np.moveaxis(mid, 0, -1)
+    t = orc.fft1d(np.ascontiguousarray(t).reshape(-1, Nx), -1).reshape(t.shape)
+    got = np.moveaxis(t, -1, 0)
+    want = np.fft.fftn(orc.fill_block(shape, (0, 0, 0), shape, 2, seed=21))
+    want = want[:, ost[1]:ost[1] + osz[1], ost[2]:ost[2] + osz[2]]
+    err = np.max(np.abs(got - want)) / np.max(np.abs(want))
+    assert err < 1e-12, err
+    assert tc.calls == 2
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank} ok err={err:.2e}")
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     P1, P2 = int(sys.argv[1]), int(sys.argv[2])
     shape = tuple(int(v) for v in sys.argv[3].split("x"))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if len(sys.argv) > 4:
+        return sequence_main(sys.argv[4], rank, world, shape)
     tc = TorchComm(dist, rank, world, P1, P2)
     plan = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), tc, precision="double", rank=rank)
     plan.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(P1, P2), allocate=False, c2c=True)

@@ -17,16 +17,17 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("P1,P2,shape", [(2, 1, "16x8x8"), (1, 2, "8x8x16"), (2, 2, "16x16x8"), (2, 2, "8x8x16"), (3, 2, "16x16x16"),
-                                         (3, 1, "16x16x8")])
-def test_gloo_exchange_path(P1, P2, shape):
+@pytest.mark.parametrize("P1,P2,shape,seq", [(2, 1, "16x8x8", ""), (1, 2, "8x8x16", ""), (2, 2, "16x16x8", ""), (2, 2, "8x8x16", ""),
+                                             (3, 2, "16x16x16", ""), (3, 1, "16x16x8", ""),
+                                             (2, 1, "16x8x8", "zyx"), (3, 1, "16x6x10", "zyx"), (2, 1, "8x8x16", "yzx"), (3, 1, "10x16x6", "yzx")])
+def test_gloo_exchange_path(P1, P2, shape, seq):
     world = P1 * P2
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_gloo_worker.py"), str(P1), str(P2), shape],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_gloo_worker.py"), str(P1), str(P2), shape] + ([seq] if seq else []),
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
