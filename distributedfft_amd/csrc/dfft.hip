@@ -205,6 +205,7 @@ struct Launch {
     PassArgs args;            // in/out/tw and the device table pointers are filled at enqueue time
     SegTable lseg{}, sseg{};  // host copies of the segment tables (uploaded by upload_tables)
     size_t ltab = 0, stab = 0;   // byte offsets of the tables in the plan's device table buffer
+    size_t lent = SIZE_MAX, sent = SIZE_MAX;   // byte offsets of the per-point address tables (SIZE_MAX: none)
     size_t in_off = 0;        // byte offset added to the stage's input buffer
     size_t out_off = 0;       // byte offset added to the stage's output buffer
 };
@@ -638,6 +639,8 @@ static void fill_tables(dfft_plan *p, const Launch &L, PassArgs &A)
     A.lseg = reinterpret_cast<const SegTable *>(static_cast<const char *>(p->tables_d) + L.ltab);
     A.sseg = reinterpret_cast<const SegTable *>(static_cast<const char *>(p->tables_d) + L.stab);
     A.lnseg = L.lseg.nseg; A.snseg = L.sseg.nseg;
+    A.ltab = L.lent == SIZE_MAX ? nullptr : reinterpret_cast<const SegEntry *>(static_cast<const char *>(p->tables_d) + L.lent);
+    A.stab = L.sent == SIZE_MAX ? nullptr : reinterpret_cast<const SegEntry *>(static_cast<const char *>(p->tables_d) + L.sent);
 }
 
 // complex axis pass on axis `axis` (0 = z, 1 = y, 2 = x)
@@ -1270,9 +1273,41 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
     return 0;
 }
 
+// per-point address tables (SegEntry, fft_pass.hip.h) of a launch's segmented side
+static void point_table(const Launch &L, bool store, std::vector<SegEntry> &tab)
+{
+    const SegTable &T = store ? L.sseg : L.lseg;
+    const PassArgs &A = L.args;
+    size_t cover = 0;
+    for (int s = 0; s < T.nseg; s++) cover = std::max(cover, (size_t)T.start[s] + T.len[s]);
+    tab.assign(cover, SegEntry{0, 0, 0});
+    for (size_t n = 0; n < cover; n++) {
+        int s = 0;                      // same rule as the kernels: last segment whose start is <= n
+        for (int q = 1; q < T.nseg; q++) if (n >= T.start[q]) s = q;
+        const uint64_t d = n - T.start[s], ln = T.len[s];
+        SegEntry e;
+        e.ln = (uint32_t)ln;
+        if (!store) {
+            e.base = T.base[s]; e.aux = (uint32_t)d;
+        } else if (A.store_kind == STORE_TILED_SAME) {
+            e.base = T.base[s] + d * A.LB * A.LA; e.aux = 0;
+        } else {
+            const uint64_t T2 = 1ull << A.T2shift, kt = d >> A.T2shift, kr = d & (T2 - 1);
+            const uint64_t r2 = ln - kt * T2;
+            e.base = T.base[s] + kt * T2 * A.LB + kr;
+            e.aux = (uint32_t)std::min(r2, T2);
+        }
+        tab[n] = e;
+    }
+}
+
 static int upload_tables(dfft_plan *p)
 {
     Pipeline &pl = p->pl;
+    // DFFT_TABLES: 0 = search the segment table per point, 1 = per-point tables for launches with
+    // more than one segment (default), 2 = tables for every tiled load / store
+    int mode = 1;
+    if (const char *v = getenv("DFFT_TABLES")) mode = atoi(v);
     std::vector<Launch *> all;
     for (auto *v : {&pl.fz, &pl.fy, &pl.ix, &pl.iy, &pl.iz, &pl.py2, &pl.qy2, &pl.zy, &pl.ziy}) for (auto &L : *v) all.push_back(&L);
     all.push_back(&pl.fx); all.push_back(&pl.pz1); all.push_back(&pl.qz1); all.push_back(&pl.zix); all.push_back(&pl.yz);
@@ -1281,6 +1316,22 @@ static int upload_tables(dfft_plan *p)
     for (Launch *L : all) {
         L->ltab = off; memcpy(host.data() + off, &L->lseg, sizeof(SegTable)); off += sizeof(SegTable);
         L->stab = off; memcpy(host.data() + off, &L->sseg, sizeof(SegTable)); off += sizeof(SegTable);
+    }
+    std::vector<SegEntry> tab;
+    for (Launch *L : all) {
+        L->lent = L->sent = SIZE_MAX;
+        const bool tl = L->args.load_kind == LOAD_TILED && L->lseg.nseg >= 1;
+        const bool ts = (L->args.store_kind == STORE_TILED_SAME || L->args.store_kind == STORE_TILED_TRANSPOSE) && L->sseg.nseg >= 1;
+        for (int side = 0; side < 2; side++) {
+            const bool want = side == 0 ? tl : ts;
+            const int nseg = side == 0 ? L->lseg.nseg : L->sseg.nseg;
+            if (!want || mode == 0 || (mode == 1 && nseg < 2) || L->args.ntiles == 0) continue;
+            point_table(*L, side == 1, tab);
+            (side == 0 ? L->lent : L->sent) = host.size();
+            const size_t bytes = tab.size() * sizeof(SegEntry);
+            host.resize(host.size() + bytes);
+            memcpy(host.data() + host.size() - bytes, tab.data(), bytes);
+        }
     }
     if (p->tables_d) { (void)hipFree(p->tables_d); p->tables_d = nullptr; }
     HIP_TRY(hipMalloc(&p->tables_d, host.size()));

@@ -51,6 +51,18 @@ struct SegTable {
     uint64_t base[MAXSEG];    // element offset of the peer block in the buffer
 };
 
+// Per-point address table of a segmented (multi-peer) load or store, built by the host once per
+// launch descriptor: the segment search, the tile split and the tile widths are done ahead of time,
+// the kernel does one cached 16-byte load and two multiply-adds per point.
+//   tiled load, point n:          off = base + ln*(a*LB + b*TL) + aux*tw + l        (aux = n - start)
+//   transposed-tile store, k:     off = base + ln*(a*LB) + (b*TL + l)*aux           (aux = tw2; base holds bs + kt*T2*LB + kr)
+//   same-tile store, k:           off = base + b*TL*LA + a*tw + l                   (base holds bs + (k-start)*LB*LA)
+struct SegEntry {
+    uint64_t base;
+    uint32_t ln;
+    uint32_t aux;
+};
+
 struct PassArgs {
     const void *in;
     void *out;
@@ -79,6 +91,7 @@ struct PassArgs {
     // arguments would be copied to scratch
     const SegTable *lseg, *sseg;
     int32_t lnseg, snseg;
+    const SegEntry *ltab, *stab;   // per-point tables (null: search the segment table per point)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -354,6 +367,17 @@ __device__ __forceinline__ void transform(typename Cfg::C *v, typename Cfg::real
     transform<Cfg>(v, lds, W, t, lw, t, lw);
 }
 
+// one 16-byte load of a table entry (every lane of a wave reads nearby entries: L1 hits)
+__device__ __forceinline__ SegEntry seg_entry(const SegEntry *p)
+{
+    const uint4 r = *reinterpret_cast<const uint4 *>(p);
+    SegEntry e;
+    e.base = (uint64_t)r.x | ((uint64_t)r.y << 32);
+    e.ln = r.z;
+    e.aux = r.w;
+    return e;
+}
+
 // logical workgroup index: identity, or the XCD-aware remap of the guide (T1, bijective form)
 __device__ __forceinline__ uint32_t logical_block(const PassArgs &A)
 {
@@ -430,7 +454,14 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
             const C *p = in + (uint64_t)a * A.AS_in + (uint64_t)b * TL + l + (uint64_t)t * A.KS_in;
             static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = stream_load<Cfg>(p + (uint64_t)(NT * c) * A.KS_in); });
         } else {
-            if (A.lnseg == 1) {
+            if (A.ltab) {
+                const uint32_t Q = a * A.LB + b * TL;
+                static_for<0, E>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    const SegEntry e = seg_entry(A.ltab + (t + NT * c));
+                    v[c] = stream_load<Cfg>(in + e.base + (uint64_t)e.ln * Q + (uint64_t)e.aux * tw + l);
+                });
+            } else if (A.lnseg == 1) {
                 const uint64_t len = A.lseg->len[0];
                 const C *p = in + A.lseg->base[0] + (uint64_t)a * len * A.LB + (uint64_t)b * TL * len + l + (uint64_t)t * tw;
                 static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = stream_load<Cfg>(p + (uint64_t)(NT * c) * tw); });
@@ -480,6 +511,18 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
             stream_store<Cfg>(p + (uint64_t)k0 * A.KS_out, v[c]);
         });
+    } else if (A.stab) {
+        const bool same = A.store_kind == STORE_TILED_SAME;
+        const uint32_t line = b2 * TL + l2;
+        const uint64_t fixed = same ? (uint64_t)b2 * TL * A.LA + (uint64_t)a2 * tws + l2 : 0;
+        const uint32_t aLB = a2 * A.LB;
+        static_for<0, E>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
+            const SegEntry e = seg_entry(A.stab + (t2 + k0));
+            const uint64_t off = same ? e.base + fixed : e.base + (uint64_t)e.ln * aLB + (uint64_t)line * e.aux;
+            stream_store<Cfg>(out + off, v[c]);
+        });
     } else {
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
@@ -522,6 +565,10 @@ template <int TL> struct TileCtx { uint32_t a, b, tw; int l; };
 template <int TL>
 __device__ __forceinline__ uint64_t tiled_load_offset(const PassArgs &A, const TileCtx<TL> &c, uint32_t n)
 {
+    if (A.ltab) {
+        const SegEntry e = seg_entry(A.ltab + n);
+        return e.base + (uint64_t)e.ln * (c.a * A.LB + c.b * TL) + (uint64_t)e.aux * c.tw + c.l;
+    }
     uint32_t s0 = A.lseg->start[0], ln = A.lseg->len[0];
     uint64_t bs = A.lseg->base[0];
     for (int s = 1; s < A.lnseg; s++)
@@ -531,6 +578,10 @@ __device__ __forceinline__ uint64_t tiled_load_offset(const PassArgs &A, const T
 template <int TL>
 __device__ __forceinline__ uint64_t tiled_transpose_store_offset(const PassArgs &A, const TileCtx<TL> &c, uint32_t k)
 {
+    if (A.stab) {
+        const SegEntry e = seg_entry(A.stab + k);
+        return e.base + (uint64_t)e.ln * (c.a * A.LB) + (uint64_t)(c.b * TL + c.l) * e.aux;
+    }
     uint32_t s0 = A.sseg->start[0], ln = A.sseg->len[0];
     uint64_t bs = A.sseg->base[0];
     for (int s = 1; s < A.snseg; s++)
@@ -542,6 +593,21 @@ __device__ __forceinline__ uint64_t tiled_transpose_store_offset(const PassArgs 
     const uint32_t tw2 = r2 < T2 ? r2 : T2;
     return bs + (uint64_t)c.a * ln * A.LB + (uint64_t)kt * T2 * A.LB + ((uint64_t)c.b * TL + c.l) * tw2 + kr;
 }
+
+// transposed-tile store into the block of a single peer: the per-thread part is computed once
+template <int TL> struct TransposeOne {
+    uint64_t base;
+    uint32_t s0, ln, LB, line, sh;
+    __device__ __forceinline__ TransposeOne(const PassArgs &A, const TileCtx<TL> &c)
+        : base(A.sseg->base[0] + (uint64_t)c.a * A.sseg->len[0] * A.LB), s0(A.sseg->start[0]), ln(A.sseg->len[0]),
+          LB(A.LB), line(c.b * TL + c.l), sh(A.T2shift) {}
+    __device__ __forceinline__ uint64_t operator()(uint32_t k) const
+    {
+        const uint32_t kl = k - s0, T2 = 1u << sh, kt = kl >> sh, kr = kl & (T2 - 1);
+        const uint32_t r2 = ln - (kt << sh), tw2 = r2 < T2 ? r2 : T2;
+        return base + (uint64_t)(kt << sh) * LB + (uint64_t)line * tw2 + kr;
+    }
+};
 
 // forward z pass of an R2C plan: real lines [a][LB][2M] -> tiled send buffer with M+1 points
 template <typename Cfg>
@@ -591,26 +657,36 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
     });
     __syncthreads();
     if (!active) return;
-    const bool lines_out = A.store_kind == STORE_LINES;
-    static_for<0, E>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        const int k = t + NT * c;
-        const int km = (M - k) & (M - 1);
-        const int i0 = lds_pad<Cfg>(k * TW + lw), i1 = lds_pad<Cfg>(km * TW + lw);
-        const R zr = p0[i0], zi = p1[i0], mr = p0[i1], mi = p1[i1];
-        const C wv = W2[k];
-        const R Ar = zr + mr, Ai = zi - mi, Br = zr - mr, Bi = zi + mi;
-        C x;
-        x.x = (R)0.5 * (Ar + wv.x * Bi + wv.y * Br);
-        x.y = (R)0.5 * (Ai - wv.x * Br + wv.y * Bi);
-        // natural [line][M+1] rows (partial transform, d = 1) or the tiled send buffer
+    // the address form is chosen once per thread, not once per point
+    auto emit = [&](auto offset_of) {
+        static_for<0, E>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            const int k = t + NT * c;
+            const int km = (M - k) & (M - 1);
+            const int i0 = lds_pad<Cfg>(k * TW + lw), i1 = lds_pad<Cfg>(km * TW + lw);
+            const R zr = p0[i0], zi = p1[i0], mr = p0[i1], mi = p1[i1];
+            const C wv = W2[k];
+            const R Ar = zr + mr, Ai = zi - mi, Br = zr - mr, Bi = zi + mi;
+            C x;
+            x.x = (R)0.5 * (Ar + wv.x * Bi + wv.y * Br);
+            x.y = (R)0.5 * (Ai - wv.x * Br + wv.y * Bi);
+            out[offset_of((uint32_t)k)] = x;
+            if (c == 0 && t == 0) {          // k = M: X[M] = Re Z[0] - Im Z[0]
+                C xm; xm.x = zr - zi; xm.y = 0;
+                out[offset_of((uint32_t)M)] = xm;
+            }
+        });
+    };
+    if (A.store_kind == STORE_LINES) {
+        // natural [line][M+1] rows (partial transform, d = 1)
         const uint64_t row = ((uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + tc.l) * (uint64_t)(M + 1);
-        out[lines_out ? row + k : tiled_transpose_store_offset<TL>(A, tc, (uint32_t)k)] = x;
-        if (c == 0 && t == 0) {          // k = M: X[M] = Re Z[0] - Im Z[0]
-            C xm; xm.x = zr - zi; xm.y = 0;
-            out[lines_out ? row + M : tiled_transpose_store_offset<TL>(A, tc, (uint32_t)M)] = xm;
-        }
-    });
+        emit([&](uint32_t k) { return row + k; });
+    } else if (A.stab || A.snseg != 1) {
+        emit([&](uint32_t k) { return tiled_transpose_store_offset<TL>(A, tc, k); });
+    } else {
+        const TransposeOne<TL> one(A, tc);      // the tiled send buffer of a single peer
+        emit([&](uint32_t k) { return one(k); });
+    }
 }
 
 // inverse z pass of an R2C plan: tiled recv buffer with M+1 points -> real lines [a][LB][2M]
@@ -641,20 +717,32 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
 
     C v[E];
     if (active) {
-        static_for<0, E>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            const int k = t + NT * c;
-            const bool lines_in = A.load_kind == LOAD_LINES;
+        auto fetch = [&](auto offset_of) {
+            static_for<0, E>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                const int k = t + NT * c;
+                C x = in[offset_of((uint32_t)k)];
+                C m = in[offset_of((uint32_t)(M - k))];
+                if (k == 0) { x.y = 0; m.y = 0; }      // imaginary parts of X[0], X[M] are ignored
+                const C wv = W2[k];
+                const R Ar = x.x + m.x, Ai = x.y - m.y, Br = x.x - m.x, Bi = x.y + m.y;
+                // swapped on the fly (inverse via re<->im swap): v = (Im Z', Re Z')
+                v[c].y = Ar - wv.x * Bi + wv.y * Br;
+                v[c].x = Ai + wv.x * Br + wv.y * Bi;
+            });
+        };
+        if (A.load_kind == LOAD_LINES) {
             const uint64_t row = ((uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + tc.l) * (uint64_t)(M + 1);
-            C x = in[lines_in ? row + k : tiled_load_offset<TL>(A, tc, (uint32_t)k)];
-            C m = in[lines_in ? row + (M - k) : tiled_load_offset<TL>(A, tc, (uint32_t)(M - k))];
-            if (k == 0) { x.y = 0; m.y = 0; }      // imaginary parts of X[0], X[M] are ignored
-            const C wv = W2[k];
-            const R Ar = x.x + m.x, Ai = x.y - m.y, Br = x.x - m.x, Bi = x.y + m.y;
-            // swapped on the fly (inverse via re<->im swap): v = (Im Z', Re Z')
-            v[c].y = Ar - wv.x * Bi + wv.y * Br;
-            v[c].x = Ai + wv.x * Br + wv.y * Bi;
-        });
+            fetch([&](uint32_t k) { return row + k; });
+        } else if (A.ltab || A.lnseg != 1) {
+            fetch([&](uint32_t k) { return tiled_load_offset<TL>(A, tc, k); });
+        } else {
+            // one peer: the tile is one contiguous [point][line] block
+            const uint64_t len = A.lseg->len[0];
+            const uint64_t base = A.lseg->base[0] + (uint64_t)tc.a * len * A.LB + (uint64_t)tc.b * TL * len + tc.l;
+            const uint32_t s0 = A.lseg->start[0], tw = tc.tw;
+            fetch([&](uint32_t k) { return base + (uint64_t)(k - s0) * tw; });
+        }
     } else {
         static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].x = 0; v[c].y = 0; });
     }
@@ -697,6 +785,7 @@ __device__ __forceinline__ uint64_t generic_store_offset(const PassArgs &A, cons
                          : ((uint64_t)c.a * A.LB + (uint64_t)c.b * TL + c.l) * NP) + k;
     if (A.store_kind == STORE_KMAJOR) return (uint64_t)k * A.KS_out + (uint64_t)c.a * A.AS_out + (uint64_t)c.b * TL + c.l;
     if (A.store_kind == STORE_TILED_TRANSPOSE) return tiled_transpose_store_offset<TL>(A, c, k);
+    if (A.stab) return seg_entry(A.stab + k).base + (uint64_t)c.b * TL * A.LA + (uint64_t)c.a * c.tw + c.l;
     uint32_t s0 = A.sseg->start[0], ln = A.sseg->len[0];
     uint64_t bs = A.sseg->base[0];
     for (int s = 1; s < A.snseg; s++)
@@ -766,31 +855,49 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_bluestein_kernel(const PassA
     const C *__restrict__ BH = reinterpret_cast<const C *>(A.tw3);
 
     C v[E];
-    static_for<0, E>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        const uint32_t n = t + NT * c;
-        C x; x.x = 0; x.y = 0;
-        if (active && n < NL) {
-            if (A.real_mode == 1) {            // real input line
-                x.x = rin[generic_load_offset<TL>(A, tc, n, NL)];
-            } else if (A.real_mode == 2) {     // Hermitian half in, rebuild the full spectrum
-                if (n < NK) {
-                    x = in[generic_load_offset<TL>(A, tc, n, NK)];
-                    if (n == 0 || 2 * n == NL) x.y = 0;
+    // the address form (load kind) and the real mode are chosen once per thread, not per point;
+    // offset_of(n, NP): element offset of point n of this thread's line, NP = points per natural line
+    auto load_all = [&](auto offset_of) {
+        static_for<0, E>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            const uint32_t n = t + NT * c;
+            C x; x.x = 0; x.y = 0;
+            if (active && n < NL) {
+                if (A.real_mode == 1) {            // real input line
+                    x.x = rin[offset_of(n, NL)];
+                } else if (A.real_mode == 2) {     // Hermitian half in, rebuild the full spectrum
+                    if (n < NK) {
+                        x = in[offset_of(n, NK)];
+                        if (n == 0 || 2 * n == NL) x.y = 0;
+                    } else {
+                        x = in[offset_of(NL - n, NK)];
+                        x.y = -x.y;
+                    }
                 } else {
-                    x = in[generic_load_offset<TL>(A, tc, NL - n, NK)];
-                    x.y = -x.y;
+                    x = in[offset_of(n, NL)];
                 }
-            } else {
-                x = in[generic_load_offset<TL>(A, tc, n, NL)];
+                if (A.swap) { R tmp = x.x; x.x = x.y; x.y = tmp; }
+                const C ch = CH[n];
+                C r; r.x = x.x * ch.x - x.y * ch.y; r.y = x.x * ch.y + x.y * ch.x;
+                x = r;
             }
-            if (A.swap) { R tmp = x.x; x.x = x.y; x.y = tmp; }
-            const C ch = CH[n];
-            C r; r.x = x.x * ch.x - x.y * ch.y; r.y = x.x * ch.y + x.y * ch.x;
-            x = r;
-        }
-        v[c] = x;
-    });
+            v[c] = x;
+        });
+    };
+    const uint64_t rowline = (uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + tc.l;
+    if (A.load_kind == LOAD_LINES) {
+        load_all([&](uint32_t n, uint32_t NP) { return rowline * NP + n; });
+    } else if (A.load_kind == LOAD_KMAJOR) {
+        const uint64_t base = (uint64_t)tc.a * A.AS_in + (uint64_t)tc.b * TL + tc.l, ks = A.KS_in;
+        load_all([&](uint32_t n, uint32_t) { return base + (uint64_t)n * ks; });
+    } else if (A.ltab || A.lnseg != 1) {
+        load_all([&](uint32_t n, uint32_t) { return tiled_load_offset<TL>(A, tc, n); });
+    } else {
+        const uint64_t len = A.lseg->len[0];
+        const uint64_t base = A.lseg->base[0] + (uint64_t)tc.a * len * A.LB + (uint64_t)tc.b * TL * len + tc.l;
+        const uint32_t s0 = A.lseg->start[0], tw = tc.tw;
+        load_all([&](uint32_t n, uint32_t) { return base + (uint64_t)(n - s0) * tw; });
+    }
     transform<Cfg>(v, lds, W, t, lw, tid);
     {   // pointwise product with the chirp spectrum, then swap for the inverse transform
         constexpr int RL = Cfg::RLAST, S = E / RL;
@@ -807,22 +914,40 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_bluestein_kernel(const PassA
     if (Cfg::NPASS > 1) __syncthreads();
     transform<Cfg>(v, lds, W, t, lw, tid);
     if (!active) return;
-    {
+    const uint32_t kmax = A.real_mode == 1 ? NK : NL;
+    auto store_all = [&](auto offset_of) {
         constexpr int RL = Cfg::RLAST, S = E / RL;
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
             const uint32_t k = t + k0;
-            const uint32_t kmax = A.real_mode == 1 ? NK : NL;
             if (k < kmax) {
                 C x; x.x = v[c].y; x.y = v[c].x;       // swap back
                 const C ch = CH[k];
                 C r; r.x = x.x * ch.x - x.y * ch.y; r.y = x.x * ch.y + x.y * ch.x;
                 if (A.swap) { R tmp = r.x; r.x = r.y; r.y = tmp; }
-                if (A.real_mode == 2) rout[generic_store_offset<TL>(A, tc, k, NL)] = r.x;
-                else out[generic_store_offset<TL>(A, tc, k, kmax)] = r;
+                if (A.real_mode == 2) rout[offset_of(k)] = r.x;
+                else out[offset_of(k)] = r;
             }
         });
+    };
+    if (A.store_kind == STORE_LINES) {
+        const uint64_t row = A.KS_out ? (uint64_t)tc.a * A.AS_out + ((uint64_t)tc.b * TL + tc.l) * A.KS_out
+                                      : rowline * (A.real_mode == 2 ? NL : kmax);
+        store_all([&](uint32_t k) { return row + k; });
+    } else if (A.store_kind == STORE_KMAJOR) {
+        const uint64_t base = (uint64_t)tc.a * A.AS_out + (uint64_t)tc.b * TL + tc.l, ks = A.KS_out;
+        store_all([&](uint32_t k) { return base + (uint64_t)k * ks; });
+    } else if (A.stab || A.snseg != 1) {
+        store_all([&](uint32_t k) { return generic_store_offset<TL>(A, tc, k, kmax); });
+    } else if (A.store_kind == STORE_TILED_TRANSPOSE) {
+        const TransposeOne<TL> one(A, tc);
+        store_all([&](uint32_t k) { return one(k); });
+    } else {
+        const uint64_t base = A.sseg->base[0] + (uint64_t)tc.b * TL * A.LA + (uint64_t)tc.a * tc.tw + tc.l;
+        const uint64_t step = (uint64_t)A.LB * A.LA;
+        const uint32_t s0 = A.sseg->start[0];
+        store_all([&](uint32_t k) { return base + (uint64_t)(k - s0) * step; });
     }
 }
 
