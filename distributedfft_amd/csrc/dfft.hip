@@ -292,6 +292,24 @@ static PassArgs pass_args(int TL, size_t na, size_t LB, int load_kind, int store
     return A;
 }
 
+// Point-major store whose row pitch (AS_out) is not a multiple of the tile, e.g. the 513-wide rows
+// of an R2C spectrum: let every workgroup's window start at a cache-line boundary of its output row.
+// Needs every row start to differ from an aligned address by (a*AS_out) mod TL only, i.e. KS_out a
+// multiple of TL (the caller's buffer is assumed 128-byte aligned, like every hipMalloc result).
+static void set_shift(const dfft_plan *p, PassArgs &X)
+{
+    const uint32_t TL = (uint32_t)p->TL;
+    const char *v = getenv("DFFT_SHIFT");
+    if (v && atoi(v) == 0) return;
+    if (p->ax[2].bluestein) return;               // the Bluestein kernel has no shifted windows
+    // fp32 (16-line tiles of 8-byte points) measured 10 % slower with shifted windows, fp64 24 % faster
+    if (p->prec != DFFT_F64 && !(v && atoi(v) == 2)) return;
+    if (X.AS_out % TL == 0 || X.KS_out % TL != 0 || X.LB < TL) return;
+    X.shift = 1;
+    X.nb += 1;
+    X.ntiles = X.na * X.nb;
+}
+
 static void seg_push(SegTable &t, size_t start, size_t len, size_t base_elems)
 {
     int s = t.nseg++;
@@ -329,6 +347,7 @@ static int build_pipeline(dfft_plan *p, Pipeline &pl)
         // neighbouring tiles along z' share cache lines whenever the pitch zs is not a multiple of the
         // tile; keeping consecutive tiles on one XCD lets its L2 merge them (R2C, 513-wide: 6.3 -> 4.5 ms)
         X.a_fastest = 0; X.xcd_swizzle = 1;
+        set_shift(p, X);
         // segments of the x axis, ascending: peer q major, chunk c minor
         std::vector<size_t> r2c_of(C, 0);
         { size_t acc = 0; for (int c = 0; c < C; c++) { r2c_of[c] = acc; for (int q = 0; q < P1; q++) acc += xlq[q][c] * yo * zs; } }
@@ -524,6 +543,7 @@ static int build_pipeline_zyx(dfft_plan *p, Pipeline &pl)
     {   // x pass: lines along x from the P*C blocks -> [kx][ky][kz']
         PassArgs X = base(Ny, zs, LOAD_TILED, STORE_KMAJOR, 0);
         X.KS_out = (uint64_t)Ny * zs; X.AS_out = zs; X.xcd_swizzle = 1;
+        set_shift(p, X);
         pl.fx.args = X;
         for (int q = 0; q < P; q++)
             for (int c = 0; c < C; c++)

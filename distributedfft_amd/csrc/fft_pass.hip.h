@@ -81,6 +81,8 @@ struct PassArgs {
     int32_t a_fastest;     // workgroup -> tile order: 0: b fastest (w = a*nb + b), 1: a fastest (w = b*na + a)
     int32_t xcd_swizzle;   // 1: consecutive tiles go to the same XCD (block b runs on XCD b % 8), so that
                            //    neighbouring tiles that share a cache line meet in one L2
+    int32_t shift;         // 1: STORE_KMAJOR with an odd row pitch: tile windows follow the cache lines of each
+                           //    output row (nb counts one extra tile per row); fft_pass_kernel only
     uint32_t LA;           // STORE_TILED_SAME: extent of the a axis
     uint32_t T2shift;      // STORE_TILED_TRANSPOSE: log2 of the consumer's tile size
     uint64_t KS_in;        // LOAD_KMAJOR point stride
@@ -425,20 +427,36 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
 
     // tile of a line (workgroup index, b fastest or a fastest, optionally XCD-remapped)
     const uint32_t blk = logical_block(A);
-    auto tile_of = [&](int lwx, uint32_t &a, uint32_t &b, uint32_t &tw, int &l) -> bool {
+    // e = index of the lane's line along the tiled axis.  With A.shift (point-major stores whose
+    // row pitch is not a multiple of the tile) the window of a workgroup is moved back by the row's
+    // misalignment, so that its TL stores per point fill exactly one aligned 128-byte line; (b, l, tw)
+    // then describe where that line lives in the (unshifted) tiled input.
+    auto tile_of = [&](int lwx, uint32_t &a, uint32_t &b, uint32_t &tw, int &l, uint32_t &e) -> bool {
         const int g = lwx / TL;
         l = lwx % TL;
         const uint32_t w = blk * Cfg::kG + g;
-        const bool ok = w < A.ntiles;
+        bool ok = w < A.ntiles;
         a = !ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
         b = !ok ? 0 : (A.a_fastest ? w / A.na : w % A.nb);
+        if (A.shift) {
+            const uint32_t s = (uint32_t)((uint64_t)a * A.AS_out) & (uint32_t)(TL - 1);
+            const int ei = (int)(b * TL + l) - (int)s;
+            ok = ok && ei >= 0 && (uint32_t)ei < A.LB;
+            e = ok ? (uint32_t)ei : 0;
+            b = e / TL;
+            l = (int)(e % TL);
+            const uint32_t rem = A.LB - b * TL;
+            tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;
+            return ok;
+        }
         const uint32_t rem = A.LB - b * TL;
         tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;     // valid lines of this tile
+        e = b * TL + l;
         return ok && (uint32_t)l < tw;
     };
-    uint32_t a, b, tw;
+    uint32_t a, b, tw, e1;
     int l;
-    const bool active = tile_of(lw, a, b, tw, l);
+    const bool active = tile_of(lw, a, b, tw, l, e1);
 
     const C *__restrict__ in = reinterpret_cast<const C *>(A.in);
     C *__restrict__ out = reinterpret_cast<C *>(A.out);
@@ -488,9 +506,9 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
     if (A.swap) static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; R tmp = v[c].x; v[c].x = v[c].y; v[c].y = tmp; });
 
     // ------------------------------------------------------------------ store (coordinates of the later passes)
-    uint32_t a2, b2, tws;
+    uint32_t a2, b2, tws, e2;
     int l2;
-    if (!tile_of(lw2, a2, b2, tws, l2)) return;
+    if (!tile_of(lw2, a2, b2, tws, l2, e2)) return;
     constexpr int RL = Cfg::RLAST;     // radix of the last pass
     constexpr int S = E / RL;
     // register c = i + mr*S holds output k = t2 + NT*i + brev(mr)*(N/RL)
@@ -505,7 +523,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
             stream_store<Cfg>(p + k0, v[c]);
         });
     } else if (A.store_kind == STORE_KMAJOR) {
-        C *p = out + (uint64_t)a2 * A.AS_out + (uint64_t)b2 * TL + l2 + (uint64_t)t2 * A.KS_out;
+        C *p = out + (uint64_t)a2 * A.AS_out + e2 + (uint64_t)t2 * A.KS_out;
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
