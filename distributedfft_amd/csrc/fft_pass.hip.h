@@ -574,8 +574,11 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
 //   C2R:  Z[k] = (X[k] + conj X[M-k]) + i w^-k (X[k] - conj X[M-k]),       k = 0..M-1
 // with w = exp(-2*pi*i/(2M)).  Cfg::kN is M.
 // ------------------------------------------------------------------------------------------
-template <typename Cfg> struct RealCfg {
-    static constexpr size_t LDS_BYTES = 2 * (size_t)Cfg::PLANE_SLOTS * sizeof(typename Cfg::real);
+// ONEPLANE: the split step sends re and im through one LDS plane one after the other (two more
+// barriers, half the LDS: twice the workgroups or twice the lines per workgroup on a CU)
+template <typename Cfg, int ONEPLANE = 0> struct RealCfg {
+    static constexpr size_t SPLIT_BYTES = (ONEPLANE ? 1 : 2) * (size_t)Cfg::PLANE_SLOTS * sizeof(typename Cfg::real);
+    static constexpr size_t LDS_BYTES = SPLIT_BYTES > Cfg::LDS_BYTES ? SPLIT_BYTES : Cfg::LDS_BYTES;
 };
 
 template <int TL> struct TileCtx { uint32_t a, b, tw; int l; };
@@ -628,7 +631,7 @@ template <int TL> struct TransposeOne {
 };
 
 // forward z pass of an R2C plan: real lines [a][LB][2M] -> tiled send buffer with M+1 points
-template <typename Cfg>
+template <typename Cfg, int ONEPLANE = 0>
 __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
 {
     using C = typename Cfg::C;
@@ -662,18 +665,41 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
     }
     transform<Cfg>(v, lds, W, t, lw, tid);
 
-    // split step through both LDS planes: scatter Z by natural index, gather the (k, M-k) pairs
+    // split step through LDS: scatter Z by natural index, gather the (k, M-k) pairs
     constexpr int RL = Cfg::RLAST, S = E / RL;
-    R *p0 = lds, *p1 = lds + Cfg::PLANE_SLOTS;
+    R *p0 = lds, *p1 = ONEPLANE ? lds : lds + Cfg::PLANE_SLOTS;
+    R zr_[ONEPLANE ? E : 1], mr_[ONEPLANE ? E : 1];
     if (Cfg::NPASS > 1) __syncthreads();
-    static_for<0, E>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (M / RL);
-        const int idx = lds_pad<Cfg>((t + k0) * TW + lw);
-        p0[idx] = v[c].x;
-        p1[idx] = v[c].y;
-    });
-    __syncthreads();
+    if constexpr (!ONEPLANE) {
+        static_for<0, E>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (M / RL);
+            const int idx = lds_pad<Cfg>((t + k0) * TW + lw);
+            p0[idx] = v[c].x;
+            p1[idx] = v[c].y;
+        });
+        __syncthreads();
+    } else {
+        static_for<0, E>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (M / RL);
+            lds[lds_pad<Cfg>((t + k0) * TW + lw)] = v[c].x;
+        });
+        __syncthreads();
+        static_for<0, E>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            const int k = t + NT * c, km = (M - k) & (M - 1);
+            zr_[c] = lds[lds_pad<Cfg>(k * TW + lw)];
+            mr_[c] = lds[lds_pad<Cfg>(km * TW + lw)];
+        });
+        __syncthreads();
+        static_for<0, E>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (M / RL);
+            lds[lds_pad<Cfg>((t + k0) * TW + lw)] = v[c].y;
+        });
+        __syncthreads();
+    }
     if (!active) return;
     // the address form is chosen once per thread, not once per point
     auto emit = [&](auto offset_of) {
@@ -682,7 +708,8 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
             const int k = t + NT * c;
             const int km = (M - k) & (M - 1);
             const int i0 = lds_pad<Cfg>(k * TW + lw), i1 = lds_pad<Cfg>(km * TW + lw);
-            const R zr = p0[i0], zi = p1[i0], mr = p0[i1], mi = p1[i1];
+            const R zr = ONEPLANE ? zr_[ONEPLANE ? c : 0] : p0[i0], mr = ONEPLANE ? mr_[ONEPLANE ? c : 0] : p0[i1];
+            const R zi = p1[i0], mi = p1[i1];
             const C wv = W2[k];
             const R Ar = zr + mr, Ai = zi - mi, Br = zr - mr, Bi = zi + mi;
             C x;

@@ -27,8 +27,10 @@ using F64_512_v3 = PassCfg<double, 512, 16, 8, 1, 8, 8, 8, 1, 1, 0, 3>;       //
 using F64_2048_v3 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 3>;   // nontemporal, 2048
 // variant 2 = table-loaded twiddles (bit-for-bit the round-1 baseline), kept for A/B runs
 using F64_1024_v2 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 0>;
+// variant 4 = two radix-32 passes on 8 lines (256 threads, one LDS exchange), for A/B runs
+using F64_1024_v4 = PassCfg<double, 1024, 32, 8, 1, 32, 32, 1, 1, 1, 1>;
 
-#define DFFT_F64_LIST(X) X(1024, 1, F64_1024_v1) X(1024, 2, F64_1024_v2) X(1024, 3, F64_1024_v3) X(512, 1, F64_512_v1) X(512, 3, F64_512_v3) X(2048, 3, F64_2048_v3) \
+#define DFFT_F64_LIST(X) X(1024, 1, F64_1024_v1) X(1024, 2, F64_1024_v2) X(1024, 3, F64_1024_v3) X(1024, 4, F64_1024_v4) X(512, 1, F64_512_v1) X(512, 3, F64_512_v3) X(2048, 3, F64_2048_v3) \
     X(2, 0, F64_2) X(4, 0, F64_4) X(8, 0, F64_8) X(16, 0, F64_16) X(32, 0, F64_32) X(64, 0, F64_64) \
     X(128, 0, F64_128) X(256, 0, F64_256) X(512, 0, F64_512) X(1024, 0, F64_1024) X(2048, 0, F64_2048)
 
@@ -56,8 +58,23 @@ bool pass_info_f64(int N, int variant, PassInfo *pi)
 using F64_R512 = PassCfg<double, 512, 8, 8, 1, 8, 8, 8, 1, 1>;
 #define DFFT_F64_BASE(X) X(2, 0, F64_2) X(4, 0, F64_4) X(8, 0, F64_8) X(16, 0, F64_16) X(32, 0, F64_32) X(64, 0, F64_64) \
     X(128, 0, F64_128) X(256, 0, F64_256) X(512, 0, F64_R512) X(1024, 0, F64_1024)
+// experiment variants of the real z passes (DFFT_REAL_VARIANT): 1 = one-plane split, same configuration;
+// 2 = one-plane split with 16 points per thread x 16 lines (twice the bytes in flight per workgroup)
+using F64_R512_16 = PassCfg<double, 512, 16, 8, 2, 8, 8, 8, 1, 1>;
+static int launch_real_variant_f64(int M, int mode, int variant, const PassArgs &A, hipStream_t stream)
+{
+    if (M == 512 && variant == 1) return mode == 1 ? launch_real_cfg<F64_R512, 1, 1>(A, stream) : launch_real_cfg<F64_R512, 2>(A, stream);
+    if (M == 512 && variant == 2) return mode == 1 ? launch_real_cfg<F64_R512_16, 1, 1>(A, stream) : launch_real_cfg<F64_R512_16, 2>(A, stream);
+    if (M == 512 && variant == 3) return mode == 1 ? launch_real_cfg<F64_512, 1, 1>(A, stream) : launch_real_cfg<F64_512, 2>(A, stream);
+    if (M == 1024 && variant == 1) return mode == 1 ? launch_real_cfg<F64_1024, 1, 1>(A, stream) : launch_real_cfg<F64_1024, 2>(A, stream);
+    return -2;
+}
 int launch_real_f64(int M, int mode, const PassArgs &A, hipStream_t stream)
 {
+    if (const char *v = getenv("DFFT_REAL_VARIANT")) {
+        const int r = launch_real_variant_f64(M, mode, atoi(v), A, stream);
+        if (r != -2) return r;
+    }
     switch (M) {
 #define X(n, v, cfg) case n: return mode == 1 ? launch_real_cfg<cfg, 1>(A, stream) : launch_real_cfg<cfg, 2>(A, stream);
         DFFT_F64_BASE(X)

@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 import distributedfft_amd as dfft
-for N in (64, 128, 256, 512):
+for N in (64, 128, 256, 512, 1024):
     plan = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), precision="double")
     plan.initFFT(dfft.GlobalSize(N, N, N), dfft.Partition(1, 1), True)
     x = torch.rand((N, N, N), dtype=torch.float64, device="cuda")

@@ -30,6 +30,8 @@ for it in range(iters + 1):
     if it:
         for k, v in f + b:
             acc.setdefault(k, []).append(v)
+torch.cuda.synchronize()
+print(f"round trip rel L-inf {float((back / float(N) ** 3 - x).abs().max()) / 255.0:.2e}")
 Nzc = N // 2 + 1
 real_b, half_b = N ** 3 * esz / 2, N * N * Nzc * esz
 print(f"N={N} {prec} R2C/C2R  (real {real_b / 2**30:.2f} GiB, half spectrum {half_b / 2**30:.2f} GiB)")
