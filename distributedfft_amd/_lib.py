@@ -16,6 +16,17 @@ class Config(C.Structure):
                 ("send_method", C.c_int), ("comm_method2", C.c_int), ("send_method2", C.c_int)]
 
 
+class PassDesc(C.Structure):
+    """dfft_pass_desc (include/dfft_c.h): one axis pass as the kernels see it"""
+    _fields_ = [("na", C.c_uint32), ("LB", C.c_uint32), ("nb", C.c_uint32), ("LA", C.c_uint32), ("T2shift", C.c_uint32),
+                ("load_kind", C.c_int32), ("store_kind", C.c_int32), ("swap", C.c_int32), ("shift", C.c_int32),
+                ("KS_in", C.c_uint64), ("KS_out", C.c_uint64), ("AS_in", C.c_uint64), ("AS_out", C.c_uint64),
+                ("in_off", C.c_uint64), ("out_off", C.c_uint64),
+                ("lnseg", C.c_int32), ("snseg", C.c_int32),
+                ("lstart", C.c_uint32 * 32), ("llen", C.c_uint32 * 32), ("lbase", C.c_uint64 * 32),
+                ("sstart", C.c_uint32 * 32), ("slen", C.c_uint32 * 32), ("sbase", C.c_uint64 * 32)]
+
+
 # every symbol include/dfft_c.h declares: (name, restype, argtypes)
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
 _psz = C.POINTER(C.c_size_t)
@@ -55,6 +66,9 @@ SYMBOLS = [
     ("dfft_phase_name", C.c_char_p, [_i, _i]),
     ("dfft_enable_phase_timing", _i, [_vp, _i]),
     ("dfft_fft1d_batched", _i, [_i, _sz, _sz, _vp, _vp, _i, _vp]),
+    ("dfft_debug_get_pass", _i, [_vp, C.c_char_p, _i, C.POINTER(PassDesc)]),
+    ("dfft_debug_get_point_table", _i, [_vp, C.c_char_p, _i, _i, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+                                        C.POINTER(C.c_uint32), _sz, _psz]),
     ("dfft_last_error", C.c_char_p, []),
     ("dfft_version", C.c_char_p, []),
     ("dfft_kernel_info", _i, [_i, _sz, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),

@@ -262,6 +262,22 @@ class MPIcuFFT:
         check(lib().dfft_get_pipeline_tables(self._h, direction, which, chunk, *arrs))
         return [list(a) for a in arrs]
 
+    def debugPass(self, name, index=0):
+        """descriptor of one axis pass (dfft_debug_get_pass); None if the plan has no such launch"""
+        from ._lib import PassDesc
+        d = PassDesc()
+        if lib().dfft_debug_get_pass(self._h, name.encode(), int(index), C.byref(d)) != 0:
+            return None
+        return d
+
+    def debugPointTable(self, name, index=0, store=False):
+        """[(base, ln, aux)] per point of a segmented side (dfft_debug_get_point_table)"""
+        n = C.c_size_t(0)
+        check(lib().dfft_debug_get_point_table(self._h, name.encode(), int(index), int(store), None, None, None, 0, C.byref(n)))
+        base, ln, aux = (C.c_uint64 * n.value)(), (C.c_uint32 * n.value)(), (C.c_uint32 * n.value)()
+        check(lib().dfft_debug_get_point_table(self._h, name.encode(), int(index), int(store), base, ln, aux, n.value, C.byref(n)))
+        return list(zip(base, ln, aux))
+
     def getTileLines(self):
         return lib().dfft_tile_lines(self._h)
 

@@ -1532,6 +1532,70 @@ int dfft_get_pipeline_tables(const dfft_plan *p, int direction, int which, int c
     return 0;
 }
 
+static const Launch *find_launch(const dfft_plan *p, const char *name, int index)
+{
+    const Pipeline &pl = p->pl;
+    const std::string n = name ? name : "";
+    auto at = [&](const std::vector<Launch> &v) -> const Launch * {
+        return index >= 0 && (size_t)index < v.size() ? &v[(size_t)index] : nullptr;
+    };
+    if (n == "fz") return at(pl.fz);
+    if (n == "fy") return at(pl.fy);
+    if (n == "ix") return at(pl.ix);
+    if (n == "iy") return at(pl.iy);
+    if (n == "iz") return at(pl.iz);
+    if (n == "py2") return at(pl.py2);
+    if (n == "qy2") return at(pl.qy2);
+    if (n == "zy") return at(pl.zy);
+    if (n == "ziy") return at(pl.ziy);
+    if (index != 0) return nullptr;
+    if (n == "fx") return &pl.fx;
+    if (n == "zix") return p->zyx ? &pl.zix : nullptr;
+    if (n == "yz") return p->yzx ? &pl.yz : nullptr;
+    if (n == "pz1") return &pl.pz1;
+    if (n == "qz1") return &pl.qz1;
+    return nullptr;
+}
+
+int dfft_debug_get_pass(const dfft_plan *p, const char *name, int index, dfft_pass_desc *d)
+{
+    if (!p || !p->initialized) return fail(ERR_STATE, "plan not initialised");
+    if (!d) return fail(ERR_ARG, "null descriptor");
+    const Launch *L = find_launch(p, name, index);
+    if (!L) return fail(ERR_ARG, "the plan has no such launch");
+    const PassArgs &A = L->args;
+    memset(d, 0, sizeof(*d));
+    d->na = A.na; d->LB = A.LB; d->nb = A.nb; d->LA = A.LA; d->T2shift = A.T2shift;
+    d->load_kind = A.load_kind; d->store_kind = A.store_kind; d->swap = A.swap; d->shift = A.shift;
+    d->KS_in = A.KS_in; d->KS_out = A.KS_out; d->AS_in = A.AS_in; d->AS_out = A.AS_out;
+    d->in_off = L->in_off; d->out_off = L->out_off;
+    d->lnseg = L->lseg.nseg; d->snseg = L->sseg.nseg;
+    for (int s = 0; s < L->lseg.nseg; s++) { d->lstart[s] = L->lseg.start[s]; d->llen[s] = L->lseg.len[s]; d->lbase[s] = L->lseg.base[s]; }
+    for (int s = 0; s < L->sseg.nseg; s++) { d->sstart[s] = L->sseg.start[s]; d->slen[s] = L->sseg.len[s]; d->sbase[s] = L->sseg.base[s]; }
+    return 0;
+}
+
+int dfft_debug_get_point_table(const dfft_plan *p, const char *name, int index, int store, uint64_t *base, uint32_t *ln,
+                               uint32_t *aux, size_t capacity, size_t *count)
+{
+    if (!p || !p->initialized) return fail(ERR_STATE, "plan not initialised");
+    const Launch *L = find_launch(p, name, index);
+    if (!L) return fail(ERR_ARG, "the plan has no such launch");
+    const SegTable &T = store ? L->sseg : L->lseg;
+    const bool tiled = store ? (L->args.store_kind == STORE_TILED_SAME || L->args.store_kind == STORE_TILED_TRANSPOSE)
+                             : L->args.load_kind == LOAD_TILED;
+    if (!tiled || T.nseg < 1) return fail(ERR_ARG, "that side of the launch is not segmented");
+    std::vector<SegEntry> tab;
+    point_table(*L, store != 0, tab);
+    if (count) *count = tab.size();
+    for (size_t i = 0; i < tab.size() && i < capacity; i++) {
+        if (base) base[i] = tab[i].base;
+        if (ln) ln[i] = tab[i].ln;
+        if (aux) aux[i] = tab[i].aux;
+    }
+    return 0;
+}
+
 int dfft_enable_phase_timing(dfft_plan *p, int enable)
 {
     if (!p) return fail(ERR_ARG, "null plan");

@@ -185,6 +185,32 @@ int dfft_enable_phase_timing(dfft_plan *plan, int enable);
 int dfft_fft1d_batched(int precision, size_t N, size_t batch, void *out, const void *in,
                        int direction, void *hip_stream);
 
+/* ---- introspection of the pass descriptors (host only; used by the CPU layout tests) -------- *
+ * One axis pass of the plan: which lines it transforms and the address forms of its load and store
+ * side (enum values as in distributedfft_amd/csrc/fft_pass.hip.h).  Offsets
+ * are in ELEMENTS of the side's type except in_off / out_off (bytes added to the stage buffer). */
+typedef struct dfft_pass_desc {
+    uint32_t na, LB, nb, LA, T2shift;
+    int32_t load_kind;      /* 0 natural lines, 1 tiled (segments), 2 point-major (KS_in, AS_in) */
+    int32_t store_kind;     /* 0 lines (row strides if KS_out != 0), 1 point-major, 2 tiled-same, 3 tiled-transpose */
+    int32_t swap, shift;
+    uint64_t KS_in, KS_out, AS_in, AS_out;
+    uint64_t in_off, out_off;
+    int32_t lnseg, snseg;
+    uint32_t lstart[32], llen[32];
+    uint64_t lbase[32];
+    uint32_t sstart[32], slen[32];
+    uint64_t sbase[32];
+} dfft_pass_desc;
+/* name: "fz" "fy" "ix" "iy" "iz" "py2" "qy2" "zy" "ziy" (index = chunk, or chunk*P + peer for zy/ziy)
+ * and "fx" "zix" "yz" "pz1" "qz1" (index 0).  Returns nonzero if the plan has no such launch. */
+int dfft_debug_get_pass(const dfft_plan *plan, const char *name, int index, dfft_pass_desc *desc);
+/* the per-point address table the kernels use for a segmented side of that launch (store = 0: load
+ * side, 1: store side); entry i = {base[i], ln[i], aux[i]} as documented for SegEntry.  *count receives
+ * the number of points; at most `capacity` entries are written. */
+int dfft_debug_get_point_table(const dfft_plan *plan, const char *name, int index, int store, uint64_t *base,
+                               uint32_t *ln, uint32_t *aux, size_t capacity, size_t *count);
+
 const char *dfft_last_error(void);
 const char *dfft_version(void);
 /* kernel configuration for line length N: returns 0 if supported and fills the fields */

@@ -1,0 +1,107 @@
+"""Every pass descriptor, segment table, per-point table and chunked exchange table of a plan,
+executed on the CPU by tests/layout_sim.py (numpy transforms + the documented address forms) and
+compared with the transform of the global array -- the GPU-free check of the plan wiring
+(build_pipeline / build_pipeline_zyx / build_pipeline_yzx in distributedfft_amd/csrc/dfft.hip).
+The kernels themselves are covered by the -m gpu parity tests."""
+import numpy as np
+import pytest
+
+import distributedfft_amd as dfft
+from layout_sim import World
+
+RNG = np.random.default_rng(7)
+
+
+def global_field(shape, c2c):
+    g = RNG.uniform(0, 255, shape)
+    return g + 1j * RNG.uniform(0, 255, shape) if c2c else g
+
+
+def local_inputs(world, g):
+    ins = []
+    for pl in world.plans:
+        s, o = pl.getInSize(), pl.getInStart()
+        blk = g[o[0]:o[0] + s[0], o[1]:o[1] + s[1], :]
+        ins.append(np.ascontiguousarray(blk).ravel().astype(np.complex128 if world.c2c else np.float64))
+    return ins
+
+
+def check_spectrum(world, outs, want):
+    scale = np.max(np.abs(want))
+    for pl, out in zip(world.plans, outs):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        got = out[:s[0] * s[1] * s[2]].reshape(s)
+        ref = want[o[0]:o[0] + s[0], o[1]:o[1] + s[1], o[2]:o[2] + s[2]]
+        assert np.max(np.abs(got - ref)) / scale < 1e-12
+
+
+def check_round_trip(world, backs, ins):
+    n3 = float(np.prod(world.shape))
+    for b, x in zip(backs, ins):
+        assert np.max(np.abs(b / n3 - x)) / 255.0 < 1e-12
+
+
+DEFAULT = [((12, 10, 14), 2, 2), ((9, 7, 10), 3, 2), ((16, 8, 8), 2, 1), ((8, 8, 16), 1, 2), ((6, 5, 9), 1, 1), ((10, 20, 18), 2, 3)]
+
+
+@pytest.mark.parametrize("chunks", [1, 3])
+@pytest.mark.parametrize("c2c", [True, False])
+@pytest.mark.parametrize("shape,P1,P2", DEFAULT)
+def test_default_sequence_descriptors(shape, P1, P2, c2c, chunks):
+    w = World(dfft.MPIcuFFT_Pencil_Opt1, shape, P1, P2, c2c, chunks)
+    g = global_field(shape, c2c)
+    ins = local_inputs(w, g)
+    outs = w.forward(ins)
+    check_spectrum(w, outs, np.fft.fftn(g) if c2c else np.fft.rfftn(g))
+    check_round_trip(w, w.inverse(outs), ins)
+
+
+@pytest.mark.parametrize("chunks", [1, 2])
+@pytest.mark.parametrize("c2c", [True, False])
+@pytest.mark.parametrize("shape,P", [((12, 10, 14), 2), ((9, 6, 20), 3), ((16, 5, 16), 4)])
+def test_z_then_yx_descriptors(shape, P, c2c, chunks):
+    w = World(dfft.MPIcuFFT_Slab_Z_Then_YX, shape, P, 1, c2c, chunks)
+    g = global_field(shape, c2c)
+    ins = local_inputs(w, g)
+    outs = w.forward(ins, "zyx")
+    check_spectrum(w, outs, np.fft.fftn(g) if c2c else np.fft.rfftn(g))
+    check_round_trip(w, w.inverse(outs, "zyx"), ins)
+
+
+@pytest.mark.parametrize("chunks", [1, 2])
+@pytest.mark.parametrize("c2c", [True, False])
+@pytest.mark.parametrize("shape,P", [((12, 10, 14), 2), ((9, 12, 7), 3), ((8, 6, 4), 1)])
+def test_y_then_zx_descriptors(shape, P, c2c, chunks):
+    w = World(dfft.MPIcuFFT_Slab_Y_Then_ZX, shape, P, 1, c2c, chunks)
+    g = global_field(shape, c2c)
+    outs = w.forward(local_inputs(w, g), "yzx")
+    want = np.fft.fftn(g)
+    check_spectrum(w, outs, want if c2c else want[:, :shape[1] // 2 + 1, :])
+
+
+@pytest.mark.parametrize("c2c", [True, False])
+@pytest.mark.parametrize("shape,P1,P2", [((12, 10, 14), 2, 2), ((9, 7, 10), 3, 2), ((6, 5, 9), 1, 1)])
+@pytest.mark.parametrize("d", [1, 2])
+def test_partial_transform_descriptors(shape, P1, P2, d, c2c):
+    """execR2C/execC2R(out, in, d): stage layouts [xs][ys][Nzc] (d = 1) and [xs][Ny][zs] (d = 2)"""
+    w = World(dfft.MPIcuFFT_Pencil, shape, P1, P2, c2c, 2)
+    g = global_field(shape, c2c)
+    ins = local_inputs(w, g)
+    outs = w.partial(ins, d, dfft.FORWARD)
+    gz = np.fft.fft(g, axis=2) if c2c else np.fft.rfft(g, axis=2)
+    stage = gz if d == 1 else np.fft.fft(gz, axis=1)
+    scale = np.max(np.abs(stage))
+    spec = []
+    for pl, out in zip(w.plans, outs):
+        s, o, os_, oo = pl.getInSize(), pl.getInStart(), pl.getOutSize(), pl.getOutStart()
+        if d == 1:
+            ref = stage[o[0]:o[0] + s[0], o[1]:o[1] + s[1], :]
+        else:
+            ref = stage[o[0]:o[0] + s[0], :, oo[2]:oo[2] + os_[2]]
+        got = out[:ref.size].reshape(ref.shape)
+        assert np.max(np.abs(got - ref)) / scale < 1e-12
+        spec.append(out)
+    backs = w.partial(spec, d, dfft.INVERSE)
+    norm = float(shape[2]) if d == 1 else float(shape[2] * shape[1])
+    for b, x in zip(backs, ins):
+        assert np.max(np.abs(b / norm - x)) / 255.0 < 1e-12
