@@ -18,7 +18,7 @@ import distributedfft_amd as dfft
 
 LINES, TILED, KMAJOR = 0, 1, 2
 S_LINES, S_KMAJOR, S_SAME, S_TRANSPOSE = 0, 1, 2, 3
-ESZ = 16      # the model runs fp64 plans: complex = 16 bytes, real = 8
+ESZ = {"double": 16, "float": 8}      # bytes per complex element; a real element is half of it
 
 
 def _seg(starts, lens, bases, n):
@@ -33,6 +33,7 @@ class Pass:
     """one launch descriptor + its per-point tables"""
 
     def __init__(self, plan, name, index=0):
+        self.esz = 16 if plan.precision == 1 else 8
         self.d = plan.debugPass(name, index)
         assert self.d is not None, (name, index)
         d = self.d
@@ -85,8 +86,8 @@ class Pass:
         d = self.d
         nin = N // 2 + 1 if mode == "c2r" else N
         nout = N // 2 + 1 if mode == "r2c" else N
-        src = src[d.in_off // (8 if mode == "r2c" else ESZ):]
-        dst = dst[d.out_off // (8 if mode == "c2r" else ESZ):]
+        src = src[d.in_off // (self.esz // 2 if mode == "r2c" else self.esz):]
+        dst = dst[d.out_off // (self.esz // 2 if mode == "c2r" else self.esz):]
         for a in range(d.na):
             for line in range(d.LB):
                 x = np.array([src[self.load_offset(a, line, n, nin)] for n in range(nin)])
@@ -103,19 +104,20 @@ class Pass:
 class World:
     """P virtual ranks of one plan class on a small fp64 grid"""
 
-    def __init__(self, cls, shape, P1, P2, c2c, chunks=None):
+    def __init__(self, cls, shape, P1, P2, c2c, chunks=None, precision="double"):
         self.shape, self.P1, self.P2, self.c2c = shape, P1, P2, c2c
+        self.esz = ESZ[precision]
         self.P = P1 * P2
         comm = dfft.Comm.local(self.P) if self.P > 1 else None
         self.plans = []
         for r in range(self.P):
-            pl = cls(dfft.Configurations(), comm, precision="double", rank=r)
+            pl = cls(dfft.Configurations(), comm, precision=precision, rank=r)
             if chunks is not None:
                 pl.setPipelineChunks(chunks)
             pl.initFFT(dfft.GlobalSize(*shape), dfft.Partition(P1, P2), allocate=False, c2c=c2c)
             self.plans.append(pl)
         self.C = self.plans[0].getPipelineChunks()
-        self.nel = [pl.getDomainSize() // ESZ for pl in self.plans]
+        self.nel = [pl.getDomainSize() // self.esz for pl in self.plans]
 
     def buffers(self, n=3):
         return [[np.full(self.nel[r], np.nan + 0j, dtype=np.complex128) for _ in range(n)] for r in range(self.P)]
@@ -133,8 +135,8 @@ class World:
             for q, peer in enumerate(grp):
                 psc, psd, _, _ = tabs[peer]
                 assert psc[me] == rc[q]
-                n = rc[q] // ESZ
-                recv[r][rd[q] // ESZ: rd[q] // ESZ + n] = send[peer][psd[me] // ESZ: psd[me] // ESZ + n]
+                n, e = rc[q] // self.esz, self.esz
+                recv[r][rd[q] // e: rd[q] // e + n] = send[peer][psd[me] // e: psd[me] // e + n]
 
     # -- chains ------------------------------------------------------------------------------
     def forward(self, ins, kind="default"):

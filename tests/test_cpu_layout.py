@@ -105,3 +105,23 @@ def test_partial_transform_descriptors(shape, P1, P2, d, c2c):
     norm = float(shape[2]) if d == 1 else float(shape[2] * shape[1])
     for b, x in zip(backs, ins):
         assert np.max(np.abs(b / norm - x)) / 255.0 < 1e-12
+
+
+@pytest.mark.parametrize("cls,kind,shape,P1,P2,chunks,prec", [
+    (dfft.MPIcuFFT_Pencil_Opt1, "default", (16, 16, 12), 4, 4, 2, "double"),      # 16 ranks
+    (dfft.MPIcuFFT_Slab_Opt1, "default", (32, 32, 6), 8, 1, 4, "double"),          # 8 peers x 4 chunks = 32 segments
+    (dfft.MPIcuFFT_Pencil_Opt1, "default", (12, 20, 36), 2, 2, 2, "float"),       # fp32: 16-line tiles
+    (dfft.MPIcuFFT_Pencil_Opt1, "default", (9, 7, 10), 3, 2, 3, "float"),
+    (dfft.MPIcuFFT_Slab_Z_Then_YX, "zyx", (32, 6, 40), 8, 1, 4, "double"),
+    (dfft.MPIcuFFT_Slab_Z_Then_YX, "zyx", (12, 18, 34), 3, 1, 2, "float"),
+])
+@pytest.mark.parametrize("c2c", [True, False])
+def test_many_ranks_max_segments_and_fp32_tiles(cls, kind, shape, P1, P2, chunks, prec, c2c):
+    w = World(cls, shape, P1, P2, c2c, chunks, precision=prec)
+    if (P1, chunks) == (8, 4):
+        assert w.C == 4       # 32 segments on the gathered axis: the MAXSEG limit of the kernels
+    g = global_field(shape, c2c)
+    ins = local_inputs(w, g)
+    outs = w.forward(ins, kind)
+    check_spectrum(w, outs, np.fft.fftn(g) if c2c else np.fft.rfftn(g))
+    check_round_trip(w, w.inverse(outs, kind), ins)
