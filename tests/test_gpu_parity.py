@@ -451,3 +451,24 @@ def test_sixteen_and_eighteen_ranks(shape, P1, P2):
         ref = want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]]
         assert np.max(np.abs(spec[r] - ref)) / np.max(np.abs(want)) < 2e-11
         assert rel(backs[r] / n3, ins[r]) < 1e-10
+
+
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_address_table_modes_agree(mode, monkeypatch):
+    """DFFT_TABLES: 0 = segment search per point, 2 = per-point tables on every tiled side (the
+    default uses tables only for sides with more than one segment).  All three must give the same
+    spectrum; covers C2C and R2C, pencil and slab, chunked."""
+    monkeypatch.setenv("DFFT_TABLES", mode)
+    for shape, P1, P2 in (((32, 32, 32), 2, 4), ((64, 32, 16), 8, 1), ((16, 16, 16), 1, 1)):
+        plans, ins, spec, backs = run_distributed(shape, P1, P2, "double", chunks=3)
+        want = orc.fft3d_c2c(orc.fill_block(shape, (0, 0, 0), shape, 2, seed=7), -1)
+        n3 = float(np.prod(shape))
+        for r, pl in enumerate(plans):
+            s, o = pl.getOutSize(), pl.getOutStart()
+            assert np.max(np.abs(spec[r] - want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]])) / np.max(np.abs(want)) < 1e-11
+            assert rel(backs[r] / n3, ins[r]) < 1e-10
+    plans, ins, spec, backs = run_distributed_real((32, 16, 64), 2, 2, "float")
+    wantr = orc.fft3d_r2c(orc.fill_block((32, 16, 64), (0, 0, 0), (32, 16, 64), 1, seed=13).astype(np.float32).astype(np.float64))
+    for r, pl in enumerate(plans):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        assert np.max(np.abs(spec[r] - wantr[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]])) / np.max(np.abs(wantr)) < 1e-4
