@@ -42,6 +42,8 @@ SYMBOLS = [
     ("dfft_set_work_area", _i, [_vp, _vp, _vp]),
     ("dfft_set_pipeline_chunks", _i, [_vp, _i]),
     ("dfft_get_pipeline_chunks", _i, [_vp]),
+    ("dfft_set_option", _i, [_vp, C.c_char_p, C.c_long]),
+    ("dfft_get_option", C.c_long, [_vp, C.c_char_p]),
     ("dfft_set_stream", _i, [_vp, _vp]),
     ("dfft_exec_r2c", _i, [_vp, _vp, _vp]),
     ("dfft_exec_c2r", _i, [_vp, _vp, _vp]),
@@ -52,6 +54,7 @@ SYMBOLS = [
     ("dfft_get_in_start", _i, [_vp, _psz]),
     ("dfft_get_out_size", _i, [_vp, _psz]),
     ("dfft_get_out_start", _i, [_vp, _psz]),
+    ("dfft_get_partition_dimensions", _i, [_vp, _i, _i, _psz, _psz, _sz, _psz]),
     ("dfft_domain_size", _sz, [_vp]),
     ("dfft_work_size_device", _sz, [_vp]),
     ("dfft_work_size_host", _sz, [_vp]),
@@ -66,6 +69,7 @@ SYMBOLS = [
     ("dfft_phase_name", C.c_char_p, [_i, _i]),
     ("dfft_enable_phase_timing", _i, [_vp, _i]),
     ("dfft_fft1d_batched", _i, [_i, _sz, _sz, _vp, _vp, _i, _vp]),
+    ("dfft_fft1d_batched_ex", _i, [_i, _sz, _sz, _vp, _vp, _i, _vp, _i, _i]),
     ("dfft_debug_get_pass", _i, [_vp, C.c_char_p, _i, C.POINTER(PassDesc)]),
     ("dfft_debug_get_point_table", _i, [_vp, C.c_char_p, _i, _i, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
                                         C.POINTER(C.c_uint32), _sz, _psz]),

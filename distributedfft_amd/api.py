@@ -53,6 +53,22 @@ class Pencil_Partition(Partition):
         super().__init__(P1, P2)
 
 
+class Partition_Dimensions:
+    """include/params.hpp:58-81"""
+
+    def __init__(self):
+        self.size_x, self.size_y, self.size_z = [], [], []
+        self.start_x, self.start_y, self.start_z = [], [], []
+
+    def computeOffsets(self):
+        for n in "xyz":
+            off, starts = 0, []
+            for v in getattr(self, "size_" + n):
+                starts.append(off)
+                off += v
+            setattr(self, "start_" + n, starts)
+
+
 @dataclass
 class Configurations:
     """include/params.hpp:85-93"""
@@ -181,6 +197,13 @@ class MPIcuFFT:
     def getPipelineChunks(self):
         return lib().dfft_get_pipeline_chunks(self._h)
 
+    def setOption(self, key, value):
+        """named tuning knob (dfft_set_option, include/dfft_c.h); effective at the next initFFT"""
+        check(lib().dfft_set_option(self._h, key.encode(), int(value)))
+
+    def getOption(self, key):
+        return lib().dfft_get_option(self._h, key.encode())
+
     def setStream(self, stream):
         """HIP stream (int handle, e.g. torch.cuda.current_stream().cuda_stream)"""
         check(lib().dfft_set_stream(self._h, C.c_void_p(int(stream))))
@@ -231,6 +254,22 @@ class MPIcuFFT:
 
     def getOutStart(self):
         return self._get3(lib().dfft_get_out_start)
+
+    def getPartitionDimensions(self):
+        """(input_dim, transposed_dim, output_dim) of include/mpicufft_pencil.hpp:112-116, each a
+        Partition_Dimensions with size_x/y/z and start_x/y/z lists (include/params.hpp:58-81)"""
+        dims = []
+        for which in range(3):
+            d = Partition_Dimensions()
+            for axis, name in enumerate("xyz"):
+                n = C.c_size_t(0)
+                check(lib().dfft_get_partition_dimensions(self._h, which, axis, None, None, 0, C.byref(n)))
+                sz, st = (C.c_size_t * n.value)(), (C.c_size_t * n.value)()
+                check(lib().dfft_get_partition_dimensions(self._h, which, axis, sz, st, n.value, C.byref(n)))
+                setattr(d, "size_" + name, list(sz))
+                setattr(d, "start_" + name, list(st))
+            dims.append(d)
+        return tuple(dims)
 
     def getDomainSize(self):
         return lib().dfft_domain_size(self._h)
@@ -294,7 +333,8 @@ class MPIcuFFT_Slab(MPIcuFFT):
     _kind = 0
 
 
-class MPIcuFFT_Slab_Opt1(MPIcuFFT):
+class MPIcuFFT_Slab_Opt1(MPIcuFFT_Slab):
+    """include/mpicufft_slab_opt1.hpp:70 (derives from MPIcuFFT_Slab)"""
     _kind = 1
 
 
@@ -303,7 +343,7 @@ class MPIcuFFT_Slab_Z_Then_YX(MPIcuFFT):
     _kind = 4
 
 
-class MPIcuFFT_Slab_Z_Then_YX_Opt1(MPIcuFFT):
+class MPIcuFFT_Slab_Z_Then_YX_Opt1(MPIcuFFT_Slab_Z_Then_YX):
     _kind = 5
 
 
@@ -316,14 +356,16 @@ class MPIcuFFT_Pencil(MPIcuFFT):
     _kind = 2
 
 
-class MPIcuFFT_Pencil_Opt1(MPIcuFFT):
+class MPIcuFFT_Pencil_Opt1(MPIcuFFT_Pencil):
+    """include/mpicufft_pencil_opt1.hpp:23 (derives from MPIcuFFT_Pencil)"""
     _kind = 3
 
 
-def fft1d_batched(out, in_, N, batch, direction=FORWARD, precision="double", stream=0):
+def fft1d_batched(out, in_, N, batch, direction=FORWARD, precision="double", stream=0, variant=0, debug=0):
     """one axis pass on natural lines [batch][N] (kernel-level entry point)"""
     prec = {"double": 1, "float": 0}[precision]
-    check(lib().dfft_fft1d_batched(prec, N, batch, _ptr(out), _ptr(in_), direction, C.c_void_p(int(stream))))
+    check(lib().dfft_fft1d_batched_ex(prec, N, batch, _ptr(out), _ptr(in_), direction, C.c_void_p(int(stream)),
+                                      int(variant), int(debug)))
 
 
 def kernel_info(N, precision="double"):

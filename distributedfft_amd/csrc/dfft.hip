@@ -233,6 +233,19 @@ struct Pipeline {
 
 struct TimedSpan { hipEvent_t a = nullptr, b = nullptr; int phase = 0; bool used = false; };
 
+// Tuning knobs of a plan (dfft_set_option; a few have environment defaults read once at plan creation).
+// Nothing here is read on the execution path.
+struct Options {
+    int chunks = 0;          // requested pipeline depth (0 = default)
+    int mirror = 0;          // single-rank complex inverse in the mirrored (multi-rank) pass order x, y, z
+    int tables = 1;          // per-point address tables: 0 never, 1 sides with more than one segment, 2 always
+    int shift = -1;          // row-aligned tile windows of odd-pitch point-major stores: -1 auto (fp64), 0 off, 2 always
+    int debug = 0;           // PassArgs::debug of every launch (measurement only; results are wrong when set)
+    int real_variant = 0;    // A/B configurations of the real z passes (DFFT_EXPERIMENTS builds)
+    int order[6] = {-1, -1, -1, -1, -1, -1};     // workgroup->tile order per pass: fz fy fx ix iy iz; a_fastest + 2*xcd_swizzle
+    int variant[6] = {-1, -1, -1, -1, -1, -1};   // kernel configuration per pass, same order (-1 = the plan's choice)
+};
+
 struct dfft_plan {
     int kind = DFFT_PENCIL_OPT1, prec = DFFT_F64;
     dfft_config cfg{};
@@ -260,7 +273,7 @@ struct dfft_plan {
     std::vector<size_t> sc1, sd1, rc1, rd1, sc2, sd2, rc2, rd2;
     std::vector<int> group1, group2;
     int vfwd[3] = {0, 0, 0}, vinv[3] = {0, 0, 0};   // kernel variant per pass: [0]=z [1]=y [2]=x
-    int chunks_req = 0;          // requested pipeline depth (0 = default)
+    Options opt;
     Pipeline pl;
     // phase timing: (start, stop) event pairs, phases 0..4 = z, exchange 1, y, exchange 2, x
     bool timing = false;
@@ -299,11 +312,10 @@ static PassArgs pass_args(int TL, size_t na, size_t LB, int load_kind, int store
 static void set_shift(const dfft_plan *p, PassArgs &X)
 {
     const uint32_t TL = (uint32_t)p->TL;
-    const char *v = getenv("DFFT_SHIFT");
-    if (v && atoi(v) == 0) return;
+    if (p->opt.shift == 0) return;
     if (p->ax[2].bluestein) return;               // the Bluestein kernel has no shifted windows
     // fp32 (16-line tiles of 8-byte points) measured 10 % slower with shifted windows, fp64 24 % faster
-    if (p->prec != DFFT_F64 && !(v && atoi(v) == 2)) return;
+    if (p->prec != DFFT_F64 && p->opt.shift != 2) return;
     if (X.AS_out % TL == 0 || X.KS_out % TL != 0 || X.LB < TL) return;
     X.shift = 1;
     X.nb += 1;
@@ -669,7 +681,7 @@ static int launch(dfft_plan *p, const Launch &L, int variant, int axis, const ch
     if (L.args.ntiles == 0) return 0;
     const Axis &ax = p->ax[axis];
     PassArgs A = L.args;
-    A.in = in + L.in_off; A.out = out + L.out_off; A.tw = ax.tw;
+    A.in = in + L.in_off; A.out = out + L.out_off; A.tw = ax.tw; A.debug = p->opt.debug;
     fill_tables(p, L, A);
     if (!ax.bluestein) return launch_pass(p->prec, (int)ax.N, variant, A, p->stream);
     A.tw2 = ax.chirp; A.tw3 = ax.bhat; A.NL = (uint32_t)ax.N; A.NK = (uint32_t)ax.N; A.real_mode = 0;
@@ -686,12 +698,15 @@ static int launch_real(dfft_plan *p, const Launch &L, int mode, const char *in, 
     if (L.args.ntiles == 0) return 0;
     const Axis &ax = p->ax[0];
     PassArgs A = L.args;
-    A.in = in + L.in_off; A.out = out + L.out_off; A.tw = ax.tw; A.tw2 = p->tw_zr;
+    A.in = in + L.in_off; A.out = out + L.out_off; A.tw = ax.tw; A.tw2 = p->tw_zr; A.debug = p->opt.debug;
     fill_tables(p, L, A);
     int r;
     if (p->zreal_native) {
         const int M = (int)(p->Nz / 2);
-        r = p->prec == DFFT_F64 ? launch_real_f64(M, mode, A, p->stream) : launch_real_f32(M, mode, A, p->stream);
+        r = p->prec == DFFT_F64 ? launch_real_f64(M, mode, p->opt.real_variant, A, p->stream)
+                                : launch_real_f32(M, mode, p->opt.real_variant, A, p->stream);
+    } else if (!ax.bluestein) {
+        return fail(ERR_UNSUPPORTED, "real z pass without a native or Bluestein plan");      // (dfft_init rules this out)
     } else {
         A.tw2 = ax.chirp; A.tw3 = ax.bhat; A.NL = (uint32_t)p->Nz; A.NK = (uint32_t)p->Nzc; A.real_mode = mode;
         r = p->prec == DFFT_F64 ? launch_bluestein_f64((int)ax.M, A, p->stream) : launch_bluestein_f32((int)ax.M, A, p->stream);
@@ -848,7 +863,7 @@ static int enqueue_inverse(dfft_plan *p, void *out, void *in)
     hipStream_t Sc = p->stream, Sm = pl.comm_stream;
     hipStream_t Sm2 = (pl.comm_stream2 && p->comm && p->comm->concurrent_channels()) ? pl.comm_stream2 : Sm;
     p->nspans = 0; p->last_dir = DFFT_INVERSE;
-    if (p->nranks == 1 && p->c2c) {
+    if (p->nranks == 1 && p->c2c && !p->opt.mirror) {
         // single rank, complex: input and output are both natural [x][y][z], so the inverse may use
         // the forward pass order (z, y, x) with conjugation -- it avoids the strided *read* of the
         // x-first order (the fft3d branch of the reference is one cuFFT plan, order is not observable)
@@ -1087,6 +1102,16 @@ static int check_ready(dfft_plan *p)
 
 static int ensure_device_state(dfft_plan *p);
 
+// environment defaults of the user-facing knobs, read once per plan (never on the execution path)
+static void env_defaults(Options &o)
+{
+    auto geti = [](const char *name, int &dst) { if (const char *v = getenv(name)) dst = atoi(v); };
+    geti("DFFT_CHUNKS", o.chunks);
+    geti("DFFT_TABLES", o.tables);
+    geti("DFFT_SHIFT", o.shift);
+    geti("DFFT_MIRROR", o.mirror);
+}
+
 extern "C" {
 
 const char *dfft_last_error(void) { return g_error.c_str(); }
@@ -1135,8 +1160,39 @@ int dfft_plan_create(dfft_plan **plan, int kind, int precision, const dfft_confi
     if (p->rank < 0 || p->rank >= p->nranks) { delete p; return fail(ERR_ARG, "rank outside the world"); }
     p->esz = precision == DFFT_F64 ? 16 : 8;
     p->TL = precision == DFFT_F64 ? TL_F64 : TL_F32;
+    env_defaults(p->opt);
     *plan = p;
     return 0;
+}
+
+static const char *const kPassNames[6] = {"fz", "fy", "fx", "ix", "iy", "iz"};
+static int *option_slot(Options &o, const std::string &k)
+{
+    if (k == "pipeline_chunks") return &o.chunks;
+    if (k == "mirror_inverse") return &o.mirror;
+    if (k == "point_tables") return &o.tables;
+    if (k == "shift") return &o.shift;
+    if (k == "debug_skip") return &o.debug;
+    if (k == "real_variant") return &o.real_variant;
+    for (int i = 0; i < 6; i++) {
+        if (k == std::string("variant_") + kPassNames[i]) return &o.variant[i];
+        if (k == std::string("order_") + kPassNames[i]) return &o.order[i];
+    }
+    return nullptr;
+}
+int dfft_set_option(dfft_plan *p, const char *key, long value)
+{
+    if (!p || !key) return fail(ERR_ARG, "null plan or key");
+    int *slot = option_slot(p->opt, key);
+    if (!slot) return fail(ERR_ARG, std::string("unknown option ") + key);
+    *slot = (int)value;      // takes effect at the next dfft_init (debug_skip / mirror_inverse / real_variant: next exec)
+    return 0;
+}
+long dfft_get_option(dfft_plan *p, const char *key)
+{
+    if (!p || !key) return -1;
+    int *slot = option_slot(p->opt, key);
+    return slot ? *slot : -1;
 }
 
 int dfft_plan_destroy(dfft_plan *p)
@@ -1175,7 +1231,11 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         const size_t zlen = zr_native ? Nz / 2 : Nz;
         // Y_Then_ZX, R2C: the y pass reads real lines in place, which only the Bluestein kernel does
         const bool yok = yzx && !c2c ? axis_plan_bluestein(p->prec, Ny, ay) : axis_plan(p->prec, Ny, ay);
-        if (!axis_plan(p->prec, zlen, az) || !yok || !axis_plan(p->prec, Nx, axx))
+        // a real z pass is either the packed Nz/2-point kernel or the Bluestein kernel's real modes: never
+        // the plain complex chain (Nz == 2 would otherwise pick it and launch Bluestein without its tables)
+        const bool zreal_generic = !yzx && !c2c && !zr_native;
+        const bool zok = zreal_generic ? axis_plan_bluestein(p->prec, Nz, az) : axis_plan(p->prec, zlen, az);
+        if (!zok || !yok || !axis_plan(p->prec, Nx, axx))
             return fail(ERR_UNSUPPORTED, yzx && !c2c && Ny > 1024 ? "unsupported axis length (Y_Then_ZX R2C: Ny up to 1024)"
                         : "unsupported axis length (powers of two up to 2048, any other length up to 1024)");
         for (auto &a : p->ax) axis_free(a);
@@ -1233,8 +1293,7 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
     }
     // pipeline depth: chunks of the outer axis exchanged while the next chunk is transformed
     {
-        int C = p->chunks_req;
-        if (C <= 0) if (const char *v = getenv("DFFT_CHUNKS")) C = atoi(v);
+        int C = p->opt.chunks;
         if (C <= 0) C = nexch ? 4 : 1;
         size_t lim = (size_t)MAXSEG / (size_t)P1;            // segments of the x / ky axis = P1 * C
         for (int q = 0; q < P1; q++) lim = std::min({lim, p->xs[q], zyx ? p->xs[q] : p->yo[q]});
@@ -1265,29 +1324,16 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
                 if (!p->ax[ax].bluestein && pass_info_f32((int)p->ax[ax].N, 6, &vi)) { p->vfwd[ax] = 6; p->vinv[ax] = 6; }
         }
     }
-    if (const char *v = getenv("DFFT_ORDER")) {   // experiment hook: per pass digit = a_fastest + 2*xcd_swizzle (fwd z,y,x then inv x,y,z)
-        int k = 0;
-        for (const char *c = v; *c && k < 6; c++) {
-            if (*c < '0' || *c > '9') continue;
-            const int d = *c - '0';
-            auto set = [&](Launch &L) { L.args.a_fastest = d & 1; L.args.xcd_swizzle = (d >> 1) & 1; };
-            Pipeline &pl = p->pl;
-            if (k == 0) for (auto &L : pl.fz) set(L);
-            if (k == 1) for (auto &L : pl.fy) set(L);
-            if (k == 2) set(pl.fx);
-            if (k == 3) for (auto &L : pl.ix) set(L);
-            if (k == 4) for (auto &L : pl.iy) set(L);
-            if (k == 5) for (auto &L : pl.iz) set(L);
-            k++;
-        }
-    }
-    // experiment hook: DFFT_VARIANTS="zyx xyz" digits = kernel variant of fwd z,y,x then inv x,y,z
-    if (const char *v = getenv("DFFT_VARIANTS")) {
-        int k = 0;
-        for (const char *c = v; *c && k < 6; c++) {
-            if (*c < '0' || *c > '9') continue;
-            if (k < 3) p->vfwd[k] = *c - '0'; else p->vinv[5 - k] = *c - '0';
-            k++;
+    {   // per-pass overrides (dfft_set_option): fz fy fx ix iy iz
+        Pipeline &pl = p->pl;
+        std::vector<Launch> *vecs[6] = {&pl.fz, &pl.fy, nullptr, &pl.ix, &pl.iy, &pl.iz};
+        for (int k = 0; k < 6; k++) {
+            const int d = p->opt.order[k];
+            if (d >= 0) {
+                auto set = [&](Launch &L) { L.args.a_fastest = d & 1; L.args.xcd_swizzle = (d >> 1) & 1; };
+                if (k == 2) set(pl.fx); else for (auto &L : *vecs[k]) set(L);
+            }
+            if (p->opt.variant[k] >= 0) (k < 3 ? p->vfwd[k] : p->vinv[5 - k]) = p->opt.variant[k];
         }
     }
     for (auto &a : p->ax) axis_free(a);
@@ -1332,8 +1378,7 @@ static int upload_tables(dfft_plan *p)
     Pipeline &pl = p->pl;
     // DFFT_TABLES: 0 = search the segment table per point, 1 = per-point tables for launches with
     // more than one segment (default), 2 = tables for every tiled load / store
-    int mode = 1;
-    if (const char *v = getenv("DFFT_TABLES")) mode = atoi(v);
+    const int mode = p->opt.tables;
     std::vector<Launch *> all;
     for (auto *v : {&pl.fz, &pl.fy, &pl.ix, &pl.iy, &pl.iz, &pl.py2, &pl.qy2, &pl.zy, &pl.ziy}) for (auto &L : *v) all.push_back(&L);
     all.push_back(&pl.fx); all.push_back(&pl.pz1); all.push_back(&pl.qz1); all.push_back(&pl.zix); all.push_back(&pl.yz);
@@ -1400,8 +1445,7 @@ int dfft_set_pipeline_chunks(dfft_plan *p, int chunks)
 {
     if (!p) return fail(ERR_ARG, "null plan");
     if (chunks < 0) return fail(ERR_ARG, "chunks must be >= 0");
-    if (p->initialized) return fail(ERR_STATE, "set the pipeline depth before initFFT");
-    p->chunks_req = chunks;
+    p->opt.chunks = chunks;      // takes effect at the next dfft_init
     return 0;
 }
 int dfft_get_pipeline_chunks(const dfft_plan *p) { return p ? p->pl.C : 0; }
@@ -1450,8 +1494,16 @@ int dfft_exchange(dfft_plan *p, int which, int direction, const void *sendbuf, v
 {
     if (!p || !p->initialized) return fail(ERR_STATE, "plan not initialised");
     if (which != 1 && which != 2) return fail(ERR_ARG, "which must be 1 or 2");
+    // host-only callers (callback transport on a machine without a GPU) have no stream to drain; with a
+    // device the exchange always runs on a stream of the plan and is complete on return
+    int ndev = 0;
+    const bool gpu = hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0;
+    if (gpu && !p->stream && !p->stream_user) {
+        HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+        p->stream_owned = true;
+    }
     if ((which == 1 ? p->P2 : p->P1) > 1) TRY(exchange(p, which, direction != DFFT_INVERSE, sendbuf, recvbuf));
-    if (p->stream || p->stream_user) HIP_TRY(hipStreamSynchronize(p->stream));
+    if (gpu) HIP_TRY(hipStreamSynchronize(p->stream));
     return 0;
 }
 
@@ -1498,6 +1550,31 @@ int dfft_get_out_start(const dfft_plan *p, size_t s[3])
     if (!p || !p->initialized) return fail(ERR_STATE, "plan not initialised");
     s[0] = 0; s[1] = p->yostart[p->pi]; s[2] = p->zstart[p->pj];
     if (p->zyx) { s[1] = 0; s[2] = p->zstart[p->pi]; }
+    return 0;
+}
+int dfft_get_partition_dimensions(const dfft_plan *p, int which, int axis, size_t *sizes, size_t *starts, size_t capacity,
+                                  size_t *count)
+{
+    if (!p || !p->initialized) return fail(ERR_STATE, "plan not initialised");
+    if (which < 0 || which > 2 || axis < 0 || axis > 2) return fail(ERR_ARG, "which and axis must be 0, 1 or 2");
+    // input_dim / transposed_dim / output_dim of src/pencil/mpicufft_pencil_opt1.cpp:70-93; an axis that is not
+    // split at that stage has one entry holding its full extent
+    const std::vector<size_t> one_x{p->Nx}, one_y{which == 2 ? p->Nyc : p->Ny}, one_z{which == 0 ? p->Nz : p->Nzc}, zero{0};
+    const std::vector<size_t> *sz = nullptr, *st = &zero;
+    if (axis == 0) {
+        if (which == 2) sz = &one_x; else { sz = &p->xs; st = &p->xstart; }
+    } else if (axis == 1) {
+        if (which == 0) { sz = &p->ys; st = &p->ystart; }
+        else if (which == 1 || p->zyx) sz = &one_y;
+        else { sz = &p->yo; st = &p->yostart; }
+    } else {
+        if (which == 0 || p->yzx) sz = &one_z; else { sz = &p->zs; st = &p->zstart; }
+    }
+    if (count) *count = sz->size();
+    for (size_t i = 0; i < sz->size() && i < capacity; i++) {
+        if (sizes) sizes[i] = (*sz)[i];
+        if (starts) starts[i] = st->size() == sz->size() ? (*st)[i] : 0;
+    }
     return 0;
 }
 size_t dfft_domain_size(const dfft_plan *p) { return p ? p->domainsize : 0; }
@@ -1624,32 +1701,41 @@ const char *dfft_phase_name(int phase, int direction)
     return direction == DFFT_INVERSE ? b[phase] : f[phase];
 }
 
-int dfft_fft1d_batched(int precision, size_t N, size_t batch, void *out, const void *in, int direction,
-                       void *hip_stream)
+int dfft_fft1d_batched_ex(int precision, size_t N, size_t batch, void *out, const void *in, int direction,
+                          void *hip_stream, int variant, int debug)
 {
     static thread_local Axis ax;
     static thread_local int axP = -1;
     if (ax.N != N || axP != precision) {
         axis_free(ax);
         ax = Axis();
-        if (!axis_plan(precision, N, ax)) return fail(ERR_UNSUPPORTED, "unsupported line length");
-        TRY(axis_upload(precision, ax));
+        axP = -1;
+        if (!axis_plan(precision, N, ax)) { ax = Axis(); return fail(ERR_UNSUPPORTED, "unsupported line length"); }
+        if (int r = axis_upload(precision, ax)) { axis_free(ax); ax = Axis(); return r; }
         axP = precision;
     }
     PassInfo pi;
-    pass_info(precision, (int)ax.M, &pi);
+    const bool has = !ax.bluestein && variant ? (precision == DFFT_F64 ? pass_info_f64((int)ax.M, variant, &pi) : pass_info_f32((int)ax.M, variant, &pi)) : false;
+    if (!has) {
+        variant = 0;
+        if (!pass_info(precision, (int)ax.M, &pi)) return fail(ERR_UNSUPPORTED, "unsupported line length");
+    }
     PassArgs A;
     memset(&A, 0, sizeof(A));
-    A.in = in; A.out = out; A.tw = ax.tw;
+    A.in = in; A.out = out; A.tw = ax.tw; A.debug = debug;
     A.na = 1; A.LB = (uint32_t)batch; A.nb = ((uint32_t)batch + pi.TL - 1) / pi.TL; A.ntiles = A.nb;
     A.load_kind = LOAD_LINES; A.store_kind = STORE_LINES; A.swap = direction == DFFT_INVERSE;
-    if (!ax.bluestein)
-        return launch_pass(precision, (int)N, getenv("DFFT_VARIANT_1D") ? atoi(getenv("DFFT_VARIANT_1D")) : 0, A, (hipStream_t)hip_stream);
+    if (!ax.bluestein) return launch_pass(precision, (int)N, variant, A, (hipStream_t)hip_stream);
     A.tw2 = ax.chirp; A.tw3 = ax.bhat; A.NL = (uint32_t)N; A.NK = (uint32_t)N;
     int r = precision == DFFT_F64 ? launch_bluestein_f64((int)ax.M, A, (hipStream_t)hip_stream)
                                   : launch_bluestein_f32((int)ax.M, A, (hipStream_t)hip_stream);
     if (r != 0) return fail(r == -1 ? ERR_UNSUPPORTED : r, "Bluestein launch failed");
     return 0;
+}
+int dfft_fft1d_batched(int precision, size_t N, size_t batch, void *out, const void *in, int direction,
+                       void *hip_stream)
+{
+    return dfft_fft1d_batched_ex(precision, N, batch, out, in, direction, hip_stream, 0, 0);
 }
 
 int dfft_kernel_info(int precision, size_t N, int *threads, int *lds_bytes, int *points_per_thread,

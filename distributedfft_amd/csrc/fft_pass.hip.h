@@ -22,7 +22,7 @@
 //    TL x TL (1 KiB) or TL (128 B) contiguous runs.  Per-peer blocks stay contiguous and have
 //    exactly the reference's all-to-all byte counts/displacements
 //    (mpicufft_pencil_opt1.cpp:269-273, 315-319) -- only the order inside a block differs.
-//  * The inverse transform reuses the forward butterflies via the re<->im swap identity.
+//  * The inverse transform reuses the forward butterflies: conj(forward(conj(x))).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -81,6 +81,8 @@ struct PassArgs {
     int32_t a_fastest;     // workgroup -> tile order: 0: b fastest (w = a*nb + b), 1: a fastest (w = b*na + a)
     int32_t xcd_swizzle;   // 1: consecutive tiles go to the same XCD (block b runs on XCD b % 8), so that
                            //    neighbouring tiles that share a cache line meet in one L2
+    int32_t debug;         // measurement only: bit 0 = skip the transform (the pass becomes a copy with the same
+                           //    access pattern: its time is the pattern's own roofline), results are then wrong
     int32_t shift;         // 1: STORE_KMAJOR with an odd row pitch: tile windows follow the cache lines of each
                            //    output row (nb counts one extra tile per row); fft_pass_kernel only
     uint32_t LA;           // STORE_TILED_SAME: extent of the a axis
@@ -117,39 +119,47 @@ constexpr int brev(int m, int R)
     return r;
 }
 
-// cos/sin(2*pi*j/32), j = 0..8 (one octant + 1); everything else by symmetry
-__device__ constexpr double kCos32[9] = {1.0,
-                                         0.98078528040323044913,
-                                         0.92387953251128675613,
-                                         0.83146961230254523708,
-                                         0.70710678118654752440,
-                                         0.55557023301960222474,
-                                         0.38268343236508977173,
-                                         0.19509032201612826785,
-                                         0.0};
-constexpr double cos32(int j)
+// cos(2*pi*j/64), j = 0..16 (one octant + 1); everything else by symmetry
+__device__ constexpr double kCos64[17] = {1.0,
+                                          0.99518472667219688624,
+                                          0.98078528040323044913,
+                                          0.95694033573220886494,
+                                          0.92387953251128675613,
+                                          0.88192126434835502971,
+                                          0.83146961230254523708,
+                                          0.77301045336273696081,
+                                          0.70710678118654752440,
+                                          0.63439328416364549822,
+                                          0.55557023301960222474,
+                                          0.47139673682599764856,
+                                          0.38268343236508977173,
+                                          0.29028467725446236764,
+                                          0.19509032201612826785,
+                                          0.09801714032956060199,
+                                          0.0};
+constexpr double cos64(int j)
 {
-    // j in [0, 32)
-    j &= 31;
-    if (j > 16) j = 32 - j;           // cos even about 16
-    if (j > 8) return -kCos32[16 - j];
-    return kCos32[j];
+    j &= 63;
+    if (j > 32) j = 64 - j;           // cos even about 32
+    if (j > 16) return -kCos64[32 - j];
+    return kCos64[j];
 }
-constexpr double sin32(int j) { return cos32((j + 24) & 31); }   // sin(x) = cos(x - pi/2)
+constexpr double sin64(int j) { return cos64((j + 48) & 63); }   // sin(x) = cos(x - pi/2)
 
 // multiply by exp(-2*pi*i*J/R) (forward kernel), compile-time J, trivial cases folded
 template <int R, int J, typename C> __device__ __forceinline__ C mul_w(C d)
 {
     using T = decltype(d.x);
-    constexpr int j32 = (J * (32 / R)) & 31;
-    if constexpr (j32 == 0) return d;
-    else if constexpr (j32 == 8) { C r; r.x = d.y; r.y = -d.x; return r; }           // * -i
-    else if constexpr (j32 == 16) { C r; r.x = -d.x; r.y = -d.y; return r; }
-    else if constexpr (j32 == 24) { C r; r.x = -d.y; r.y = d.x; return r; }          // * +i
-    else if constexpr (j32 == 4) { constexpr T s = (T)0.70710678118654752440; C r; r.x = (d.x + d.y) * s; r.y = (d.y - d.x) * s; return r; }
-    else if constexpr (j32 == 12) { constexpr T s = (T)0.70710678118654752440; C r; r.x = (d.y - d.x) * s; r.y = -(d.x + d.y) * s; return r; }
+    static_assert(R <= 64, "radix-R butterflies up to 64");
+    constexpr int j64 = (J * (64 / R)) & 63;
+    if constexpr (j64 == 0) return d;
+    else if constexpr (j64 == 16) { C r; r.x = d.y; r.y = -d.x; return r; }           // * -i
+    else if constexpr (j64 == 32) { C r; r.x = -d.x; r.y = -d.y; return r; }
+    else if constexpr (j64 == 48) { C r; r.x = -d.y; r.y = d.x; return r; }          // * +i
+    else if constexpr (j64 == 8) { constexpr T s = (T)0.70710678118654752440; C r; r.x = (d.x + d.y) * s; r.y = (d.y - d.x) * s; return r; }
+    else if constexpr (j64 == 24) { constexpr T s = (T)0.70710678118654752440; C r; r.x = (d.y - d.x) * s; r.y = -(d.x + d.y) * s; return r; }
     else {
-        constexpr T c = (T)cos32(j32), s = (T)sin32(j32);   // w = c - i s
+        constexpr T c = (T)cos64(j64), s = (T)sin64(j64);   // w = c - i s
         C r;
         r.x = d.x * c + d.y * s;
         r.y = d.y * c - d.x * s;
@@ -189,15 +199,21 @@ template <int R, int OFF, int STRIDE, typename C> struct Dif {
 //      The point-fastest forms exist for fp32: with 8-byte points and 16-line tiles a line-fastest
 //      wave touches natural lines and transposed tiles in 32-byte pieces; point fastest makes
 //      those accesses 128-byte runs.  The LDS exchange between passes does the re-mapping for free.
-template <typename R, int N, int E, int TL, int G, int R1, int R2, int R3, int R4, int PLANES, int TWCHAIN = 0, int NTMEM = 0, int MAP = 0>
+// SUB: sub-tile workgroups.  The layouts interleave TL lines per tile; with SUB = 2 a workgroup transforms
+//      only TL/2 of them (half the on-chip footprint: two workgroups per CU at N = 2048) and its sibling
+//      (the next logical workgroup, kept on the same XCD so that L2 sees both halves of every 128-byte
+//      run) the rest.  Only fft_pass_kernel; needs G == 1.
+template <typename R, int N, int E, int TL, int G, int R1, int R2, int R3, int R4, int PLANES, int TWCHAIN = 0, int NTMEM = 0, int MAP = 0, int SUB = 1>
 struct PassCfg {
     using real = R;
     using C = typename Vec2<R>::type;
     static constexpr int kN = N, kE = E, kTL = TL, kG = G;
     static constexpr int r1 = R1, r2 = R2, r3 = R3, r4 = R4, kPLANES = PLANES, kTWCHAIN = TWCHAIN, kNTMEM = NTMEM, kMAP = MAP;
+    static constexpr int kSUB = SUB, TLK = TL / SUB;  // lines of a tile one workgroup transforms
     static constexpr int RLAST = R4 > 1 ? R4 : (R3 > 1 ? R3 : (R2 > 1 ? R2 : R1));
     static constexpr int NT = N / E;                 // threads per line
-    static constexpr int TW = TL * G;                // lines per workgroup
+    static constexpr int TW = TLK * G;               // lines per workgroup
+    static_assert(SUB == 1 || (G == 1 && TL % SUB == 0), "sub-tile workgroups need G == 1");
     static constexpr int THREADS = NT * TW;
     static constexpr int NPASS = (R1 > 1) + (R2 > 1) + (R3 > 1) + (R4 > 1);
     static constexpr int PS = ilog2(R1 * TW);        // pad once per first-pass scatter stride ...
@@ -286,6 +302,28 @@ template <typename Cfg> __device__ __forceinline__ int lds_slot(int lw, int n)
     else return lw * Cfg::PITCH + n + (n >> 5);
 }
 
+// Slot of point n0 + dn when dn is a compile-time constant whose padding separates from n0's
+// (no carry into the padded bits): slot(n0 + dn) = slot(n0) + lds_slot_off(dn).  The per-point LDS
+// addresses of a scatter / gather then are one computed base plus immediate offsets.
+template <typename Cfg> constexpr int lds_slot_off(int dn)
+{
+    if constexpr (Cfg::kMAP == 0) return dn * Cfg::TW + (((dn * Cfg::TW) >> Cfg::PS) << Cfg::PWS);
+    else return dn + (dn >> 5);
+}
+// scatter of pass (RP, NS): point offsets are m*NS.  Line-fastest plane: separable because NS is 1 (then
+// RP == R1 and m*TW stays below the padded block) or a multiple of R1.  Line-major plane: 32-point pad blocks.
+template <typename Cfg, int RP, int NS> constexpr bool scatter_separable()
+{
+    if constexpr (Cfg::kMAP == 0) return NS == 1 ? RP == Cfg::r1 : NS % Cfg::r1 == 0;
+    else return NS == 1 ? RP % 32 == 0 : NS % 32 == 0;
+}
+// gather: point offsets are NT*c
+template <typename Cfg> constexpr bool gather_separable()
+{
+    if constexpr (Cfg::kMAP == 0) return Cfg::NT % Cfg::r1 == 0;
+    else return Cfg::NT % 32 == 0;
+}
+
 // scatter the outputs of pass (RP, NS) to LDS plane, Stockham output index
 template <typename Cfg, int RP, int NS, int COMP>
 __device__ __forceinline__ void lds_scatter(const typename Cfg::C *v, typename Cfg::real *plane, int t, int lw)
@@ -296,10 +334,13 @@ __device__ __forceinline__ void lds_scatter(const typename Cfg::C *v, typename C
         const int j = t + Cfg::NT * i;
         const int k = j & (NS - 1);
         const int nbase = (j - k) * RP + k;       // (j/NS)*NS*RP + k
+        const int base = lds_slot<Cfg>(lw, nbase);
         static_for<0, RP>([&](auto mc) {
             constexpr int mr = decltype(mc)::value;          // register slot
             constexpr int m = brev(mr, RP);                  // output index of that slot
-            const int idx = lds_slot<Cfg>(lw, nbase + m * NS);
+            int idx;
+            if constexpr (scatter_separable<Cfg, RP, NS>()) idx = base + lds_slot_off<Cfg>(m * NS);
+            else idx = lds_slot<Cfg>(lw, nbase + m * NS);
             plane[idx] = COMP == 0 ? v[i + mr * S].x : v[i + mr * S].y;
         });
     });
@@ -307,9 +348,12 @@ __device__ __forceinline__ void lds_scatter(const typename Cfg::C *v, typename C
 template <typename Cfg, int COMP>
 __device__ __forceinline__ void lds_gather(typename Cfg::C *v, const typename Cfg::real *plane, int t, int lw)
 {
+    const int base = lds_slot<Cfg>(lw, t);
     static_for<0, Cfg::kE>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
-        const int idx = lds_slot<Cfg>(lw, t + Cfg::NT * c);
+        int idx;
+        if constexpr (gather_separable<Cfg>()) idx = base + lds_slot_off<Cfg>(Cfg::NT * c);
+        else idx = lds_slot<Cfg>(lw, t + Cfg::NT * c);
         if (COMP == 0) v[c].x = plane[idx]; else v[c].y = plane[idx];
     });
 }
@@ -381,10 +425,10 @@ __device__ __forceinline__ SegEntry seg_entry(const SegEntry *p)
 }
 
 // logical workgroup index: identity, or the XCD-aware remap of the guide (T1, bijective form)
-__device__ __forceinline__ uint32_t logical_block(const PassArgs &A)
+template <bool ALWAYS = false> __device__ __forceinline__ uint32_t logical_block(const PassArgs &A)
 {
     const uint32_t id = blockIdx.x;
-    if (!A.xcd_swizzle) return id;
+    if (!ALWAYS && !A.xcd_swizzle) return id;
     const uint32_t cpx = gridDim.x >> 3;
     return id < (cpx << 3) ? (id & 7) * cpx + (id >> 3) : id;
 }
@@ -426,15 +470,20 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
     thread_map<Cfg, PF_REST>(tid, lw2, t2);
 
     // tile of a line (workgroup index, b fastest or a fastest, optionally XCD-remapped)
-    const uint32_t blk = logical_block(A);
+    const uint32_t blk = logical_block<(Cfg::kSUB > 1)>(A);
     // e = index of the lane's line along the tiled axis.  With A.shift (point-major stores whose
     // row pitch is not a multiple of the tile) the window of a workgroup is moved back by the row's
     // misalignment, so that its TL stores per point fill exactly one aligned 128-byte line; (b, l, tw)
     // then describe where that line lives in the (unshifted) tiled input.
     auto tile_of = [&](int lwx, uint32_t &a, uint32_t &b, uint32_t &tw, int &l, uint32_t &e) -> bool {
-        const int g = lwx / TL;
-        l = lwx % TL;
-        const uint32_t w = blk * Cfg::kG + g;
+        uint32_t w;
+        if constexpr (Cfg::kSUB > 1) {          // sub-tile workgroup: lines [sub*TLK, sub*TLK + TLK) of tile blk / SUB
+            w = blk / Cfg::kSUB;
+            l = (int)(blk % Cfg::kSUB) * Cfg::TLK + lwx;
+        } else {
+            w = blk * Cfg::kG + lwx / TL;
+            l = lwx % TL;
+        }
         bool ok = w < A.ntiles;
         a = !ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
         b = !ok ? 0 : (A.a_fastest ? w / A.na : w % A.nb);
@@ -498,12 +547,16 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
     } else {
         static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].x = 0; v[c].y = 0; });
     }
-    if (A.swap) static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; R tmp = v[c].x; v[c].x = v[c].y; v[c].y = tmp; });
+    // inverse transform = conj(forward(conj(x))): one multiplication by +-1 per point and side, no
+    // branch and no second copy of the data (a conditional re<->im swap costs both: the compiler keeps
+    // the swapped and the unswapped registers alive across the branch, +64 VGPRs at 32 points per thread)
+    const R sgn = A.swap ? (R)-1 : (R)1;
+    static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].y *= sgn; });
 
     // ------------------------------------------------------------------ passes
-    transform<Cfg>(v, lds, W, t, lw, t2, lw2);
+    if (!(A.debug & 1)) transform<Cfg>(v, lds, W, t, lw, t2, lw2);
 
-    if (A.swap) static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; R tmp = v[c].x; v[c].x = v[c].y; v[c].y = tmp; });
+    static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].y *= sgn; });
 
     // ------------------------------------------------------------------ store (coordinates of the later passes)
     uint32_t a2, b2, tws, e2;
@@ -642,7 +695,8 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
     const int tid = threadIdx.x;
     const int lw = tid % TW, t = tid / TW;
     const int g = lw / TL, l = lw % TL;
-    const uint32_t w = logical_block(A) * Cfg::kG + g;
+    static_assert(Cfg::kSUB == 1, "sub-tile workgroups: fft_pass_kernel only");
+    const uint32_t w = logical_block<>(A) * Cfg::kG + g;
     const bool tile_ok = w < A.ntiles;
     TileCtx<TL> tc;
     tc.a = !tile_ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
@@ -662,6 +716,16 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
         static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = p[NT * c]; });
     } else {
         static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].x = 0; v[c].y = 0; });
+    }
+    if (A.debug & 1) {          // measurement only: copy with this pass's access pattern
+        if (!active) return;
+        const uint64_t row = ((uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + tc.l) * (uint64_t)(M + 1);
+        static_for<0, E>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            const uint32_t k = t + NT * c;
+            out[A.store_kind == STORE_LINES ? row + k : tiled_transpose_store_offset<TL>(A, tc, k)] = v[c];
+        });
+        return;
     }
     transform<Cfg>(v, lds, W, t, lw, tid);
 
@@ -746,7 +810,8 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
     const int tid = threadIdx.x;
     const int lw = tid % TW, t = tid / TW;
     const int g = lw / TL, l = lw % TL;
-    const uint32_t w = logical_block(A) * Cfg::kG + g;
+    static_assert(Cfg::kSUB == 1, "sub-tile workgroups: fft_pass_kernel only");
+    const uint32_t w = logical_block<>(A) * Cfg::kG + g;
     const bool tile_ok = w < A.ntiles;
     TileCtx<TL> tc;
     tc.a = !tile_ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
@@ -791,7 +856,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
     } else {
         static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].x = 0; v[c].y = 0; });
     }
-    transform<Cfg>(v, lds, W, t, lw, tid);
+    if (!(A.debug & 1)) transform<Cfg>(v, lds, W, t, lw, tid);
     if (!active) return;
     constexpr int RL = Cfg::RLAST, S = E / RL;
     C *p = out + ((uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + l) * M + t;
@@ -881,7 +946,8 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_bluestein_kernel(const PassA
     const int tid = threadIdx.x;
     const int lw = tid % TW, t = tid / TW;
     const int g = lw / TL, l = lw % TL;
-    const uint32_t w = logical_block(A) * Cfg::kG + g;
+    static_assert(Cfg::kSUB == 1, "sub-tile workgroups: fft_pass_kernel only");
+    const uint32_t w = logical_block<>(A) * Cfg::kG + g;
     const bool tile_ok = w < A.ntiles;
     TileCtx<TL> tc;
     tc.a = !tile_ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);

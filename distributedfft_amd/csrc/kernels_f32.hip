@@ -14,71 +14,108 @@ using F32_512  = PassCfg<float, 512, 16, 16, 1,  8, 8, 8, 1,   2>;
 // 32 points per thread: fp32 runs out of instruction issue, not bandwidth, at 16
 using F32_1024 = PassCfg<float, 1024, 32, 16, 1, 32, 8, 4, 1,  1, 1>;
 using F32_2048 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1,  1, 1>;
-using F32_1024_v1 = PassCfg<float, 1024, 16, 16, 1, 16, 16, 4, 1, 1>;   // round-1 baseline, for A/B runs
 // point-fastest lane mappings (see PassCfg::MAP): variant 4 = every pass (natural-line load + transposed-tile
 // store: forward z), variant 5 = from the first exchange on (tiled load + natural-line / transposed store)
 using F32_1024_v4 = PassCfg<float, 1024, 32, 16, 1, 32, 8, 4, 1, 1, 1, 0, 1>;
 using F32_1024_v5 = PassCfg<float, 1024, 32, 16, 1, 32, 8, 4, 1, 1, 1, 0, 2>;
-using F32_512_v1 = PassCfg<float, 512, 32, 16, 1, 32, 4, 4, 1, 1, 1>;
-// two radix-32 passes (one LDS exchange instead of two): variants 6 (line fastest), 7 / 8 (point-fastest forms)
+// two radix-32 passes (one LDS exchange instead of two): variant 6
 using F32_1024_v6 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1>;
-using F32_1024_v7 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 1>;
-using F32_1024_v8 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 2>;
 using F32_512_v6 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1>;
 using F32_512_v4 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1, 0, 1>;    // point-fastest forms, as for 1024
 using F32_512_v5 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1, 0, 2>;
-// (2048 with the point-fastest mapping measured slower than line fastest: 0.89 vs 0.81 ms on 256x256x2048)
+// 2048: 16 lines x 2048 points are 256 KiB -- one workgroup per CU.  Variant 6 (as for 1024: the two-pass
+// configuration): 64 points per thread, radix 64.32 with a single LDS exchange on 512 threads; 4 / 5 its
+// point-fastest forms.  Variant 1: sub-tile workgroups of 8 lines (PassCfg::SUB = 2, 66 KiB LDS, two per
+// CU) with the three-pass chain, variant 3: sub-tiles with the two-pass chain (256 threads).
+using F32_2048_v6 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1>;
+using F32_2048_v4 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 1>;
+using F32_2048_v5 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 2>;
+using F32_2048_v1 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 0, 2>;
+using F32_2048_v3 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 0, 2>;
+#ifdef DFFT_EXPERIMENTS
+// A/B-only configurations (tools/kbench --opt variant_*=N); not part of the shipped library
+using F32_1024_v1 = PassCfg<float, 1024, 16, 16, 1, 16, 16, 4, 1, 1>;   // round-1 baseline
+using F32_512_v1 = PassCfg<float, 512, 32, 16, 1, 32, 4, 4, 1, 1, 1>;
+using F32_1024_v7 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 1>;   // two passes, point-fastest forms
+using F32_1024_v8 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 2>;
+using F32_1024_v9 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 0, 2>;  // sub-tiles (8 lines, 256 threads)
+// nontemporal forms: 10 = two-pass line-fastest (tiled passes), loads and stores; 11 stores only; 12 loads only;
+// 13 = point-fastest two-pass (natural-line passes), loads and stores
+using F32_1024_v10 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 3>;
+using F32_1024_v11 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 2>;
+using F32_1024_v12 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 1>;
+using F32_1024_v13 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 3, 1>;
+// 2048: nontemporal forms: 9 = variant 7 (natural lines), 10 = variant 6 (tiled), 11 = three-pass 1024 threads (tiled)
+using F32_2048_v9 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3, 1, 2>;
+using F32_2048_v10 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3>;
+using F32_2048_v11 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3>;
+// 2048: point-fastest forms of the two-pass sub-tile configuration
+using F32_2048_v7 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 1, 2>;
+using F32_2048_v8 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 2, 2>;
+#endif
 
-#define DFFT_F32_LIST(X) X(1024, 1, F32_1024_v1) X(512, 1, F32_512_v1) X(1024, 4, F32_1024_v4) X(1024, 5, F32_1024_v5) \
-    X(1024, 6, F32_1024_v6) X(1024, 7, F32_1024_v7) X(1024, 8, F32_1024_v8) X(512, 6, F32_512_v6) X(512, 4, F32_512_v4) X(512, 5, F32_512_v5) \
-    X(2, 0, F32_2) X(4, 0, F32_4) X(8, 0, F32_8) X(16, 0, F32_16) X(32, 0, F32_32) X(64, 0, F32_64) \
-    X(128, 0, F32_128) X(256, 0, F32_256) X(512, 0, F32_512) X(1024, 0, F32_1024) X(2048, 0, F32_2048)
+#ifdef DFFT_EXPERIMENTS
+#define DFFT_F32_EXP_SMALL(X) X(512, 1, F32_512_v1)
+#define DFFT_F32_EXP_1024(X) X(1024, 10, F32_1024_v10) X(1024, 11, F32_1024_v11) X(1024, 12, F32_1024_v12) X(1024, 13, F32_1024_v13) X(1024, 1, F32_1024_v1) X(1024, 7, F32_1024_v7) X(1024, 8, F32_1024_v8) X(1024, 9, F32_1024_v9)
+#define DFFT_F32_EXP_2048(X) X(2048, 9, F32_2048_v9) X(2048, 10, F32_2048_v10) X(2048, 11, F32_2048_v11) X(2048, 7, F32_2048_v7) X(2048, 8, F32_2048_v8)
+#else
+#define DFFT_F32_EXP_SMALL(X)
+#define DFFT_F32_EXP_1024(X)
+#define DFFT_F32_EXP_2048(X)
+#endif
+#define DFFT_F32_LIST_SMALL(X) X(512, 6, F32_512_v6) X(512, 4, F32_512_v4) X(512, 5, F32_512_v5) X(2, 0, F32_2) X(4, 0, F32_4) X(8, 0, F32_8) X(16, 0, F32_16) X(32, 0, F32_32) X(64, 0, F32_64) X(128, 0, F32_128) X(256, 0, F32_256) X(512, 0, F32_512) DFFT_F32_EXP_SMALL(X)
+#define DFFT_F32_LIST_1024(X) X(1024, 4, F32_1024_v4) X(1024, 5, F32_1024_v5) X(1024, 6, F32_1024_v6) X(1024, 0, F32_1024) DFFT_F32_EXP_1024(X)
+#define DFFT_F32_LIST_2048(X) X(2048, 1, F32_2048_v1) X(2048, 3, F32_2048_v3) X(2048, 4, F32_2048_v4) X(2048, 5, F32_2048_v5) X(2048, 6, F32_2048_v6) X(2048, 0, F32_2048) DFFT_F32_EXP_2048(X)
 
+DFFT_SLICE_DECLS(f32)
+#if DFFT_SLICE == 0
+DFFT_SLICE_FUNCS(f32, 0, DFFT_F32_LIST_SMALL)
 int launch_pass_f32(int N, int variant, const PassArgs &A, hipStream_t stream)
 {
-    switch (N * 16 + variant) {
-#define X(n, v, cfg) case n * 16 + v: return launch_cfg<cfg>(A, stream);
-        DFFT_F32_LIST(X)
-#undef X
-    }
-    return -1;
+    return N <= 512 ? launch_pass_f32_s0(N, variant, A, stream) : N == 1024 ? launch_pass_f32_s1(N, variant, A, stream)
+                                                                          : launch_pass_f32_s2(N, variant, A, stream);
 }
 bool pass_info_f32(int N, int variant, PassInfo *pi)
 {
-    switch (N * 16 + variant) {
-#define X(n, v, cfg) case n * 16 + v: info_cfg<cfg>(pi); return true;
-        DFFT_F32_LIST(X)
-#undef X
-    }
-    return false;
+    return N <= 512 ? pass_info_f32_s0(N, variant, pi) : N == 1024 ? pass_info_f32_s1(N, variant, pi) : pass_info_f32_s2(N, variant, pi);
 }
+#elif DFFT_SLICE == 1
+DFFT_SLICE_FUNCS(f32, 1, DFFT_F32_LIST_1024)
+#elif DFFT_SLICE == 2
+DFFT_SLICE_FUNCS(f32, 2, DFFT_F32_LIST_2048)
+#else
+// slices 3 (real z passes) and 4 (Bluestein) share the base list
 
 // real-transform z passes (variant 0 configurations only); M = Nz/2
 #define DFFT_F32_BASE(X) X(2, 0, F32_2) X(4, 0, F32_4) X(8, 0, F32_8) X(16, 0, F32_16) X(32, 0, F32_32) X(64, 0, F32_64) \
     X(128, 0, F32_128) X(256, 0, F32_256) X(512, 0, F32_512) X(1024, 0, F32_1024)
-// experiment variants of the real z passes (DFFT_REAL_VARIANT): 1 = one-plane split, same configuration;
-// 2 = one-plane split, 32 points per thread
+#if DFFT_SLICE == 3
+// 512 and 1024 (Nz = 1024, 2048): two radix passes (one exchange) + one-plane split, measured +14 % / +5-10 %
+// over the three-pass configurations
 using F32_R512_32 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1>;
+#ifdef DFFT_EXPERIMENTS
+// A/B variants of the real z passes (option real_variant): 1 = three-pass configuration, two-plane split (the
+// round-1 baseline); 2 = three-pass configuration, one-plane split
 static int launch_real_variant_f32(int M, int mode, int variant, const PassArgs &A, hipStream_t stream)
 {
-    if (M == 512 && variant == 1) return mode == 1 ? launch_real_cfg<F32_512, 1, 1>(A, stream) : launch_real_cfg<F32_512, 2>(A, stream);
-    if (M == 512 && variant == 2) return mode == 1 ? launch_real_cfg<F32_R512_32, 1, 1>(A, stream) : launch_real_cfg<F32_R512_32, 2>(A, stream);
-    if (M == 1024 && variant == 1) return mode == 1 ? launch_real_cfg<F32_1024, 1, 1>(A, stream) : launch_real_cfg<F32_1024, 2>(A, stream);
-    if (M == 1024 && variant == 2) return mode == 1 ? launch_real_cfg<F32_1024_v6, 1, 1>(A, stream) : launch_real_cfg<F32_1024_v6, 2>(A, stream);
+    if (M == 512 && variant == 1) return mode == 1 ? launch_real_cfg<F32_512, 1>(A, stream) : launch_real_cfg<F32_512, 2>(A, stream);
+    if (M == 512 && variant == 2) return mode == 1 ? launch_real_cfg<F32_512, 1, 1>(A, stream) : launch_real_cfg<F32_512, 2>(A, stream);
+    if (M == 1024 && variant == 1) return mode == 1 ? launch_real_cfg<F32_1024, 1>(A, stream) : launch_real_cfg<F32_1024, 2>(A, stream);
+    if (M == 1024 && variant == 2) return mode == 1 ? launch_real_cfg<F32_1024, 1, 1>(A, stream) : launch_real_cfg<F32_1024, 2>(A, stream);
     return -2;
 }
-int launch_real_f32(int M, int mode, const PassArgs &A, hipStream_t stream)
+#endif
+int launch_real_f32(int M, int mode, int variant, const PassArgs &A, hipStream_t stream)
 {
-    // 512 and 1024: two radix passes (one exchange) + one-plane split, measured +14 % / +5-10 % over the
-    // three-pass configurations (DFFT_REAL_VARIANT=0 selects those for A/B runs)
-    if (!getenv("DFFT_REAL_VARIANT")) {
-        if (M == 512) return mode == 1 ? launch_real_cfg<F32_R512_32, 1, 1>(A, stream) : launch_real_cfg<F32_R512_32, 2>(A, stream);
-        if (M == 1024) return mode == 1 ? launch_real_cfg<F32_1024_v6, 1, 1>(A, stream) : launch_real_cfg<F32_1024_v6, 2>(A, stream);
-    }
-    if (const char *v = getenv("DFFT_REAL_VARIANT")) {
-        const int r = launch_real_variant_f32(M, mode, atoi(v), A, stream);
+#ifdef DFFT_EXPERIMENTS
+    if (variant > 0) {
+        const int r = launch_real_variant_f32(M, mode, variant, A, stream);
         if (r != -2) return r;
     }
+#endif
+    (void)variant;
+    if (M == 512) return mode == 1 ? launch_real_cfg<F32_R512_32, 1, 1>(A, stream) : launch_real_cfg<F32_R512_32, 2>(A, stream);
+    if (M == 1024) return mode == 1 ? launch_real_cfg<F32_1024_v6, 1, 1>(A, stream) : launch_real_cfg<F32_1024_v6, 2>(A, stream);
     switch (M) {
 #define X(n, v, cfg) case n: return mode == 1 ? launch_real_cfg<cfg, 1>(A, stream) : launch_real_cfg<cfg, 2>(A, stream);
         DFFT_F32_BASE(X)
@@ -87,6 +124,7 @@ int launch_real_f32(int M, int mode, const PassArgs &A, hipStream_t stream)
     return -1;
 }
 
+#else
 // Bluestein passes for arbitrary line lengths: M = power of two >= 2*NL - 1
 int launch_bluestein_f32(int M, const PassArgs &A, hipStream_t stream)
 {
@@ -98,4 +136,6 @@ int launch_bluestein_f32(int M, const PassArgs &A, hipStream_t stream)
     }
     return -1;
 }
+#endif  // DFFT_SLICE == 3
+#endif  // DFFT_SLICE
 }  // namespace dfft

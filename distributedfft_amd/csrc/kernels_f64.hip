@@ -25,40 +25,73 @@ using F64_1024_v3 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 3>;
 using F64_512_v1 = PassCfg<double, 512, 32, 8, 2, 32, 16, 1, 1, 1, 1>;      // strided read, 512
 using F64_512_v3 = PassCfg<double, 512, 16, 8, 1, 8, 8, 8, 1, 1, 0, 3>;       // nontemporal, 512
 using F64_2048_v3 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 3>;   // nontemporal, 2048
-// variant 2 = table-loaded twiddles (bit-for-bit the round-1 baseline), kept for A/B runs
+// 2048: 8 lines x 2048 points are 256 KiB, one workgroup per CU whatever the configuration.  Variants 5 / 6
+// split every tile between two sibling workgroups of 4 lines (PassCfg::SUB): 68 KiB LDS, two per CU
+// (5 = plain, 6 = nontemporal; same numbering as the 1024 sub-tile variants).
+using F64_2048_v5 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 0, 0, 2>;
+using F64_2048_v6 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 3, 0, 2>;
+#ifdef DFFT_EXPERIMENTS
+// A/B-only configurations (tools/kbench --opt variant_*=N); not part of the shipped library
+// variant 2 = table-loaded twiddles (bit-for-bit the round-1 baseline)
 using F64_1024_v2 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 0>;
-// variant 4 = two radix-32 passes on 8 lines (256 threads, one LDS exchange), for A/B runs
+// variant 4 = two radix-32 passes on 8 lines (256 threads, one LDS exchange)
 using F64_1024_v4 = PassCfg<double, 1024, 32, 8, 1, 32, 32, 1, 1, 1, 1>;
+// variants 5/6 = sub-tile workgroups (4 lines, 256 threads, 34 KiB LDS: four per CU), plain / nontemporal
+using F64_1024_v5 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 0, 0, 2>;
+using F64_1024_v6 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 3, 0, 2>;
+// variant 7 = strided-read configuration with nontemporal stores
+using F64_1024_v7 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 2>;
+// variants 8 / 9 = default configuration with nontemporal loads only / stores only
+using F64_1024_v8 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 1>;
+using F64_1024_v9 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 2>;
+// variants 10 / 11 = strided-read configuration with nontemporal loads only / loads and stores
+using F64_1024_v10 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 1>;
+using F64_1024_v11 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 3>;
+// 2048: 32 points per thread (512 threads, three passes 32.32.2), whole tiles / sub-tiles
+using F64_2048_v2 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1>;
+using F64_2048_v4 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 0, 0, 2>;
+#endif
 
-#define DFFT_F64_LIST(X) X(1024, 1, F64_1024_v1) X(1024, 2, F64_1024_v2) X(1024, 3, F64_1024_v3) X(1024, 4, F64_1024_v4) X(512, 1, F64_512_v1) X(512, 3, F64_512_v3) X(2048, 3, F64_2048_v3) \
-    X(2, 0, F64_2) X(4, 0, F64_4) X(8, 0, F64_8) X(16, 0, F64_16) X(32, 0, F64_32) X(64, 0, F64_64) \
-    X(128, 0, F64_128) X(256, 0, F64_256) X(512, 0, F64_512) X(1024, 0, F64_1024) X(2048, 0, F64_2048)
+#ifdef DFFT_EXPERIMENTS
+#define DFFT_F64_EXP_SMALL(X) 
+#define DFFT_F64_EXP_1024(X) X(1024, 2, F64_1024_v2) X(1024, 4, F64_1024_v4) X(1024, 5, F64_1024_v5) X(1024, 6, F64_1024_v6) X(1024, 7, F64_1024_v7) X(1024, 8, F64_1024_v8) X(1024, 9, F64_1024_v9) X(1024, 10, F64_1024_v10) X(1024, 11, F64_1024_v11)
+#define DFFT_F64_EXP_2048(X) X(2048, 2, F64_2048_v2) X(2048, 4, F64_2048_v4)
+#else
+#define DFFT_F64_EXP_SMALL(X)
+#define DFFT_F64_EXP_1024(X)
+#define DFFT_F64_EXP_2048(X)
+#endif
+#define DFFT_F64_LIST_SMALL(X) X(512, 1, F64_512_v1) X(512, 3, F64_512_v3) X(2, 0, F64_2) X(4, 0, F64_4) X(8, 0, F64_8) X(16, 0, F64_16) X(32, 0, F64_32) X(64, 0, F64_64) X(128, 0, F64_128) X(256, 0, F64_256) X(512, 0, F64_512) DFFT_F64_EXP_SMALL(X)
+#define DFFT_F64_LIST_1024(X) X(1024, 1, F64_1024_v1) X(1024, 3, F64_1024_v3) X(1024, 0, F64_1024) DFFT_F64_EXP_1024(X)
+#define DFFT_F64_LIST_2048(X) X(2048, 3, F64_2048_v3) X(2048, 5, F64_2048_v5) X(2048, 6, F64_2048_v6) X(2048, 0, F64_2048) DFFT_F64_EXP_2048(X)
 
+DFFT_SLICE_DECLS(f64)
+#if DFFT_SLICE == 0
+DFFT_SLICE_FUNCS(f64, 0, DFFT_F64_LIST_SMALL)
 int launch_pass_f64(int N, int variant, const PassArgs &A, hipStream_t stream)
 {
-    switch (N * 16 + variant) {
-#define X(n, v, cfg) case n * 16 + v: return launch_cfg<cfg>(A, stream);
-        DFFT_F64_LIST(X)
-#undef X
-    }
-    return -1;
+    return N <= 512 ? launch_pass_f64_s0(N, variant, A, stream) : N == 1024 ? launch_pass_f64_s1(N, variant, A, stream)
+                                                                          : launch_pass_f64_s2(N, variant, A, stream);
 }
 bool pass_info_f64(int N, int variant, PassInfo *pi)
 {
-    switch (N * 16 + variant) {
-#define X(n, v, cfg) case n * 16 + v: info_cfg<cfg>(pi); return true;
-        DFFT_F64_LIST(X)
-#undef X
-    }
-    return false;
+    return N <= 512 ? pass_info_f64_s0(N, variant, pi) : N == 1024 ? pass_info_f64_s1(N, variant, pi) : pass_info_f64_s2(N, variant, pi);
 }
+#elif DFFT_SLICE == 1
+DFFT_SLICE_FUNCS(f64, 1, DFFT_F64_LIST_1024)
+#elif DFFT_SLICE == 2
+DFFT_SLICE_FUNCS(f64, 2, DFFT_F64_LIST_2048)
+#else
+// slices 3 (real z passes) and 4 (Bluestein) share the base list
 
 // real-transform z passes; M = Nz/2.  512 gets its own 8-points-per-thread configuration: the
 // split/merge step needs both LDS planes, and 512 threads x 64 KiB keeps 16 waves on a CU
 using F64_R512 = PassCfg<double, 512, 8, 8, 1, 8, 8, 8, 1, 1>;
 #define DFFT_F64_BASE(X) X(2, 0, F64_2) X(4, 0, F64_4) X(8, 0, F64_8) X(16, 0, F64_16) X(32, 0, F64_32) X(64, 0, F64_64) \
     X(128, 0, F64_128) X(256, 0, F64_256) X(512, 0, F64_R512) X(1024, 0, F64_1024)
-// experiment variants of the real z passes (DFFT_REAL_VARIANT): 1 = one-plane split, same configuration;
+#if DFFT_SLICE == 3
+#ifdef DFFT_EXPERIMENTS
+// A/B variants of the real z passes (option real_variant): 1 = one-plane split, same configuration;
 // 2 = one-plane split with 16 points per thread x 16 lines (twice the bytes in flight per workgroup)
 using F64_R512_16 = PassCfg<double, 512, 16, 8, 2, 8, 8, 8, 1, 1>;
 static int launch_real_variant_f64(int M, int mode, int variant, const PassArgs &A, hipStream_t stream)
@@ -69,12 +102,16 @@ static int launch_real_variant_f64(int M, int mode, int variant, const PassArgs 
     if (M == 1024 && variant == 1) return mode == 1 ? launch_real_cfg<F64_1024, 1, 1>(A, stream) : launch_real_cfg<F64_1024, 2>(A, stream);
     return -2;
 }
-int launch_real_f64(int M, int mode, const PassArgs &A, hipStream_t stream)
+#endif
+int launch_real_f64(int M, int mode, int variant, const PassArgs &A, hipStream_t stream)
 {
-    if (const char *v = getenv("DFFT_REAL_VARIANT")) {
-        const int r = launch_real_variant_f64(M, mode, atoi(v), A, stream);
+#ifdef DFFT_EXPERIMENTS
+    if (variant > 0) {
+        const int r = launch_real_variant_f64(M, mode, variant, A, stream);
         if (r != -2) return r;
     }
+#endif
+    (void)variant;
     switch (M) {
 #define X(n, v, cfg) case n: return mode == 1 ? launch_real_cfg<cfg, 1>(A, stream) : launch_real_cfg<cfg, 2>(A, stream);
         DFFT_F64_BASE(X)
@@ -83,6 +120,7 @@ int launch_real_f64(int M, int mode, const PassArgs &A, hipStream_t stream)
     return -1;
 }
 
+#else
 // Bluestein passes for arbitrary line lengths: M = power of two >= 2*NL - 1
 int launch_bluestein_f64(int M, const PassArgs &A, hipStream_t stream)
 {
@@ -94,4 +132,6 @@ int launch_bluestein_f64(int M, const PassArgs &A, hipStream_t stream)
     }
     return -1;
 }
+#endif  // DFFT_SLICE == 3
+#endif  // DFFT_SLICE
 }  // namespace dfft

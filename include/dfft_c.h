@@ -112,10 +112,25 @@ int dfft_set_work_area(dfft_plan *plan, void *device, void *host);
 /* Pipeline depth of the exchanges: every pass that feeds an all-to-all is cut into `chunks`
  * pieces so that chunk c travels (communication stream) while chunk c+1 is transformed (compute
  * stream).  The reference's counterpart is the Peer2Peer overlap of
- * src/pencil/mpicufft_pencil_opt1.cpp:601-754.  Call before dfft_init; 0 = default (4 when the
+ * src/pencil/mpicufft_pencil_opt1.cpp:601-754.  Takes effect at the next dfft_init; 0 = default (4 when the
  * plan has an exchange, else 1), 1 = no pipelining = the reference's exact message sizes. */
 int dfft_set_pipeline_chunks(dfft_plan *plan, int chunks);
 int dfft_get_pipeline_chunks(const dfft_plan *plan);
+/* Tuning knobs, by name (takes effect at the next dfft_init unless noted).  The reference's counterpart is the
+ * Configurations struct (include/params.hpp:85-93); these are the knobs this engine has instead:
+ *   "pipeline_chunks"  as dfft_set_pipeline_chunks                      (env default DFFT_CHUNKS)
+ *   "mirror_inverse"   1: a single-rank complex inverse runs the multi-rank pass order x, y, z instead of the
+ *                      forward order with conjugation (next exec; benchmarking the N > 1 compute path on one GPU;
+ *                      env default DFFT_MIRROR)
+ *   "point_tables"     per-point address tables: 0 never, 1 segmented sides (default), 2 always (DFFT_TABLES)
+ *   "shift"            row-aligned tile windows for odd-pitch output rows: -1 auto, 0 off, 2 always (DFFT_SHIFT)
+ *   "debug_skip"       measurement only: 1 = every pass skips its transform and becomes a copy with the same
+ *                      access pattern (results are wrong); used to measure the pattern's own roofline
+ *   "variant_<pass>", "order_<pass>", "real_variant"   kernel configuration / workgroup order per pass
+ *                      (<pass> = fz fy fx ix iy iz; -1 = the plan's choice), for A/B measurements
+ * Returns nonzero for an unknown key.  dfft_get_option returns -1 for an unknown key. */
+int dfft_set_option(dfft_plan *plan, const char *key, long value);
+long dfft_get_option(dfft_plan *plan, const char *key);
 /* HIP stream all kernels/exchanges are enqueued on (default: a non-blocking stream owned by the
  * plan).  exec orders itself only against this stream: work that produces `in` or initialises
  * `out` on another stream must be complete (or that stream handed over here) before exec. */
@@ -147,6 +162,13 @@ int dfft_get_in_size(const dfft_plan *plan, size_t size[3]);
 int dfft_get_in_start(const dfft_plan *plan, size_t start[3]);
 int dfft_get_out_size(const dfft_plan *plan, size_t size[3]);
 int dfft_get_out_start(const dfft_plan *plan, size_t start[3]);
+/* getPartitionDimensions(input_dim, transposed_dim, output_dim)   include/mpicufft_pencil.hpp:112-116, tables of
+ * struct Partition_Dimensions (include/params.hpp:58-81) as built in src/pencil/mpicufft_pencil_opt1.cpp:70-93.
+ * which = 0 input_dim, 1 transposed_dim, 2 output_dim; axis = 0 x, 1 y, 2 z.  Writes the per-rank extents and
+ * offsets of that axis at that stage (one entry = the full extent when the axis is not split there); *count
+ * receives the number of entries, at most `capacity` are written (sizes/starts may be NULL to query). */
+int dfft_get_partition_dimensions(const dfft_plan *plan, int which, int axis, size_t *sizes, size_t *starts,
+                                  size_t capacity, size_t *count);
 /* getDomainSize / getWorkSizeDevice / getWorkSizeHost / getRank / getWorldSize
  * include/mpicufft.hpp:65-78 */
 size_t dfft_domain_size(const dfft_plan *plan);        /* bytes `out` must hold */
@@ -184,6 +206,11 @@ int dfft_enable_phase_timing(dfft_plan *plan, int enable);
  * [batch][N]); used by the kernel-level parity tests and the micro-benchmarks */
 int dfft_fft1d_batched(int precision, size_t N, size_t batch, void *out, const void *in,
                        int direction, void *hip_stream);
+
+/* same with an explicit kernel configuration (0 = default; unknown values fall back to 0) and the
+ * measurement-only debug flags of "debug_skip" */
+int dfft_fft1d_batched_ex(int precision, size_t N, size_t batch, void *out, const void *in, int direction,
+                          void *hip_stream, int variant, int debug);
 
 /* ---- introspection of the pass descriptors (host only; used by the CPU layout tests) -------- *
  * One axis pass of the plan: which lines it transforms and the address forms of its load and store

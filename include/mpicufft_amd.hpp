@@ -11,6 +11,7 @@
 #pragma once
 #include <mpi.h>
 
+#include <algorithm>
 #include <climits>
 #include <cstring>
 #include <map>
@@ -30,6 +31,25 @@ struct GlobalSize {
 struct Partition { size_t P1, P2; };
 struct Slab_Partition : public Partition { explicit Slab_Partition(size_t P1_) { P1 = P1_; P2 = 1; } };
 struct Pencil_Partition : public Partition { Pencil_Partition(size_t P1_, size_t P2_) { P1 = P1_; P2 = P2_; } };
+// include/params.hpp:58-81: per-rank extents and offsets of one decomposition stage
+struct Partition_Dimensions {
+    void computeOffsets()
+    {
+        computeStart(&size_x, &start_x);
+        computeStart(&size_y, &start_y);
+        computeStart(&size_z, &start_z);
+    }
+    std::vector<size_t> size_x, size_y, size_z;
+    std::vector<size_t> start_x, start_y, start_z;
+
+private:
+    void computeStart(std::vector<size_t> *size, std::vector<size_t> *start)
+    {
+        size_t offset = 0;
+        start->clear();
+        for (size_t i = 0; i < size->size(); i++) { start->push_back(offset); offset += (*size)[i]; }
+    }
+};
 enum CommunicationMethod { Peer2Peer, All2All };
 enum SendMethod { Sync, Streams, MPI_Type };
 struct Configurations {
@@ -52,8 +72,8 @@ public:
     ~DfftHostStagedMPI()
     {
         for (auto &kv : groups_) MPI_Comm_free(&kv.second);
-        if (hsend_) hipHostFree(hsend_);
-        if (hrecv_) hipHostFree(hrecv_);
+        if (hsend_) (void)hipHostFree(hsend_);
+        if (hrecv_) (void)hipHostFree(hrecv_);
     }
     static int alltoallv(void *user, const void *sendbuf, const size_t *scounts, const size_t *sdispls, void *recvbuf,
                          const size_t *rcounts, const size_t *rdispls, const int *group, int ngroup, int me, void *stream)
@@ -74,27 +94,37 @@ private:
             MPI_Comm_split(comm_, group[0], me, &sub);
             it = groups_.emplace(key, sub).first;
         }
-        size_t stot = 0, rtot = 0;
+        // MPI_Alltoallv takes int counts and displacements: the exchange runs in rounds of at most `piece` bytes
+        // per peer so that one round's staging buffer stays below INT_MAX (C4's exchange 1 is 2 GiB per rank,
+        // C5's messages are 2-4 GiB).  Every member of the group must run the same number of rounds.
+        const size_t piece = ((size_t)INT_MAX / (size_t)ng) & ~(size_t)255;
+        unsigned long long mymax = 0, gmax = 0;
+        for (int q = 0; q < ng; q++) mymax = std::max<unsigned long long>(mymax, std::max(sc[q], rc[q]));
+        if (MPI_Allreduce(&mymax, &gmax, 1, MPI_UNSIGNED_LONG_LONG, MPI_MAX, it->second) != MPI_SUCCESS) return 5;
+        const size_t rounds = gmax ? (size_t)((gmax + piece - 1) / piece) : 0;
         std::vector<int> isc(ng), isd(ng), irc(ng), ird(ng);
-        for (int q = 0; q < ng; q++) {
-            if (sc[q] > (size_t)INT_MAX || rc[q] > (size_t)INT_MAX || stot > (size_t)INT_MAX || rtot > (size_t)INT_MAX) return 2;
-            isc[q] = (int)sc[q]; isd[q] = (int)stot; stot += sc[q];
-            irc[q] = (int)rc[q]; ird[q] = (int)rtot; rtot += rc[q];
+        for (size_t r = 0; r < rounds; r++) {
+            const size_t lo = r * piece;
+            size_t stot = 0, rtot = 0;
+            for (int q = 0; q < ng; q++) {
+                const size_t s = sc[q] > lo ? std::min(piece, sc[q] - lo) : 0, v = rc[q] > lo ? std::min(piece, rc[q] - lo) : 0;
+                isc[q] = (int)s; isd[q] = (int)stot; stot += s;
+                irc[q] = (int)v; ird[q] = (int)rtot; rtot += v;
+            }
+            if (stot > hcap_s_) { if (hsend_) (void)hipHostFree(hsend_); hsend_ = nullptr; hcap_s_ = 0; if (hipHostMalloc(&hsend_, stot) != hipSuccess) return 3; hcap_s_ = stot; }
+            if (rtot > hcap_r_) { if (hrecv_) (void)hipHostFree(hrecv_); hrecv_ = nullptr; hcap_r_ = 0; if (hipHostMalloc(&hrecv_, rtot) != hipSuccess) return 3; hcap_r_ = rtot; }
+            for (int q = 0; q < ng; q++)
+                if (isc[q] && hipMemcpyAsync(static_cast<char *>(hsend_) + isd[q], static_cast<const char *>(sendbuf) + sd[q] + lo, (size_t)isc[q],
+                                             hipMemcpyDeviceToHost, stream) != hipSuccess) return 4;
+            if (hipStreamSynchronize(stream) != hipSuccess) return 4;
+            if (MPI_Alltoallv(hsend_, isc.data(), isd.data(), MPI_BYTE, hrecv_, irc.data(), ird.data(), MPI_BYTE, it->second) != MPI_SUCCESS)
+                return 5;
+            for (int q = 0; q < ng; q++)
+                if (irc[q] && hipMemcpyAsync(static_cast<char *>(recvbuf) + rd[q] + lo, static_cast<const char *>(hrecv_) + ird[q], (size_t)irc[q],
+                                             hipMemcpyHostToDevice, stream) != hipSuccess) return 4;
+            // the next round (and my next exchange) reuses the staging buffers: drain before going on
+            if (hipStreamSynchronize(stream) != hipSuccess) return 4;
         }
-        if (stot > hcap_s_) { if (hsend_) hipHostFree(hsend_); if (hipHostMalloc(&hsend_, stot) != hipSuccess) return 3; hcap_s_ = stot; }
-        if (rtot > hcap_r_) { if (hrecv_) hipHostFree(hrecv_); if (hipHostMalloc(&hrecv_, rtot) != hipSuccess) return 3; hcap_r_ = rtot; }
-        for (int q = 0; q < ng; q++)
-            if (sc[q] && hipMemcpyAsync(static_cast<char *>(hsend_) + isd[q], static_cast<const char *>(sendbuf) + sd[q], sc[q],
-                                        hipMemcpyDeviceToHost, stream) != hipSuccess) return 4;
-        if (hipStreamSynchronize(stream) != hipSuccess) return 4;
-        if (MPI_Alltoallv(hsend_, isc.data(), isd.data(), MPI_BYTE, hrecv_, irc.data(), ird.data(), MPI_BYTE, it->second) != MPI_SUCCESS)
-            return 5;
-        for (int q = 0; q < ng; q++)
-            if (rc[q] && hipMemcpyAsync(static_cast<char *>(recvbuf) + rd[q], static_cast<const char *>(hrecv_) + ird[q], rc[q],
-                                        hipMemcpyHostToDevice, stream) != hipSuccess) return 4;
-        // peers may overwrite nothing of mine (everything went through host copies), but my own next
-        // exchange reuses the staging buffers: drain before returning
-        if (hipStreamSynchronize(stream) != hipSuccess) return 4;
         return 0;
     }
     MPI_Comm comm_;
@@ -103,29 +133,42 @@ private:
     size_t hcap_s_ = 0, hcap_r_ = 0;
 };
 
+// include/mpicufft.hpp:55-105.  The reference's base class is abstract; here it carries the plan handle and
+// every member function the concrete classes share.  A rank outside the FFT world (pidx >= max_world_size)
+// holds no plan: its member functions are no-ops, like a rank that never constructs the reference's object.
 template <typename T> class MPIcuFFT {
 public:
     MPIcuFFT(Configurations config, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1, int kind = DFFT_PENCIL_OPT1)
     {
-        MPI_Comm_size(comm, &pcnt);
+        int size = 1;
+        MPI_Comm_size(comm, &size);
         MPI_Comm_rank(comm, &pidx);
-        if (max_world_size > 0 && max_world_size < pcnt) pcnt = max_world_size;   // src/mpicufft.cpp:46-51
-        if (pidx >= pcnt) return;                                                 // not part of the FFT world
+        pcnt = size;
+        MPI_Comm world = comm;
+        if (max_world_size > 0 && size > max_world_size) {
+            // src/mpicufft.cpp:46-51: EVERY rank that constructs the object takes part in this split (a rank that
+            // does not construct one matches it with MPI_Comm_split(comm, MPI_UNDEFINED, ...) as the reference's
+            // coordinator does, tests/src/pencil/random_dist_3D.cu:314-315).  Ranks beyond max_world_size get
+            // MPI_COMM_NULL and stay outside.
+            pcnt = max_world_size;
+            MPI_Comm_split(comm, pidx < pcnt ? 0 : MPI_UNDEFINED, pidx, &sub_);
+            world = sub_;
+        }
+        if (pidx >= pcnt) return;                       // not part of the FFT world
         if (pcnt > 1) {
-            MPI_Comm_split(comm, 0, pidx, &sub_);      // the first pcnt ranks (src/mpicufft.cpp:46-51)
             if (config.cuda_aware) {                   // device path: RCCL over xGMI, one rank per GPU
                 char id[128];
                 if (pidx == 0) check(dfft_rccl_unique_id(id));
-                MPI_Bcast(id, 128, MPI_BYTE, 0, sub_);
+                MPI_Bcast(id, 128, MPI_BYTE, 0, world);
                 check(dfft_comm_create_rccl(id, pcnt, pidx, &comm_));
             } else {                                   // host-staged MPI, ranks may share a GPU
-                staged_ = new DfftHostStagedMPI(sub_);
+                staged_ = new DfftHostStagedMPI(world);
                 check(dfft_comm_create_callback(pcnt, pidx, &DfftHostStagedMPI::alltoallv, staged_, &comm_));
             }
         }
         dfft_config c{config.cuda_aware, config.warmup_rounds, (int)config.comm_method, (int)config.send_method,
                       (int)config.comm_method2, (int)config.send_method2};
-        check(dfft_plan_create(&plan_, kind, sizeof(T) == 8 ? DFFT_F64 : DFFT_F32, &c, comm_, pidx, max_world_size));
+        check(dfft_plan_create(&plan_, kind, sizeof(T) == 8 ? DFFT_F64 : DFFT_F32, &c, comm_, pidx, -1));
     }
     virtual ~MPIcuFFT()
     {
@@ -136,6 +179,7 @@ public:
     }
     virtual void initFFT(GlobalSize *global_size, Partition *partition, bool allocate = true)
     {
+        if (!plan_) return;
         if (!global_size || !partition) throw std::runtime_error("GlobalSize or Partition not initialized!");
         check(dfft_init(plan_, global_size->Nx, global_size->Ny, global_size->Nz, (int)partition->P1,
                         (int)partition->P2, /*c2c=*/0, allocate));
@@ -143,16 +187,16 @@ public:
     // complex-to-complex plan (extension): same layouts with Nz_out = Nz
     void initFFT_C2C(GlobalSize *g, Partition *p, bool allocate = true)
     {
-        check(dfft_init(plan_, g->Nx, g->Ny, g->Nz, (int)p->P1, (int)p->P2, 1, allocate));
+        if (plan_) check(dfft_init(plan_, g->Nx, g->Ny, g->Nz, (int)p->P1, (int)p->P2, 1, allocate));
     }
-    virtual void setWorkArea(void *device = nullptr, void *host = nullptr) { check(dfft_set_work_area(plan_, device, host)); }
-    virtual void execR2C(void *out, const void *in) { check(dfft_exec_r2c(plan_, out, in)); }
-    virtual void execC2R(void *out, const void *in) { check(dfft_exec_c2r(plan_, out, const_cast<void *>(in))); }
-    void execC2C(void *out, void *in, int direction) { check(dfft_exec_c2c(plan_, out, in, direction)); }
-    inline void getInSize(size_t *isize) { check(dfft_get_in_size(plan_, isize)); }
-    inline void getInStart(size_t *istart) { check(dfft_get_in_start(plan_, istart)); }
-    inline void getOutSize(size_t *osize) { check(dfft_get_out_size(plan_, osize)); }
-    inline void getOutStart(size_t *ostart) { check(dfft_get_out_start(plan_, ostart)); }
+    virtual void setWorkArea(void *device = nullptr, void *host = nullptr) { if (plan_) check(dfft_set_work_area(plan_, device, host)); }
+    virtual void execR2C(void *out, const void *in) { if (plan_) check(dfft_exec_r2c(plan_, out, in)); }
+    virtual void execC2R(void *out, const void *in) { if (plan_) check(dfft_exec_c2r(plan_, out, const_cast<void *>(in))); }
+    void execC2C(void *out, void *in, int direction) { if (plan_) check(dfft_exec_c2c(plan_, out, in, direction)); }
+    virtual inline void getInSize(size_t *isize) { if (plan_) check(dfft_get_in_size(plan_, isize)); }
+    virtual inline void getInStart(size_t *istart) { if (plan_) check(dfft_get_in_start(plan_, istart)); }
+    virtual inline void getOutSize(size_t *osize) { if (plan_) check(dfft_get_out_size(plan_, osize)); }
+    virtual inline void getOutStart(size_t *ostart) { if (plan_) check(dfft_get_out_start(plan_, ostart)); }
     inline size_t getDomainSize() const { return dfft_domain_size(plan_); }
     inline size_t getWorkSizeDevice() const { return dfft_work_size_device(plan_); }
     inline size_t getWorkSizeHost() const { return dfft_work_size_host(plan_); }
@@ -166,6 +210,13 @@ protected:
     {
         if (rc != 0) throw std::runtime_error(std::string("dfft: ") + dfft_last_error());
     }
+    // slab classes: initFFT(global_size, nullptr, allocate) is legal, the partition is the world size
+    // (include/mpicufft_slab.hpp:103-106)
+    void initSlab(GlobalSize *g, Partition *partition, bool allocate)
+    {
+        Slab_Partition p((size_t)pcnt);
+        MPIcuFFT<T>::initFFT(g, partition ? partition : &p, allocate);
+    }
     dfft_plan *plan_ = nullptr;
     dfft_comm *comm_ = nullptr;
     DfftHostStagedMPI *staged_ = nullptr;
@@ -173,55 +224,85 @@ protected:
     int pidx = 0, pcnt = 1;
 };
 
-template <typename T> struct MPIcuFFT_Slab : MPIcuFFT<T> {
+// include/mpicufft_slab.hpp:85 and include/mpicufft_slab_opt1.hpp:70 (Opt1 derives from the opt0 class, so
+// `MPIcuFFT_Slab<T> *p = new MPIcuFFT_Slab_Opt1<T>(...)` of tests/src/slab/random_dist_default.cu:194-198 compiles)
+template <typename T> class MPIcuFFT_Slab : public MPIcuFFT<T> {
+public:
     MPIcuFFT_Slab(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1) : MPIcuFFT<T>(c, comm, max_world_size, DFFT_SLAB) {}
-    using MPIcuFFT<T>::initFFT;
-    void initFFT(GlobalSize *g, bool allocate = true)     // include/mpicufft_slab.hpp:103-106
-    {
-        Slab_Partition p(this->getWorldSize());
-        MPIcuFFT<T>::initFFT(g, &p, allocate);
-    }
+    virtual void initFFT(GlobalSize *g, Partition *partition, bool allocate = true) { this->initSlab(g, partition, allocate); }
+    void initFFT(GlobalSize *g, bool allocate = true) { initFFT(g, nullptr, allocate); }     // include/mpicufft_slab.hpp:103-106
+
+protected:
+    MPIcuFFT_Slab(Configurations c, MPI_Comm comm, int max_world_size, int kind) : MPIcuFFT<T>(c, comm, max_world_size, kind) {}
 };
-template <typename T> struct MPIcuFFT_Slab_Opt1 : MPIcuFFT<T> {
-    MPIcuFFT_Slab_Opt1(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1) : MPIcuFFT<T>(c, comm, max_world_size, DFFT_SLAB_OPT1) {}
+template <typename T> class MPIcuFFT_Slab_Opt1 : public MPIcuFFT_Slab<T> {
+public:
+    MPIcuFFT_Slab_Opt1(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1) : MPIcuFFT_Slab<T>(c, comm, max_world_size, DFFT_SLAB_OPT1) {}
+    void initFFT(GlobalSize *g, Partition *partition, bool allocate = true) { this->initSlab(g, partition, allocate); }
+    void initFFT(GlobalSize *g, bool allocate = true) { this->initFFT(g, nullptr, allocate); }
 };
-// alternative slab sequence (include/mpicufft_slab_z_then_yx.hpp, _opt1.hpp): output [Nx][Ny][Nzc/P]
-template <typename T> struct MPIcuFFT_Slab_Z_Then_YX : MPIcuFFT<T> {
-    MPIcuFFT_Slab_Z_Then_YX(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1, int kind = DFFT_SLAB_Z_THEN_YX)
-        : MPIcuFFT<T>(c, comm, max_world_size, kind) {}
-    using MPIcuFFT<T>::initFFT;
-    void initFFT(GlobalSize *g, bool allocate = true)     // include/mpicufft_slab_z_then_yx.hpp:33-37
-    {
-        Slab_Partition p(this->getWorldSize());
-        MPIcuFFT<T>::initFFT(g, &p, allocate);
-    }
+// alternative slab sequence (include/mpicufft_slab_z_then_yx.hpp:29, _opt1.hpp:22): output [Nx][Ny][Nzc/P]
+template <typename T> class MPIcuFFT_Slab_Z_Then_YX : public MPIcuFFT<T> {
+public:
+    MPIcuFFT_Slab_Z_Then_YX(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1) : MPIcuFFT<T>(c, comm, max_world_size, DFFT_SLAB_Z_THEN_YX) {}
+    virtual void initFFT(GlobalSize *g, Partition *partition, bool allocate = true) { this->initSlab(g, partition, allocate); }
+    void initFFT(GlobalSize *g, bool allocate = true) { initFFT(g, nullptr, allocate); }     // include/mpicufft_slab_z_then_yx.hpp:33-37
+
+protected:
+    MPIcuFFT_Slab_Z_Then_YX(Configurations c, MPI_Comm comm, int max_world_size, int kind) : MPIcuFFT<T>(c, comm, max_world_size, kind) {}
 };
-template <typename T> struct MPIcuFFT_Slab_Z_Then_YX_Opt1 : MPIcuFFT_Slab_Z_Then_YX<T> {
+template <typename T> class MPIcuFFT_Slab_Z_Then_YX_Opt1 : public MPIcuFFT_Slab_Z_Then_YX<T> {
+public:
     MPIcuFFT_Slab_Z_Then_YX_Opt1(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1)
         : MPIcuFFT_Slab_Z_Then_YX<T>(c, comm, max_world_size, DFFT_SLAB_Z_THEN_YX_OPT1) {}
+    void initFFT(GlobalSize *g, Partition *partition, bool allocate = true) { this->initSlab(g, partition, allocate); }
+    void initFFT(GlobalSize *g, bool allocate = true) { this->initFFT(g, nullptr, allocate); }
 };
-// forward-only sequence with the Hermitian axis in y (include/mpicufft_slab_y_then_zx.hpp): output [Nx][(Ny/2+1)/P][Nz]
-template <typename T> struct MPIcuFFT_Slab_Y_Then_ZX : MPIcuFFT<T> {
+// forward-only sequence with the Hermitian axis in y (include/mpicufft_slab_y_then_zx.hpp:29): output [Nx][(Ny/2+1)/P][Nz]
+template <typename T> class MPIcuFFT_Slab_Y_Then_ZX : public MPIcuFFT<T> {
+public:
     MPIcuFFT_Slab_Y_Then_ZX(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1)
         : MPIcuFFT<T>(c, comm, max_world_size, DFFT_SLAB_Y_THEN_ZX) {}
-    using MPIcuFFT<T>::initFFT;
-    void initFFT(GlobalSize *g, bool allocate = true)     // include/mpicufft_slab_y_then_zx.hpp:34-35
+    void initFFT(GlobalSize *g, Partition *partition, bool allocate = true) { this->initSlab(g, partition, allocate); }
+    void initFFT(GlobalSize *g, bool allocate = true) { this->initFFT(g, nullptr, allocate); }     // include/mpicufft_slab_y_then_zx.hpp:34-35
+};
+// include/mpicufft_pencil.hpp:88-122 and include/mpicufft_pencil_opt1.hpp:23 (Opt1 derives from the opt0 class:
+// tests/src/pencil/random_dist_3D.cu:183-187 declares MPIcuFFT_Pencil<T>* and news either)
+template <typename T> class MPIcuFFT_Pencil : public MPIcuFFT<T> {
+public:
+    MPIcuFFT_Pencil(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1) : MPIcuFFT<T>(c, comm, max_world_size, DFFT_PENCIL) {}
+    virtual void execR2C(void *out, const void *in) { this->execR2C(out, in, 3); }
+    virtual void execC2R(void *out, const void *in) { this->execC2R(out, in, 3); }
+    // partial transforms execR2C/execC2R(out, in, d), include/mpicufft_pencil.hpp:101-111
+    virtual void execR2C(void *out, const void *in, int d)
     {
-        Slab_Partition p(this->getWorldSize());
-        MPIcuFFT<T>::initFFT(g, &p, allocate);
+        if (this->plan_) this->check(dfft_exec_dim(this->plan_, out, const_cast<void *>(in), DFFT_FORWARD, d));
     }
+    virtual void execC2R(void *out, const void *in, int d)
+    {
+        if (this->plan_) this->check(dfft_exec_dim(this->plan_, out, const_cast<void *>(in), DFFT_INVERSE, d));
+    }
+    // include/mpicufft_pencil.hpp:112-116; tables as built in src/pencil/mpicufft_pencil_opt1.cpp:70-93
+    void getPartitionDimensions(Partition_Dimensions &input_dim_, Partition_Dimensions &transposed_dim_, Partition_Dimensions &output_dim_)
+    {
+        if (!this->plan_) return;
+        Partition_Dimensions *dims[3] = {&input_dim_, &transposed_dim_, &output_dim_};
+        for (int which = 0; which < 3; which++) {
+            std::vector<size_t> *sz[3] = {&dims[which]->size_x, &dims[which]->size_y, &dims[which]->size_z};
+            std::vector<size_t> *st[3] = {&dims[which]->start_x, &dims[which]->start_y, &dims[which]->start_z};
+            for (int axis = 0; axis < 3; axis++) {
+                size_t n = 0;
+                this->check(dfft_get_partition_dimensions(this->plan_, which, axis, nullptr, nullptr, 0, &n));
+                sz[axis]->assign(n, 0); st[axis]->assign(n, 0);
+                this->check(dfft_get_partition_dimensions(this->plan_, which, axis, sz[axis]->data(), st[axis]->data(), n, &n));
+            }
+        }
+    }
+
+protected:
+    MPIcuFFT_Pencil(Configurations c, MPI_Comm comm, int max_world_size, int kind) : MPIcuFFT<T>(c, comm, max_world_size, kind) {}
 };
-// partial transforms execR2C/execC2R(out, in, d), include/mpicufft_pencil.hpp:101-111
-template <typename T> struct MPIcuFFT_PencilBase : MPIcuFFT<T> {
-    using MPIcuFFT<T>::MPIcuFFT;
-    using MPIcuFFT<T>::execR2C;
-    using MPIcuFFT<T>::execC2R;
-    void execR2C(void *out, const void *in, int d) { this->check(dfft_exec_dim(this->plan_, out, const_cast<void *>(in), DFFT_FORWARD, d)); }
-    void execC2R(void *out, const void *in, int d) { this->check(dfft_exec_dim(this->plan_, out, const_cast<void *>(in), DFFT_INVERSE, d)); }
-};
-template <typename T> struct MPIcuFFT_Pencil : MPIcuFFT_PencilBase<T> {
-    MPIcuFFT_Pencil(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1) : MPIcuFFT_PencilBase<T>(c, comm, max_world_size, DFFT_PENCIL) {}
-};
-template <typename T> struct MPIcuFFT_Pencil_Opt1 : MPIcuFFT_PencilBase<T> {
-    MPIcuFFT_Pencil_Opt1(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1) : MPIcuFFT_PencilBase<T>(c, comm, max_world_size, DFFT_PENCIL_OPT1) {}
+template <typename T> class MPIcuFFT_Pencil_Opt1 : public MPIcuFFT_Pencil<T> {
+public:
+    MPIcuFFT_Pencil_Opt1(Configurations c, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1) : MPIcuFFT_Pencil<T>(c, comm, max_world_size, DFFT_PENCIL_OPT1) {}
 };

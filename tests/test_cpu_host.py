@@ -70,6 +70,79 @@ def test_plan_algebra_matches_reference_formulas(shape, P1, P2, c2c, prec):
             assert pl.getExchangeTables(which) == [[v * esz for v in t] for t in opl.exchange_tables(r, which)]
 
 
+def _split(n, p):
+    sizes = [n // p + (1 if i < n % p else 0) for i in range(p)]
+    return sizes, [sum(sizes[:i]) for i in range(p)]
+
+
+@pytest.mark.parametrize("shape,P1,P2,c2c", CASES[:8])
+def test_partition_dimensions_match_reference_tables(shape, P1, P2, c2c):
+    """getPartitionDimensions (include/mpicufft_pencil.hpp:112-116) == the three tables of
+    src/pencil/mpicufft_pencil_opt1.cpp:70-93, restated here entry by entry"""
+    Nx, Ny, Nz = shape
+    Nzc = Nz if c2c else Nz // 2 + 1
+    world = dfft.Comm.local(P1 * P2) if P1 * P2 > 1 else None
+    for r in (0, P1 * P2 - 1):
+        pl = dfft.MPIcuFFT_Pencil(dfft.Configurations(), world, rank=r)
+        pl.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(P1, P2), allocate=False, c2c=c2c)
+        inp, tr, out = pl.getPartitionDimensions()
+        assert (inp.size_x, inp.start_x) == _split(Nx, P1) and (inp.size_y, inp.start_y) == _split(Ny, P2)
+        assert (inp.size_z, inp.start_z) == ([Nz], [0])
+        assert (tr.size_x, tr.start_x) == _split(Nx, P1) and (tr.size_y, tr.start_y) == ([Ny], [0])
+        assert (tr.size_z, tr.start_z) == _split(Nzc, P2)
+        assert (out.size_x, out.start_x) == ([Nx], [0]) and (out.size_y, out.start_y) == _split(Ny, P1)
+        assert (out.size_z, out.start_z) == _split(Nzc, P2)
+        i, j = r // P2, r % P2
+        assert pl.getInSize() == (inp.size_x[i], inp.size_y[j], inp.size_z[0])
+        assert pl.getOutSize() == (out.size_x[0], out.size_y[i], out.size_z[j])
+        assert pl.getOutStart() == (0, out.start_y[i], out.start_z[j])
+        d = dfft.Partition_Dimensions()
+        d.size_x, d.size_y, d.size_z = inp.size_x, inp.size_y, inp.size_z
+        d.computeOffsets()
+        assert (d.start_x, d.start_y, d.start_z) == (inp.start_x, inp.start_y, inp.start_z)
+
+
+def test_class_hierarchy_mirrors_the_reference():
+    """include/mpicufft_pencil_opt1.hpp:23, mpicufft_slab_opt1.hpp:70, mpicufft_slab_z_then_yx_opt1.hpp:22: the Opt1
+    classes derive from their opt0 class (the reference's tests hold them through opt0 pointers)"""
+    assert issubclass(dfft.MPIcuFFT_Pencil_Opt1, dfft.MPIcuFFT_Pencil)
+    assert issubclass(dfft.MPIcuFFT_Slab_Opt1, dfft.MPIcuFFT_Slab)
+    assert issubclass(dfft.MPIcuFFT_Slab_Z_Then_YX_Opt1, dfft.MPIcuFFT_Slab_Z_Then_YX)
+    hdr = open(os.path.join(ROOT, "include", "mpicufft_amd.hpp")).read()
+    for derived, base in (("MPIcuFFT_Pencil_Opt1", "MPIcuFFT_Pencil<T>"), ("MPIcuFFT_Slab_Opt1", "MPIcuFFT_Slab<T>"),
+                          ("MPIcuFFT_Slab_Z_Then_YX_Opt1", "MPIcuFFT_Slab_Z_Then_YX<T>")):
+        assert re.search(r"class %s : public %s" % (derived, re.escape(base)), hdr), derived
+
+
+def test_options_and_reinit():
+    """named options (dfft_set_option); the pipeline depth may change between two initFFT calls of one plan"""
+    world = dfft.Comm.local(2)
+    pl = dfft.MPIcuFFT_Slab_Opt1(dfft.Configurations(), world, rank=0)
+    pl.setPipelineChunks(2)
+    pl.initFFT(dfft.GlobalSize(32, 32, 32), dfft.Slab_Partition(2), allocate=False, c2c=True)
+    assert pl.getPipelineChunks() == 2
+    pl.setPipelineChunks(4)                      # (was refused after initFFT in round 1)
+    assert pl.getPipelineChunks() == 2           # ... and applies at the next initFFT
+    pl.initFFT(dfft.GlobalSize(32, 32, 32), dfft.Slab_Partition(2), allocate=False, c2c=True)
+    assert pl.getPipelineChunks() == 4
+    pl.setOption("pipeline_chunks", 3)
+    assert pl.getOption("pipeline_chunks") == 3 and pl.getOption("mirror_inverse") == 0
+    for key in ("mirror_inverse", "point_tables", "shift", "debug_skip", "variant_fx", "order_iz"):
+        pl.setOption(key, 1)
+        assert pl.getOption(key) == 1
+    with pytest.raises(dfft.DfftError, match="unknown option"):
+        pl.setOption("no_such_knob", 1)
+    assert pl.getOption("no_such_knob") == -1
+
+
+def test_r2c_with_two_point_z_axis_plans():
+    """an R2C plan with Nz == 2 must plan its z axis for the Bluestein real modes (it used to pick the plain
+    complex chain and fault at the first launch)"""
+    pl = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations())
+    pl.initFFT(dfft.GlobalSize(8, 8, 2), dfft.Pencil_Partition(1, 1), allocate=False)
+    assert pl.getOutSize() == (8, 8, 2)
+
+
 def test_init_errors():
     pl = dfft.MPIcuFFT_Slab(dfft.Configurations())
     with pytest.raises(dfft.DfftError, match="Invalid Input Partition"):

@@ -52,3 +52,24 @@ def test_cpp_shim_mpi_ranks_sharing_the_gpu(tmp_path, P1, P2, mode):
                          timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert f"ranks {P1 * P2} grid {P1}x{P2}" in out.stdout
+
+
+@needs_mpich
+@pytest.mark.parametrize("kind,opt,P1,P2,nranks,fft_ranks", [
+    ("pencil", 1, 3, 2, 6, 6), ("pencil", 0, 2, 2, 4, 4), ("slab", 1, 5, 1, 5, 5), ("slab", 0, 2, 1, 2, 2),
+    ("pencil", 1, 1, 1, 1, 1),
+    # max_world_size < communicator size: one extra rank stays outside, as the reference's coordinator does
+    ("pencil", 1, 2, 1, 3, 2), ("slab", 1, 2, 1, 3, 2)])
+def test_reference_call_sites_compile_and_run(tmp_path, kind, opt, P1, P2, nranks, fft_ranks):
+    """tests/cpp/ref_caller.cpp holds the bodies of the reference's own callers
+    (tests/src/pencil/random_dist_3D.cu:154-227, tests/src/slab/random_dist_default.cu:155-226) with only the
+    include lines and cuda* -> hip* changed: MPIcuFFT_Pencil<T>* / MPIcuFFT_Slab<T>* receive the Opt1 or opt0
+    object, getPartitionDimensions sizes `out`, initFFT(&global_size, true) for slabs; fp64 and fp32."""
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not os.path.exists(mpiexec):
+        pytest.skip("no mpiexec")
+    exe, env = build(tmp_path, "ref_caller.cpp")
+    out = subprocess.run([mpiexec, "-n", str(nranks), str(exe), kind, str(opt), str(P1), str(P2), str(fft_ranks)], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("tables ok") == 2 and "MISMATCH" not in out.stdout, out.stdout

@@ -1,0 +1,288 @@
+// tools/kbench.hip -- kernel-level benchmark harness on the C ABI (include/dfft_c.h), no Python:
+// per-pass device times of a single-GPU plan with named options, plus two self-checks that need no
+// oracle (plane-wave known answer and round trip).  Parity proper is tests/ (-m gpu) against oracle/.
+//
+//   tools/kbench --size 1024 --prec f64 --mode c2c --iters 5 --opt variant_fy=5 --opt pipeline_chunks=8 --check
+//   tools/kbench --line 2048 --batch 65536 --prec f32 --variant 3         (one pass on natural lines)
+//
+// Build: make -C tools   (hipcc, links ../distributedfft_amd/libdfft_amd.so)
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../include/dfft_c.h"
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+#define DCHK(x) do { int r_ = (x); if (r_ != 0) { fprintf(stderr, "%s -> %d: %s\n", #x, r_, dfft_last_error()); exit(3); } } while (0)
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// uniform [0, 255) like the reference's scaled cuRAND input (tests/src/pencil/base.cu:45-53)
+template <typename R> __device__ __forceinline__ R synth(uint64_t idx) { return (R)((double)(mix64(idx) >> 11) * (255.0 / 9007199254740992.0)); }
+
+template <typename R> __global__ void fill_random(R *p, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = synth<R>(i);
+}
+// superposition of three plane waves with integer frequencies: the transform is N^3 at three points
+struct Waves { int kx[3], ky[3], kz[3]; };
+template <typename R> __global__ void fill_waves(R *p, size_t Nx, size_t Ny, size_t Nz, Waves w)
+{
+    const size_t n = Nx * Ny * Nz;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t z = i % Nz, y = (i / Nz) % Ny, x = i / (Nz * Ny);
+        double re = 0, im = 0;
+        for (int q = 0; q < 3; q++) {
+            const double ph = 2.0 * M_PI * ((double)((x * w.kx[q]) % Nx) / Nx + (double)((y * w.ky[q]) % Ny) / Ny + (double)((z * w.kz[q]) % Nz) / Nz);
+            re += cos(ph); im += sin(ph);
+        }
+        p[2 * i] = (R)re; p[2 * i + 1] = (R)im;
+    }
+}
+// max |got - want| over the spectrum, want = N^3 at the three frequencies, 0 elsewhere; block partial maxima
+template <typename R> __global__ void check_waves(const R *p, size_t Nx, size_t Ny, size_t Nz, Waves w, double *partial)
+{
+    const size_t n = Nx * Ny * Nz;
+    const double peak = (double)n;
+    double m = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t z = i % Nz, y = (i / Nz) % Ny, x = i / (Nz * Ny);
+        double want = 0;
+        for (int q = 0; q < 3; q++) if ((int)x == w.kx[q] && (int)y == w.ky[q] && (int)z == w.kz[q]) want += peak;
+        const double dr = (double)p[2 * i] - want, di = (double)p[2 * i + 1];
+        m = fmax(m, fmax(fabs(dr), fabs(di)));
+    }
+    __shared__ double sm[256];
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]); __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+template <typename R> __global__ void check_random(const R *p, size_t n, double scale, double *partial)
+{
+    double m = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        m = fmax(m, fabs((double)p[i] * scale - (double)synth<R>(i)));
+    __shared__ double sm[256];
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]); __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+
+static double reduce_partials(double *d_part, int nblk)
+{
+    std::vector<double> h(nblk);
+    HIPCHK(hipMemcpy(h.data(), d_part, nblk * sizeof(double), hipMemcpyDeviceToHost));
+    double m = 0;
+    for (double v : h) m = fmax(m, v);
+    return m;
+}
+
+struct Args {
+    size_t Nx = 1024, Ny = 1024, Nz = 1024;
+    std::string prec = "f64", mode = "c2c", label;
+    int iters = 5, check = 0;
+    std::vector<std::pair<std::string, long>> opts;
+    size_t line = 0, batch = 0;
+    int variant = 0, debug = 0;
+    // --slab: all four buffers come from ONE hipMalloc, placed in the order of --perm (letters i o w b = in, out,
+    // work, back) at multiples of (buffer size + --delta bytes): probes how relative placement affects a pass
+    int slab = 0;
+    size_t delta = 0;
+    std::string perm = "wiob";
+};
+
+static Args parse(int argc, char **argv)
+{
+    Args a;
+    for (int i = 1; i < argc; i++) {
+        std::string k = argv[i];
+        auto next = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", k.c_str()); exit(1); } return argv[++i]; };
+        if (k == "--size") {
+            const char *v = next();
+            size_t x = 0, y = 0, z = 0;
+            if (sscanf(v, "%zux%zux%zu", &x, &y, &z) == 3) { a.Nx = x; a.Ny = y; a.Nz = z; }
+            else { a.Nx = a.Ny = a.Nz = (size_t)atoll(v); }
+        } else if (k == "--prec") a.prec = next();
+        else if (k == "--mode") a.mode = next();
+        else if (k == "--iters") a.iters = atoi(next());
+        else if (k == "--check") a.check = 1;
+        else if (k == "--label") a.label = next();
+        else if (k == "--line") a.line = (size_t)atoll(next());
+        else if (k == "--batch") a.batch = (size_t)atoll(next());
+        else if (k == "--variant") a.variant = atoi(next());
+        else if (k == "--debug") a.debug = atoi(next());
+        else if (k == "--slab") a.slab = 1;
+        else if (k == "--delta") { a.slab = 1; a.delta = (size_t)atoll(next()); }
+        else if (k == "--perm") { a.slab = 1; a.perm = next(); }
+        else if (k == "--opt") {
+            std::string kv = next();
+            const size_t eq = kv.find('=');
+            if (eq == std::string::npos) { fprintf(stderr, "--opt key=value\n"); exit(1); }
+            a.opts.emplace_back(kv.substr(0, eq), atol(kv.c_str() + eq + 1));
+        } else { fprintf(stderr, "unknown argument %s\n", k.c_str()); exit(1); }
+    }
+    return a;
+}
+
+template <typename R> static int run_line(const Args &a)
+{
+    const int prec = sizeof(R) == 8 ? DFFT_F64 : DFFT_F32;
+    const size_t n = a.line * a.batch;
+    R *in, *out;
+    HIPCHK(hipMalloc(&in, n * 2 * sizeof(R)));
+    HIPCHK(hipMalloc(&out, n * 2 * sizeof(R)));
+    fill_random<R><<<4096, 256>>>(in, 2 * n);
+    HIPCHK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    DCHK(dfft_fft1d_batched_ex(prec, a.line, a.batch, out, in, DFFT_FORWARD, nullptr, a.variant, a.debug));
+    HIPCHK(hipDeviceSynchronize());
+    double best = 1e30, sum = 0;
+    for (int it = 0; it < a.iters; it++) {
+        HIPCHK(hipEventRecord(e0, nullptr));
+        DCHK(dfft_fft1d_batched_ex(prec, a.line, a.batch, out, in, DFFT_FORWARD, nullptr, a.variant, a.debug));
+        HIPCHK(hipEventRecord(e1, nullptr));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        best = fmin(best, ms); sum += ms;
+    }
+    const double bytes = 2.0 * n * 2 * sizeof(R);
+    double rt = -1;
+    if (a.check && !a.debug) {      // inverse of the forward result must give N * input
+        DCHK(dfft_fft1d_batched_ex(prec, a.line, a.batch, in, out, DFFT_INVERSE, nullptr, a.variant, 0));
+        double *part;
+        HIPCHK(hipMalloc(&part, 1024 * sizeof(double)));
+        check_random<R><<<1024, 256>>>(in, 2 * n, 1.0 / (double)a.line, part);
+        rt = reduce_partials(part, 1024) / 255.0;
+    }
+    printf("LINE %s N=%zu batch=%zu %s variant=%d debug=%d avg %.4f ms min %.4f ms  %.1f GB/s (min)  roundtrip %.2e\n", a.label.c_str(),
+           a.line, a.batch, a.prec.c_str(), a.variant, a.debug, sum / a.iters, best, bytes / best / 1e6, rt);
+    return 0;
+}
+
+template <typename R> static int run_plan(const Args &a)
+{
+    const int prec = sizeof(R) == 8 ? DFFT_F64 : DFFT_F32;
+    const bool c2c = a.mode == "c2c";
+    const size_t esz = 2 * sizeof(R);
+    dfft_plan *plan;
+    DCHK(dfft_plan_create(&plan, DFFT_PENCIL_OPT1, prec, nullptr, nullptr, 0, -1));
+    for (auto &kv : a.opts) DCHK(dfft_set_option(plan, kv.first.c_str(), kv.second));
+    DCHK(dfft_init(plan, a.Nx, a.Ny, a.Nz, 1, 1, c2c ? 1 : 0, a.slab ? 0 : 1));
+    const size_t n = a.Nx * a.Ny * a.Nz;
+    const size_t in_bytes = c2c ? n * esz : n * sizeof(R);
+    const size_t dom = dfft_domain_size(plan);
+    char *in, *out, *back = nullptr, *slab = nullptr;
+    bool alias_back = false;
+    if (a.slab) {
+        const size_t slot = ((std::max(dom, dfft_work_size_device(plan)) + 255) & ~(size_t)255) + a.delta;
+        HIPCHK(hipMalloc(&slab, 4 * slot + 256));
+        char *pos[256] = {nullptr};
+        for (size_t i = 0; i < a.perm.size() && i < 4; i++) pos[(unsigned char)a.perm[i]] = slab + i * slot;
+        in = pos['i']; out = pos['o']; back = pos['b'];
+        if (!in || !out || !back || !pos['w']) { fprintf(stderr, "--perm needs the letters i o w b\n"); exit(1); }
+        DCHK(dfft_set_work_area(plan, pos['w'], nullptr));
+    } else {
+        HIPCHK(hipMalloc(&in, in_bytes));
+        HIPCHK(hipMalloc(&out, dom));
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        alias_back = free_b < in_bytes + (1ull << 30);       // 2048^3: the inverse writes over the input buffer
+        if (!alias_back) HIPCHK(hipMalloc(&back, in_bytes)); else back = in;
+    }
+    const int nblk = 4096;
+    double *part;
+    HIPCHK(hipMalloc(&part, nblk * sizeof(double)));
+    const size_t nreal = in_bytes / sizeof(R);
+    double wave_err = -1, rt_err = -1;
+    auto fwd = [&]() { if (c2c) DCHK(dfft_exec_c2c(plan, out, in, DFFT_FORWARD)); else DCHK(dfft_exec_r2c(plan, out, in)); };
+    auto inv = [&]() { if (c2c) DCHK(dfft_exec_c2c(plan, back, out, DFFT_INVERSE)); else DCHK(dfft_exec_c2r(plan, back, out)); };
+    const bool dbg = dfft_get_option(plan, "debug_skip") > 0;
+    if (a.check && c2c && !dbg) {
+        Waves w = {{1, (int)a.Nx / 2 + 3, (int)a.Nx - 1}, {0, 5 % (int)a.Ny, (int)a.Ny - 2}, {(int)a.Nz - 1, 7 % (int)a.Nz, (int)a.Nz / 2}};
+        fill_waves<R><<<nblk, 256>>>((R *)in, a.Nx, a.Ny, a.Nz, w);
+        HIPCHK(hipDeviceSynchronize());
+        fwd();
+        check_waves<R><<<nblk, 256>>>((const R *)out, a.Nx, a.Ny, a.Nz, w, part);
+        wave_err = reduce_partials(part, nblk) / (double)n;      // relative to the peak N^3
+    }
+    fill_random<R><<<nblk, 256>>>((R *)in, nreal);
+    HIPCHK(hipDeviceSynchronize());
+    fwd(); inv();                                   // warm-up
+    if (a.check && !dbg) {
+        check_random<R><<<nblk, 256>>>((const R *)back, nreal, 1.0 / (double)n, part);
+        rt_err = reduce_partials(part, nblk) / 255.0;
+    }
+    DCHK(dfft_enable_phase_timing(plan, 1));
+    double accf[8] = {0}, accb[8] = {0}, minf[8], minb[8];
+    for (int i = 0; i < 8; i++) minf[i] = minb[i] = 1e30;
+    int nf = 0, nb = 0;
+    double wall = 0;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    for (int it = 0; it < a.iters; it++) {
+        if (alias_back) { fill_random<R><<<nblk, 256>>>((R *)in, nreal); HIPCHK(hipDeviceSynchronize()); }
+        float ms[8];
+        HIPCHK(hipEventRecord(e0, nullptr));
+        fwd();
+        nf = dfft_get_phase_times(plan, ms, 8);
+        for (int i = 0; i < nf; i++) { accf[i] += ms[i]; minf[i] = fmin(minf[i], ms[i]); }
+        inv();
+        nb = dfft_get_phase_times(plan, ms, 8);
+        for (int i = 0; i < nb; i++) { accb[i] += ms[i]; minb[i] = fmin(minb[i], ms[i]); }
+        HIPCHK(hipEventRecord(e1, nullptr));
+        HIPCHK(hipEventSynchronize(e1));
+        float w;
+        HIPCHK(hipEventElapsedTime(&w, e0, e1));
+        wall += w;
+    }
+    std::string optstr;
+    for (auto &kv : a.opts) optstr += " " + kv.first + "=" + std::to_string(kv.second);
+    if (a.slab) optstr += " slab perm=" + a.perm + " delta=" + std::to_string(a.delta);
+    printf("PLAN %s %zux%zux%zu %s %s%s | wave_err %.2e roundtrip %.2e | wall %.3f ms/step\n", a.label.c_str(), a.Nx, a.Ny, a.Nz,
+           a.prec.c_str(), a.mode.c_str(), optstr.c_str(), wave_err, rt_err, wall / a.iters);
+    const size_t Nzc = c2c ? a.Nz : a.Nz / 2 + 1;
+    const double half = (double)a.Nx * a.Ny * Nzc * esz, real_b = (double)in_bytes;
+    double tot = 0;
+    for (int dir = 0; dir < 2; dir++) {
+        const int np = dir == 0 ? nf : nb;
+        for (int i = 0; i < np; i++) {
+            const double avg = (dir == 0 ? accf[i] : accb[i]) / a.iters, mn = dir == 0 ? minf[i] : minb[i];
+            if (avg <= 0) continue;
+            const char *name = dfft_phase_name(i, dir == 0 ? DFFT_FORWARD : DFFT_INVERSE);
+            const bool zpass = name[0] == 'z';
+            const double bytes = zpass ? real_b + half : 2 * half;
+            printf("  %-10s avg %8.3f ms  min %8.3f ms  %8.1f GB/s\n", name, avg, mn, bytes / avg / 1e6);
+            tot += avg;
+        }
+    }
+    printf("  total passes %.3f ms\n", tot);
+    DCHK(dfft_plan_destroy(plan));
+    if (a.slab) HIPCHK(hipFree(slab));
+    else {
+        HIPCHK(hipFree(in)); HIPCHK(hipFree(out));
+        if (!alias_back) HIPCHK(hipFree(back));
+    }
+    HIPCHK(hipFree(part));
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    Args a = parse(argc, argv);
+    if (a.line) return a.prec == "f64" ? run_line<double>(a) : run_line<float>(a);
+    return a.prec == "f64" ? run_plan<double>(a) : run_plan<float>(a);
+}
