@@ -4,16 +4,23 @@
 Metric (BASELINE.json): 3-D FFT GFLOP/s with the 5*N^3*log2(N^3) convention, forward + inverse,
 1024^3 fp64 complex, at 1/2/4/8 GPUs.  A "step" is one forward plus one inverse transform of the
 resident grid (the reference's testcase 0 + testcase 2 back to back,
-tests/src/pencil/random_dist_3D.cu:154-227, :506-579), inputs already in HBM.
+tests/src/pencil/random_dist_3D.cu:154-227, :506-579), inputs already in HBM.  Protocol of the
+reference's jobs: 10 warm-up + 20 timed iterations (jobs/bwunicluster/pencil/benchmarks_base.json:4-8).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py                      # 1 GPU, 1024^3 fp64, 10 warm-up + 20 steps
+    python bench.py --size 2048 --precision float          # config 5's grid on one GPU (in = back aliased)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        --master-port 29500 bench.py --gpus 8 --steps 5 --warmup 2
+        --master-port 29500 bench.py --gpus 8
+    python bench.py --dry-run            # build the C4 / C5 plans of all 8 ranks on a host without a GPU
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- achieved HBM GB/s of the dominant kernel (the axis-pass kernel), from
-                  algorithmic bytes per launch / HIP-event duration on the launch stream
-  cpu_baseline -- the CPU oracle (a port: the reference has no CPU path) timed on this host
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline          -- achieved HBM GB/s of the dominant kernel (the axis-pass kernel), from algorithmic bytes per
+                       launch / HIP-event duration on the launch stream
+  cpu_baseline      -- the CPU oracle (a port: the reference has no CPU path) timed on this host
+  config.per_pass   -- device time and achieved TB/s of every pass of the timed plan
+  config.multi_rank_path (N = 1 only) -- the same grid through the code path every rank runs at N > 1: mirrored
+                       inverse order (x, y, z) and segmented (8-chunk) address tables, so that a 1-GPU lease
+                       predicts the per-GPU compute of the multi-GPU runs
 """
 import argparse
 import json
@@ -27,13 +34,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+XGMI_LINK_GBS = 153.0   # same guide: per link and direction
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=1024, help="cube edge (BASELINE: 1024)")
     ap.add_argument("--precision", default="double", choices=["double", "float"])
     ap.add_argument("--p1", type=int, default=0)
@@ -44,8 +52,10 @@ def parse():
     ap.add_argument("--decomp", default="auto", choices=["auto", "slab", "pencil"],
                     help="auto = slab on one xGMI node (every GPU pair has its own link), pencil = BASELINE 2x4 / 2x2")
     ap.add_argument("--no-alt", action="store_true", help="skip the alternative-decomposition measurement")
+    ap.add_argument("--no-multi-rank-path", action="store_true", help="N = 1: skip the multi-rank code path measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=512, help="cube edge of the CPU-baseline sample")
+    ap.add_argument("--cpu-n", type=int, default=0, help="cube edge of the CPU-baseline sample (0 = 1024 if RAM allows, else 512)")
+    ap.add_argument("--dry-run", action="store_true", help="plan C4 / C5 for all 8 ranks without a GPU and print the memory budget")
     return ap.parse_args()
 
 
@@ -64,38 +74,95 @@ def choose_partition(n, decomp):
     return (n, 1)
 
 
-def cpu_baseline(n):
-    """Times the CPU oracle (oracle/dfft_oracle.c, OpenMP over lines) on an n^3 fp64 complex
-    forward+inverse.  kind = 'port': the reference has no CPU implementation to build."""
+def flops_per_direction(n):
+    return 5.0 * float(n) ** 3 * math.log2(float(n) ** 3)
+
+
+def cpu_baseline(n_req):
+    """Times the CPU oracle (oracle/dfft_oracle.c, OpenMP over lines, all host cores) on an n^3 fp64
+    complex grid, forward and inverse separately, plus a numpy.fft.fftn cross-check line
+    (BASELINE.md 3).  kind = 'port': the reference has no CPU implementation to build."""
     import ctypes as C
 
     import numpy as np
 
     from oracle import oracle as orc
     L = orc.lib()
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+    except Exception:   # noqa: BLE001
+        avail = 0
+    n = n_req or (1024 if avail > 48 * 2 ** 30 else 512)
     g = orc.fill_block((n, n, n), (0, 0, 0), (n, n, n), 2, seed=20260921)
     ptr = g.ctypes.data_as(C.c_void_p)
     L.orc_fft3d_c2c(ptr, n, n, n, -1)      # warm-up (thread pool, page faults)
     L.orc_fft3d_c2c(ptr, n, n, n, +1)
     g /= float(n) ** 3
-    iters, t0 = 0, time.perf_counter()
+    tf = tb = 0.0
+    iters, t_start = 0, time.perf_counter()
     while True:
+        t0 = time.perf_counter()
         L.orc_fft3d_c2c(ptr, n, n, n, -1)
+        t1 = time.perf_counter()
         L.orc_fft3d_c2c(ptr, n, n, n, +1)
+        t2 = time.perf_counter()
         g /= float(n) ** 3
+        tf += t1 - t0
+        tb += t2 - t1
         iters += 1
-        dt = time.perf_counter() - t0
-        if dt > 12.0 or iters >= 20:
+        if time.perf_counter() - t_start > 12.0 or iters >= 3:      # 1 warm-up + up to 3 timed (BASELINE.md 3)
             break
-    flops = 2 * 5.0 * n ** 3 * math.log2(float(n) ** 3)
-    return {"value": round(flops * iters / dt / 1e9, 3), "unit": "GFLOP/s", "cores": orc.num_threads(),
+    fl = flops_per_direction(n)
+    # cross-check against an independent implementation (pocketfft) on a 256^3 sample of the same generator
+    m = 256
+    s = orc.fill_block((m, m, m), (0, 0, 0), (m, m, m), 2, seed=20260921)
+    t0 = time.perf_counter()
+    want = np.fft.fftn(s)
+    t_np = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    got = orc.fft3d_c2c(s, -1)
+    t_or = time.perf_counter() - t0
+    dev = float(np.max(np.abs(got - want)) / np.max(np.abs(want)))
+    return {"value": round(2 * fl * iters / (tf + tb) / 1e9, 3), "unit": "GFLOP/s", "cores": orc.num_threads(),
             "kind": "port",
-            "sample": f"{n}^3 fp64 complex forward+inverse x{iters} ({dt:.1f} s), oracle/dfft_oracle.c, "
-                      f"host has {os.cpu_count()} cores"}
+            "forward_ms": round(tf / iters * 1e3, 1), "inverse_ms": round(tb / iters * 1e3, 1),
+            "forward_GFLOPs": round(fl * iters / tf / 1e9, 2), "inverse_GFLOPs": round(fl * iters / tb / 1e9, 2),
+            "numpy_check": {"grid": f"{m}^3", "numpy_fftn_ms": round(t_np * 1e3, 1), "oracle_ms": round(t_or * 1e3, 1),
+                            "max_rel_dev": dev},
+            "sample": f"{n}^3 fp64 complex, 1 warm-up + {iters} timed forward and inverse transforms ({tf + tb:.1f} s), "
+                      f"oracle/dfft_oracle.c with {orc.num_threads()} OpenMP threads, host has {os.cpu_count()} cores"}
+
+
+def dry_run():
+    """Plans BASELINE's C4 (1024^3 fp64, 2x4) and C5 (2048^3 fp32, 2x4) for every rank on this host (no GPU
+    needed: decomposition tables only) and prints the per-GPU memory budget."""
+    import distributedfft_amd as dfft
+    out = {}
+    for name, n, prec, (P1, P2) in (("C3", 512, "double", (2, 1)), ("C4", 1024, "double", (2, 4)), ("C5", 2048, "float", (2, 4)),
+                                    ("C4-slab", 1024, "double", (8, 1)), ("C5-slab", 2048, "float", (8, 1))):
+        esz = 16 if prec == "double" else 8
+        world = dfft.Comm.local(P1 * P2)
+        per_rank = []
+        for r in range(P1 * P2):
+            pl = (dfft.MPIcuFFT_Slab_Opt1 if P2 == 1 else dfft.MPIcuFFT_Pencil_Opt1)(dfft.Configurations(), world, precision=prec, rank=r)
+            pl.initFFT(dfft.GlobalSize(n, n, n), dfft.Partition(P1, P2), allocate=False, c2c=True)
+            isz = pl.getInSize()
+            in_b = isz[0] * isz[1] * isz[2] * esz
+            per_rank.append({"in": in_b, "out": pl.getDomainSize(), "work": pl.getWorkSizeDevice(),
+                             "total": 2 * in_b + pl.getDomainSize() + pl.getWorkSizeDevice()})
+        worst = max(per_rank, key=lambda d: d["total"])
+        out[name] = {"grid": f"{n}^3 {prec}", "partition": f"{P1}x{P2}", "domain_GiB": round(worst["out"] / 2 ** 30, 3),
+                     "work_GiB": round(worst["work"] / 2 ** 30, 3),
+                     "per_gpu_total_GiB (in + out + back + work)": round(worst["total"] / 2 ** 30, 3),
+                     "fits_288_GB": worst["total"] < 268 * 2 ** 30}
+    print(json.dumps({"dry_run": out}))
 
 
 def main():
     args = parse()
+    if args.dry_run:
+        return dry_run()
     import torch
 
     import distributedfft_amd as dfft
@@ -109,7 +176,8 @@ def main():
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         ngpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    dev = local_rank % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    dev = local_rank % ndev
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
@@ -134,13 +202,15 @@ def main():
     tmode = "torch" if args.backend == "gloo" else args.transport
     tmode_box = [tmode]
 
-    def make_plan(P1, P2):
+    def make_plan(P1, P2, options=None):
         comm, transport = None, "none"
         if world > 1:
             from distributedfft_amd.torch_transport import make_comm
             comm, transport = make_comm(dist, rank, world, P1, P2, tmode_box[0])
         kind = dfft.MPIcuFFT_Slab_Opt1 if P2 == 1 and ngpus > 1 else dfft.MPIcuFFT_Pencil_Opt1
         plan = kind(dfft.Configurations(), comm, precision=prec, rank=rank)
+        for k, v in (options or {}).items():
+            plan.setOption(k, v)
         plan.initFFT(dfft.GlobalSize(N, N, N), dfft.Partition(P1, P2), allocate=False, c2c=True)
         plan.setStream(stream)
         if comm is not None and transport == "torch":
@@ -160,19 +230,39 @@ def main():
     # cuRAND uniforms by 255, tests/src/pencil/base.cu:45-53), generated on the device
     isz = plan.getInSize()
     n_in = isz[0] * isz[1] * isz[2]
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(20260921 + rank)
-    d_in = torch.empty(n_in, dtype=cdt, device="cuda")
-    v = torch.view_as_real(d_in)
     chunk = 1 << 26
-    for o in range(0, n_in, chunk):
-        e = min(n_in, o + chunk)
-        v[o:e] = torch.rand((e - o, 2), dtype=rdt, device="cuda", generator=gen) * 255.0
+
+    def fill(t):
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(20260921 + rank)
+        v = torch.view_as_real(t)
+        for o in range(0, n_in, chunk):
+            e = min(n_in, o + chunk)
+            v[o:e] = torch.rand((e - o, 2), dtype=rdt, device="cuda", generator=gen) * 255.0
+
+    def round_trip_error(back):
+        """max |back/N^3 - x| / max |x| against the regenerated input (x itself may have been overwritten)"""
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(20260921 + rank)
+        worst = torch.zeros((), dtype=torch.float64, device="cuda")
+        v = torch.view_as_real(back)
+        for o in range(0, n_in, chunk):
+            e = min(n_in, o + chunk)
+            ref = torch.rand((e - o, 2), dtype=rdt, device="cuda", generator=gen) * 255.0
+            worst = torch.maximum(worst, (v[o:e] / float(N) ** 3 - ref).abs().max().to(torch.float64))
+        e = (worst / 255.0).reshape(1)
+        if dist is not None:
+            dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        return float(e)
+
+    d_in = torch.empty(n_in, dtype=cdt, device="cuda")
+    fill(d_in)
     d_out = torch.empty(domain // esz, dtype=cdt, device="cuda")
-    d_back = torch.empty(n_in, dtype=cdt, device="cuda")
+    free_b, _ = torch.cuda.mem_get_info()
+    aliased = free_b < n_in * esz + (2 << 30)     # 2048^3 fp32 on one GPU: the inverse writes back over the input
+    d_back = d_in if aliased else torch.empty(n_in, dtype=cdt, device="cuda")
     if comm is not None and transport == "torch":
         comm.register(d_out)
-    ref_sample = d_in[:4096].clone()
     torch.cuda.synchronize()
 
     def barrier():
@@ -180,26 +270,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        with torch.cuda.stream(side):
-            plan.execC2C(d_out, d_in, dfft.FORWARD)       # blocking, like the reference's exec
-            plan.execC2C(d_back, d_out, dfft.INVERSE)
-        torch.cuda.synchronize()
+    def run_steps(pl, k, out_buf, back_buf, collect=False):
+        """k forward + inverse pairs; returns (seconds, {phase name: total ms}, launches of FFT passes)"""
+        acc, launches = {}, 0
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            with torch.cuda.stream(side):
+                pl.execC2C(out_buf, d_in, dfft.FORWARD)       # blocking, like the reference's exec
+                ph_f = pl.getPhaseTimes(dfft.FORWARD) if collect else []
+                pl.execC2C(back_buf, out_buf, dfft.INVERSE)
+                ph_b = pl.getPhaseTimes(dfft.INVERSE) if collect else []
+            for name, ms in ph_f + ph_b:
+                acc[name] = acc.get(name, 0.0) + ms
+                launches += "FFT" in name
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            if acc:
+                names = sorted(acc)
+                t = torch.tensor([acc[n] for n in names], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)      # max over ranks of the per-phase device times
+                acc = dict(zip(names, t.tolist()))
+        return dt, acc, launches
 
-    def warm_and_check():
-        for _ in range(args.warmup):
-            step()
-        # round-trip check on the warm-up result (reference testcase 3), worst rank
+    def warm_and_check(pl, out_buf, back_buf):
+        run_steps(pl, args.warmup, out_buf, back_buf)
         if args.warmup == 0:
             return None
-        diff = (d_back[:4096] / float(N) ** 3 - ref_sample).abs().max() / ref_sample.abs().max()
-        full = (d_back / float(N) ** 3 - d_in).abs().max() / d_in.abs().max()
-        e = torch.maximum(diff, full).reshape(1).to(torch.float64)
-        if dist is not None:
-            dist.all_reduce(e, op=dist.ReduceOp.MAX)
-        return float(e)
+        return round_trip_error(back_buf)      # round-trip check on the warm-up result (reference testcase 3), worst rank
 
-    rt_err = warm_and_check()
+    rt_err = warm_and_check(plan, d_out, d_back)
     tol = 1e-10 if prec == "double" else 5e-5
     if rt_err is not None and not rt_err < tol and world > 1 and transport.startswith("rccl") and args.transport == "auto":
         # the native RCCL exchange produced a wrong round trip at full size: measure with the torch
@@ -211,70 +315,83 @@ def main():
         plan, comm, transport, work = make_plan(P1, P2)
         comm.register(d_out)
         transport = "torch (fallback: native RCCL failed the full-size round trip)"
-        rt_err = warm_and_check()
+        if aliased:
+            fill(d_in)
+        rt_err = warm_and_check(plan, d_out, d_back)
+    if aliased:
+        fill(d_in)          # the timed region must start from the input, not from a round-tripped copy
 
     plan.enablePhaseTiming(True)
-    kern_ms, kern_launches = 0.0, 0
-    exch_ms = 0.0
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        with torch.cuda.stream(side):
-            plan.execC2C(d_out, d_in, dfft.FORWARD)
-            ph_f = plan.getPhaseTimes(dfft.FORWARD)
-            plan.execC2C(d_back, d_out, dfft.INVERSE)
-            ph_b = plan.getPhaseTimes(dfft.INVERSE)
-        for name, ms in ph_f + ph_b:
-            if "FFT" in name:
-                kern_ms += ms
-                kern_launches += 1
-            else:
-                exch_ms += ms
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        # max over ranks of the per-phase device times as well
-        t = torch.tensor([kern_ms, exch_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        kern_ms, exch_ms = float(t[0]), float(t[1])
+    dt, phases, kern_launches = run_steps(plan, args.steps, d_out, d_back, collect=True)
+    kern_ms = sum(ms for name, ms in phases.items() if "FFT" in name)
+    exch_ms = sum(ms for name, ms in phases.items() if "FFT" not in name)
+
+    vol_bytes = 2.0 * esz * float(N) ** 3 / ngpus      # one axis pass reads the local volume once and writes it once
+
+    def per_pass(ph, steps):
+        out = {}
+        for name, ms in ph.items():
+            m = ms / steps
+            out[name] = {"ms": round(m, 3)}
+            if "FFT" in name and m > 0:
+                out[name]["TBps"] = round(vol_bytes / (m * 1e-3) / 1e12, 3)
+        return out
+
+    # N = 1: the code path of the N > 1 runs on the same grid (mirrored inverse order, 8-chunk segment tables)
+    multi_rank_path = None
+    chunks_main = plan.getPipelineChunks()
+    free_b, _ = torch.cuda.mem_get_info()
+    if ngpus == 1 and not args.no_multi_rank_path and free_b < plan.getWorkSizeDevice() + (2 << 30):
+        del plan            # 2048^3 fp32: only one work area fits next to the grid
+        plan = None
+    if ngpus == 1 and not args.no_multi_rank_path:
+        plan_m, _, _, _ = make_plan(1, 1, {"mirror_inverse": 1, "pipeline_chunks": 8})
+        ksteps = max(1, min(args.steps, 10))
+        run_steps(plan_m, 2, d_out, d_back)
+        rt_m = round_trip_error(d_back)
+        if aliased:
+            fill(d_in)
+        plan_m.enablePhaseTiming(True)
+        dtm, phm, _ = run_steps(plan_m, ksteps, d_out, d_back, collect=True)
+        multi_rank_path = {"what": "same grid, one GPU: inverse in the multi-rank pass order x^-1, y^-1, z^-1 (strided read of the "
+                                   "API layout), every pass cut into 8 pipeline chunks with segmented address tables",
+                           "ms_per_step": round(dtm / ksteps * 1e3, 3), "steps": ksteps, "round_trip_rel_linf": rt_m,
+                           "value_GFLOPs": round(2 * flops_per_direction(N) * ksteps / dtm / 1e9, 1),
+                           "per_pass": per_pass(phm, ksteps)}
+        del plan_m
 
     # the BASELINE-named pencil grid (2x2 / 2x4) measured next to the chosen decomposition
     alt = None
     alt_part = pencil_partition(ngpus)
     if world > 1 and not args.no_alt and alt_part != (P1, P2) and not (args.p1 and args.p2):
-        del d_back
+        if not aliased:
+            del d_back
         plan2, comm2, transport2, work2 = make_plan(*alt_part)
         isz2 = plan2.getInSize()
         n2 = isz2[0] * isz2[1] * isz2[2]
-        a_in = d_in[:n2] if n2 <= d_in.numel() else torch.zeros(n2, dtype=cdt, device="cuda")
+        assert n2 == n_in, "slab and pencil input blocks hold the same number of points"
         a_out = torch.empty(plan2.getDomainSize() // esz, dtype=cdt, device="cuda")
-        a_back = torch.empty(n2, dtype=cdt, device="cuda")
+        a_back = d_in if aliased else torch.empty(n2, dtype=cdt, device="cuda")
         if comm2 is not None and transport2 == "torch":
             comm2.register(a_out)
-        with torch.cuda.stream(side):
-            for _ in range(max(1, args.warmup)):
-                plan2.execC2C(a_out, a_in, dfft.FORWARD)
-                plan2.execC2C(a_back, a_out, dfft.INVERSE)
-        alt_rt = float((a_back / float(N) ** 3 - a_in).abs().max() / a_in.abs().max())
-        barrier()
-        t0 = time.perf_counter()
-        with torch.cuda.stream(side):
-            for _ in range(args.steps):
-                plan2.execC2C(a_out, a_in, dfft.FORWARD)
-                plan2.execC2C(a_back, a_out, dfft.INVERSE)
-        barrier()
-        dt2 = time.perf_counter() - t0
-        t = torch.tensor([dt2], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt2 = float(t.item())
-        alt = {"decomposition": f"pencil {alt_part[0]}x{alt_part[1]} (BASELINE.json configs)", "transport": transport2,
+        run_steps(plan2, max(1, min(args.warmup, 3)), a_out, a_back)
+        alt_rt = round_trip_error(a_back)
+        if aliased:
+            fill(d_in)
+        plan2.enablePhaseTiming(True)
+        dt2, ph2, _ = run_steps(plan2, args.steps, a_out, a_back, collect=True)
+        ex2 = sum(ms for name, ms in ph2.items() if "FFT" not in name)
+        vol = esz * float(N) ** 3 / ngpus
+        a1, a2 = alt_part
+        alt = {"decomposition": f"pencil {a1}x{a2} (BASELINE.json configs)", "transport": transport2,
                "ms_per_step": round(dt2 / args.steps * 1e3, 3), "round_trip_rel_linf": alt_rt,
-               "value": round(2 * 5.0 * float(N) ** 3 * math.log2(float(N) ** 3) * args.steps / dt2 / 1e9, 1)}
+               "value": round(2 * flops_per_direction(N) * args.steps / dt2 / 1e9, 1),
+               "per_pass": per_pass(ph2, args.steps), "exchange_ms_per_step": round(ex2 / args.steps, 3),
+               # bytes one GPU sends per step: exchange 1 inside the row group (a2 ranks), exchange 2 inside the column group
+               "xgmi_bytes_out_per_gpu_per_step": 2.0 * vol * ((a2 - 1) / a2 + (a1 - 1) / a1),
+               "links_in_use": {"exchange 1": a2 - 1, "exchange 2": a1 - 1}}
 
-    flops_step = 2 * 5.0 * float(N) ** 3 * math.log2(float(N) ** 3)
+    flops_step = 2 * flops_per_direction(N)
     ms_per_step = dt / args.steps * 1e3
     value = flops_step * args.steps / dt / 1e9
 
@@ -282,25 +399,26 @@ def main():
     # GPU; `pipeline_chunks` launches when the pass is pipelined against an exchange) reads the
     # local volume once and writes it once: algorithmic bytes = 2 * esz * N^3 / n_gpus
     # (SURVEY.md 8d).  Duration = HIP events around the launches on the launch stream.
-    bytes_launch = 2.0 * esz * float(N) ** 3 / ngpus
     avg_ms = kern_ms / max(kern_launches, 1)
-    achieved = bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    achieved = vol_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "kernel": "dfft::fft_pass_kernel", "avg_launch_ms": round(avg_ms, 4),
-                "launches_timed": kern_launches, "alg_bytes_per_launch": bytes_launch,
-                "launches_per_pass": plan.getPipelineChunks() if ngpus > 1 else 1}
+                "launches_timed": kern_launches, "alg_bytes_per_launch": vol_bytes,
+                "launches_per_pass": chunks_main if ngpus > 1 else 1}
 
-    # HBM bytes per launch from the committed PMC profile of this kernel on this workload
-    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 read correction applied)
+    # HBM bytes per launch: NOT measured by this run.  It is the figure of the committed PMC profile of this kernel
+    # on this workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 read correction applied)
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
         if ngpus == 1 and N == 1024 and prec == "double":
             roofline["traffic"] = pm["hbm_bytes_per_launch"]
-            roofline["traffic_source"] = "profiles/r1_pmc_traffic.json"
+            roofline["traffic_static"] = True
+            roofline["traffic_source"] = "profiles/r1_pmc_traffic.json (a committed rocprofv3 PMC run, not this run)"
     except Exception:   # noqa: BLE001
         pass
 
+    rccl_nranks = comm.info()[1] if (comm is not None and hasattr(comm, "info")) else 0
     if rank == 0:
         out = {
             "metric": "3D FFT GFLOP/s (5N^3 log2 N^3 per direction), forward+inverse",
@@ -313,10 +431,17 @@ def main():
                        (f"slab P={P1}" if P2 == 1 else f"pencil {P1}x{P2}"),
                        "transport": transport, "exchange_ms_per_step": round(exch_ms / args.steps, 3),
                        "fft_ms_per_step": round(kern_ms / args.steps, 3),
-                       "pipeline_chunks": plan.getPipelineChunks()},
+                       "pipeline_chunks": chunks_main,
+                       # what the transport itself says (ncclCommCount; 0 = the torch transport, ask torch.distributed)
+                       "rccl_nranks": rccl_nranks, "world_size": world, "devices_visible": ndev,
+                       "ranks_per_device": max(1, -(-world // ndev)),
+                       "per_pass": per_pass(phases, args.steps),
+                       "input_aliased_with_inverse_output": bool(aliased)},
             "round_trip_rel_linf": rt_err,
             "roofline": roofline,
         }
+        if multi_rank_path is not None:
+            out["config"]["multi_rank_path"] = multi_rank_path
         if alt is not None:
             out["config"]["alt"] = alt
         if ngpus > 1:
@@ -325,7 +450,7 @@ def main():
             vol = esz * float(N) ** 3 / ngpus
             out_bytes = 2.0 * vol * ((P1 - 1) / P1 + (P2 - 1) / P2)
             links = max(P1 - 1, 1) if P2 == 1 else None
-            xg = {"bytes_out_per_gpu_per_step": out_bytes,
+            xg = {"bytes_out_per_gpu_per_step": out_bytes, "link_peak_GBps": XGMI_LINK_GBS,
                   "achieved_GBps_per_gpu": round(out_bytes / (exch_ms / args.steps * 1e-3) / 1e9, 1) if exch_ms > 0 else None}
             if links:
                 xg["links_in_use"] = links

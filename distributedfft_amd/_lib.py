@@ -35,6 +35,7 @@ SYMBOLS = [
     ("dfft_rccl_unique_id", _i, [_vp]),
     ("dfft_comm_create_rccl", _i, [_vp, _i, _i, C.POINTER(_vp)]),
     ("dfft_comm_create_callback", _i, [_i, _i, ALLTOALLV_FN, _vp, C.POINTER(_vp)]),
+    ("dfft_comm_info", _i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     ("dfft_comm_destroy", _i, [_vp]),
     ("dfft_plan_create", _i, [C.POINTER(_vp), _i, _i, C.POINTER(Config), _vp, _i, _i]),
     ("dfft_plan_destroy", _i, [_vp]),

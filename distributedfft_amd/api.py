@@ -143,6 +143,12 @@ class Comm:
         check(lib().dfft_rccl_unique_id(buf))
         return buf.raw
 
+    def info(self):
+        """(nranks, transport_nranks): the second is ncclCommCount for the RCCL transport, 0 otherwise"""
+        a, b = C.c_int(0), C.c_int(0)
+        check(lib().dfft_comm_info(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def destroy(self):
         if self._h:
             lib().dfft_comm_destroy(self._h)

@@ -65,33 +65,39 @@ struct LocalWorld : dfft_comm {
     }
     int alltoallv(int myrank, const void *send, const size_t *scount, const size_t *sdispl, void *recv,
                   const size_t *rcount, const size_t *rdispl, const int *group, int ngroup, int me,
-                  hipStream_t stream) override
+                  hipStream_t stream, int /*channel*/) override
     {
         (void)scount;
+        // A failing rank must still meet the others at both barriers (they would wait forever otherwise):
+        // remember the first error, skip the device work after it, return it at the end.
+        int err = 0;
+        auto note = [&](hipError_t e, const char *what) {
+            if (e != hipSuccess && !err) { err = (int)e; set_error(std::string(what) + ": " + hipGetErrorString(e)); }
+        };
         Slot &mine = slots[myrank];
         if (!mine.ready) {
-            HIP_TRY(hipEventCreateWithFlags(&mine.ready, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&mine.done, hipEventDisableTiming));
+            note(hipEventCreateWithFlags(&mine.ready, hipEventDisableTiming), "hipEventCreate");
+            if (!err) note(hipEventCreateWithFlags(&mine.done, hipEventDisableTiming), "hipEventCreate");
         }
         mine.send = static_cast<const char *>(send);
         mine.sdispl = sdispl;
         mine.group = group;
         mine.ngroup = ngroup;
-        HIP_TRY(hipEventRecord(mine.ready, stream));
+        if (!err) note(hipEventRecord(mine.ready, stream), "hipEventRecord");
         barrier(myrank);   // everyone has published
-        for (int q = 0; q < ngroup; q++) {
+        for (int q = 0; q < ngroup && !err; q++) {
             const Slot &peer = slots[group[q]];
-            if (group[q] != myrank) HIP_TRY(hipStreamWaitEvent(stream, peer.ready, 0));
-            if (rcount[q])
-                HIP_TRY(hipMemcpyAsync(static_cast<char *>(recv) + rdispl[q], peer.send + peer.sdispl[me],
-                                       rcount[q], hipMemcpyDeviceToDevice, stream));
+            if (group[q] != myrank && peer.ready) note(hipStreamWaitEvent(stream, peer.ready, 0), "hipStreamWaitEvent");
+            if (rcount[q] && !err)
+                note(hipMemcpyAsync(static_cast<char *>(recv) + rdispl[q], peer.send + peer.sdispl[me], rcount[q],
+                                    hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync");
         }
-        HIP_TRY(hipEventRecord(mine.done, stream));
+        if (!err) note(hipEventRecord(mine.done, stream), "hipEventRecord");
         barrier(myrank);   // everyone has enqueued its pulls
         // my send buffer may be overwritten by my next kernel only after all peers pulled it
-        for (int q = 0; q < ngroup; q++)
-            if (group[q] != myrank) HIP_TRY(hipStreamWaitEvent(stream, slots[group[q]].done, 0));
-        return 0;
+        for (int q = 0; q < ngroup && !err; q++)
+            if (group[q] != myrank && slots[group[q]].done) note(hipStreamWaitEvent(stream, slots[group[q]].done, 0), "hipStreamWaitEvent");
+        return err;
     }
 };
 
@@ -106,6 +112,7 @@ struct RcclApi {
     int (*GetUniqueId)(void *) = nullptr;
     int (*CommInitRank)(void **, int, /*ncclUniqueId by value: 128 bytes*/ Id128, int) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
     int (*CommSplit)(void *, int, int, void **, void *) = nullptr;
     int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
@@ -128,6 +135,7 @@ static RcclApi *rccl()
         api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.h, "ncclGetUniqueId");
         api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.h, "ncclCommInitRank");
         api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.h, "ncclCommDestroy");
+        api.CommCount = (decltype(api.CommCount))dlsym(api.h, "ncclCommCount");
         api.CommSplit = (decltype(api.CommSplit))dlsym(api.h, "ncclCommSplit");
         api.Send = (decltype(api.Send))dlsym(api.h, "ncclSend");
         api.Recv = (decltype(api.Recv))dlsym(api.h, "ncclRecv");
@@ -163,9 +171,16 @@ struct RcclComm : dfft_comm {
         if (R && comm2 && R->CommDestroy) R->CommDestroy(comm2);
         if (R && comm && R->CommDestroy) R->CommDestroy(comm);
     }
+    int transport_nranks() const override
+    {
+        RcclApi *R = rccl();
+        int n = 0;
+        if (!R || !R->CommCount || !comm || R->CommCount(comm, &n) != 0) return 0;
+        return n;
+    }
     int alltoallv(int myrank, const void *send, const size_t *scount, const size_t *sdispl, void *recv,
                   const size_t *rcount, const size_t *rdispl, const int *group, int ngroup, int me,
-                  hipStream_t stream) override
+                  hipStream_t stream, int channel) override
     {
         RcclApi *R = rccl();
         if (!R) { set_error("librccl not available"); return 1; }
@@ -177,13 +192,22 @@ struct RcclComm : dfft_comm {
         if (rcount[me])
             HIP_TRY(hipMemcpyAsync(r + rdispl[me], s + sdispl[me], rcount[me], hipMemcpyDeviceToDevice, stream));
         NCCL_TRY(R->GroupStart());
-        for (int i = 1; i < ngroup; i++) {
+        // a failing call inside the group must not leave the group open: remember the first error, stop
+        // queueing, always close the group
+        int err = 0;
+        std::string what;
+        for (int i = 1; i < ngroup && !err; i++) {
             // ring order (me+i)%P like the reference's comm_order (mpicufft_pencil_opt1.cpp:107-113)
             const int to = (me + i) % ngroup, from = (me - i + ngroup) % ngroup;
-            if (scount[to]) NCCL_TRY(R->Send(s + sdispl[to], scount[to], /*ncclInt8*/ 0, group[to], use, stream));
-            if (rcount[from]) NCCL_TRY(R->Recv(r + rdispl[from], rcount[from], 0, group[from], use, stream));
+            if (scount[to] && (err = R->Send(s + sdispl[to], scount[to], /*ncclInt8*/ 0, group[to], use, stream)) != 0) { what = "ncclSend"; break; }
+            if (rcount[from] && (err = R->Recv(r + rdispl[from], rcount[from], 0, group[from], use, stream)) != 0) { what = "ncclRecv"; break; }
         }
-        NCCL_TRY(R->GroupEnd());
+        const int end = R->GroupEnd();
+        if (!err && end) { err = end; what = "ncclGroupEnd"; }
+        if (err) {
+            set_error(what + ": " + (R->GetErrorString ? R->GetErrorString(err) : "rccl error"));
+            return 1000 + err;
+        }
         (void)myrank;
         return 0;
     }
@@ -233,7 +257,7 @@ struct CallbackComm : dfft_comm {
     int fixed_rank() const override { return rank; }
     int alltoallv(int myrank, const void *send, const size_t *scount, const size_t *sdispl, void *recv,
                   const size_t *rcount, const size_t *rdispl, const int *group, int ngroup, int me,
-                  hipStream_t stream) override
+                  hipStream_t stream, int /*channel*/) override
     {
         (void)myrank;
         int r = fn(user, send, scount, sdispl, recv, rcount, rdispl, group, ngroup, me, (void *)stream);

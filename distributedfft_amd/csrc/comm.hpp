@@ -16,13 +16,15 @@ struct dfft_comm {
     virtual int fixed_rank() const { return -1; }
     // counts/displacements in bytes; group = global ranks, me = my index in group.
     // `channel` (0 or 1) lets a transport keep independent resources per exchange so that the two
-    // exchanges of a pencil plan, which use disjoint links, may be in flight at the same time.
-    int channel = 0;
+    // exchanges of a pencil plan, which use disjoint links, may be in flight at the same time.  It is an
+    // argument, not communicator state: several host threads (virtual ranks) share one communicator.
     // true if exchanges issued on channel 0 and channel 1 may run concurrently on two streams
     virtual bool concurrent_channels() const { return true; }
     virtual int alltoallv(int myrank, const void *send, const size_t *scount, const size_t *sdispl,
                           void *recv, const size_t *rcount, const size_t *rdispl, const int *group,
-                          int ngroup, int me, hipStream_t stream) = 0;
+                          int ngroup, int me, hipStream_t stream, int channel) = 0;
+    // number of ranks the transport itself reports (ncclCommCount for RCCL); 0 if it has no such notion
+    virtual int transport_nranks() const { return 0; }
     // host-side rendezvous of all ranks (used around timing); no-op by default
     virtual void barrier(int /*myrank*/) {}
 };

@@ -723,13 +723,13 @@ static int exchange_tables(dfft_plan *p, int which, const A2A &T, bool forward, 
     const std::vector<int> &grp = first ? p->group1 : p->group2;
     const int me = first ? p->pj : p->pi;
     if (!p->comm) return fail(ERR_STATE, "exchange without a communicator");
-    p->comm->channel = (which == 2 && p->pl.comm_stream2 && stream == p->pl.comm_stream2) ? 1 : 0;
+    const int channel = (which == 2 && p->pl.comm_stream2 && stream == p->pl.comm_stream2) ? 1 : 0;
     // the inverse all-to-all swaps the send and receive tables (mpicufft_pencil_opt1.cpp:829-830)
     if (forward)
         return p->comm->alltoallv(p->rank, send, T.sc.data(), T.sd.data(), recv, T.rc.data(), T.rd.data(), grp.data(),
-                                  (int)grp.size(), me, stream);
+                                  (int)grp.size(), me, stream, channel);
     return p->comm->alltoallv(p->rank, send, T.rc.data(), T.rd.data(), recv, T.sc.data(), T.sd.data(), grp.data(),
-                              (int)grp.size(), me, stream);
+                              (int)grp.size(), me, stream, channel);
 }
 
 static int exchange(dfft_plan *p, int which, bool forward, const void *send, void *recv)
@@ -1134,6 +1134,13 @@ int dfft_comm_create_callback(int nranks, int rank, dfft_alltoallv_fn fn, void *
 {
     if (!fn || !comm || rank < 0 || rank >= nranks) return fail(ERR_ARG, "bad arguments");
     *comm = make_callback_comm(nranks, rank, (void *)fn, user);
+    return 0;
+}
+int dfft_comm_info(const dfft_comm *comm, int *nranks, int *transport_nranks)
+{
+    if (!comm) return fail(ERR_ARG, "null communicator");
+    if (nranks) *nranks = comm->nranks;
+    if (transport_nranks) *transport_nranks = comm->transport_nranks();
     return 0;
 }
 int dfft_comm_destroy(dfft_comm *comm)

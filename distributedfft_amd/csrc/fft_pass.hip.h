@@ -683,28 +683,40 @@ template <int TL> struct TransposeOne {
     }
 };
 
-// forward z pass of an R2C plan: real lines [a][LB][2M] -> tiled send buffer with M+1 points
+// tile of the calling lane for the real-transform kernels; lw = the lane's line within the workgroup in
+// the coordinate set in use (first pass or later passes: they differ for the point-fastest mappings)
+template <typename Cfg> __device__ __forceinline__ bool real_tile(const PassArgs &A, int lw, TileCtx<Cfg::kTL> &tc)
+{
+    constexpr int TL = Cfg::kTL;
+    static_assert(Cfg::kSUB == 1, "sub-tile workgroups: fft_pass_kernel only");
+    const uint32_t w = logical_block<>(A) * Cfg::kG + lw / TL;
+    const bool tile_ok = w < A.ntiles;
+    tc.a = !tile_ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
+    tc.b = !tile_ok ? 0 : (A.a_fastest ? w / A.na : w % A.nb);
+    tc.l = lw % TL;
+    const uint32_t rem = A.LB - tc.b * TL;
+    tc.tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;
+    return tile_ok && (uint32_t)tc.l < tc.tw;
+}
+
+// forward z pass of an R2C plan: real lines [a][LB][2M] -> tiled send buffer with M+1 points.
+// Cfg::kMAP as in fft_pass_kernel: the natural-line load of a fp32 plan wants the point-fastest mapping.
 template <typename Cfg, int ONEPLANE = 0>
 __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
 {
     using C = typename Cfg::C;
     using R = typename Cfg::real;
-    constexpr int M = Cfg::kN, E = Cfg::kE, TL = Cfg::kTL, NT = Cfg::NT, TW = Cfg::TW;
+    constexpr int M = Cfg::kN, E = Cfg::kE, TL = Cfg::kTL, NT = Cfg::NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     R *lds = reinterpret_cast<R *>(smem);
     const int tid = threadIdx.x;
-    const int lw = tid % TW, t = tid / TW;
-    const int g = lw / TL, l = lw % TL;
-    static_assert(Cfg::kSUB == 1, "sub-tile workgroups: fft_pass_kernel only");
-    const uint32_t w = logical_block<>(A) * Cfg::kG + g;
-    const bool tile_ok = w < A.ntiles;
-    TileCtx<TL> tc;
-    tc.a = !tile_ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
-    tc.b = !tile_ok ? 0 : (A.a_fastest ? w / A.na : w % A.nb);
-    tc.l = l;
-    const uint32_t rem = A.LB - tc.b * TL;
-    tc.tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;
-    const bool active = tile_ok && (uint32_t)l < tc.tw;
+    constexpr bool PF_FIRST = Cfg::kMAP == 1, PF_REST = Cfg::kMAP != 0;
+    int lw, t, lw2, t2;
+    thread_map<Cfg, PF_FIRST>(tid, lw, t);      // coordinates of the load and the first pass
+    thread_map<Cfg, PF_REST>(tid, lw2, t2);     // ... of the later passes, the split step and the store
+    TileCtx<TL> tc, tc2;
+    const bool active = real_tile<Cfg>(A, lw, tc);
+    const bool active2 = real_tile<Cfg>(A, lw2, tc2);
     const C *__restrict__ in = reinterpret_cast<const C *>(A.in);
     C *__restrict__ out = reinterpret_cast<C *>(A.out);
     const C *__restrict__ W = reinterpret_cast<const C *>(A.tw);
@@ -712,7 +724,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
 
     C v[E];
     if (active) {
-        const C *p = in + ((uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + l) * M + t;
+        const C *p = in + ((uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + tc.l) * M + t;
         static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = p[NT * c]; });
     } else {
         static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].x = 0; v[c].y = 0; });
@@ -727,7 +739,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
         });
         return;
     }
-    transform<Cfg>(v, lds, W, t, lw, tid);
+    transform<Cfg>(v, lds, W, t, lw, t2, lw2);
 
     // split step through LDS: scatter Z by natural index, gather the (k, M-k) pairs
     constexpr int RL = Cfg::RLAST, S = E / RL;
@@ -738,7 +750,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (M / RL);
-            const int idx = lds_pad<Cfg>((t + k0) * TW + lw);
+            const int idx = lds_slot<Cfg>(lw2, t2 + k0);
             p0[idx] = v[c].x;
             p1[idx] = v[c].y;
         });
@@ -747,31 +759,31 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (M / RL);
-            lds[lds_pad<Cfg>((t + k0) * TW + lw)] = v[c].x;
+            lds[lds_slot<Cfg>(lw2, t2 + k0)] = v[c].x;
         });
         __syncthreads();
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
-            const int k = t + NT * c, km = (M - k) & (M - 1);
-            zr_[c] = lds[lds_pad<Cfg>(k * TW + lw)];
-            mr_[c] = lds[lds_pad<Cfg>(km * TW + lw)];
+            const int k = t2 + NT * c, km = (M - k) & (M - 1);
+            zr_[c] = lds[lds_slot<Cfg>(lw2, k)];
+            mr_[c] = lds[lds_slot<Cfg>(lw2, km)];
         });
         __syncthreads();
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (M / RL);
-            lds[lds_pad<Cfg>((t + k0) * TW + lw)] = v[c].y;
+            lds[lds_slot<Cfg>(lw2, t2 + k0)] = v[c].y;
         });
         __syncthreads();
     }
-    if (!active) return;
+    if (!active2) return;
     // the address form is chosen once per thread, not once per point
     auto emit = [&](auto offset_of) {
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
-            const int k = t + NT * c;
+            const int k = t2 + NT * c;
             const int km = (M - k) & (M - 1);
-            const int i0 = lds_pad<Cfg>(k * TW + lw), i1 = lds_pad<Cfg>(km * TW + lw);
+            const int i0 = lds_slot<Cfg>(lw2, k), i1 = lds_slot<Cfg>(lw2, km);
             const R zr = ONEPLANE ? zr_[ONEPLANE ? c : 0] : p0[i0], mr = ONEPLANE ? mr_[ONEPLANE ? c : 0] : p0[i1];
             const R zi = p1[i0], mi = p1[i1];
             const C wv = W2[k];
@@ -780,7 +792,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
             x.x = (R)0.5 * (Ar + wv.x * Bi + wv.y * Br);
             x.y = (R)0.5 * (Ai - wv.x * Br + wv.y * Bi);
             out[offset_of((uint32_t)k)] = x;
-            if (c == 0 && t == 0) {          // k = M: X[M] = Re Z[0] - Im Z[0]
+            if (c == 0 && t2 == 0) {          // k = M: X[M] = Re Z[0] - Im Z[0]
                 C xm; xm.x = zr - zi; xm.y = 0;
                 out[offset_of((uint32_t)M)] = xm;
             }
@@ -788,38 +800,34 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
     };
     if (A.store_kind == STORE_LINES) {
         // natural [line][M+1] rows (partial transform, d = 1)
-        const uint64_t row = ((uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + tc.l) * (uint64_t)(M + 1);
+        const uint64_t row = ((uint64_t)tc2.a * A.LB + (uint64_t)tc2.b * TL + tc2.l) * (uint64_t)(M + 1);
         emit([&](uint32_t k) { return row + k; });
     } else if (A.stab || A.snseg != 1) {
-        emit([&](uint32_t k) { return tiled_transpose_store_offset<TL>(A, tc, k); });
+        emit([&](uint32_t k) { return tiled_transpose_store_offset<TL>(A, tc2, k); });
     } else {
-        const TransposeOne<TL> one(A, tc);      // the tiled send buffer of a single peer
+        const TransposeOne<TL> one(A, tc2);      // the tiled send buffer of a single peer
         emit([&](uint32_t k) { return one(k); });
     }
 }
 
-// inverse z pass of an R2C plan: tiled recv buffer with M+1 points -> real lines [a][LB][2M]
+// inverse z pass of an R2C plan: tiled recv buffer with M+1 points -> real lines [a][LB][2M].
+// Cfg::kMAP == 2 (line-fastest tiled load, point-fastest natural-line store) is the fp32 form.
 template <typename Cfg>
 __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
 {
     using C = typename Cfg::C;
     using R = typename Cfg::real;
-    constexpr int M = Cfg::kN, E = Cfg::kE, TL = Cfg::kTL, NT = Cfg::NT, TW = Cfg::TW;
+    constexpr int M = Cfg::kN, E = Cfg::kE, TL = Cfg::kTL, NT = Cfg::NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     R *lds = reinterpret_cast<R *>(smem);
     const int tid = threadIdx.x;
-    const int lw = tid % TW, t = tid / TW;
-    const int g = lw / TL, l = lw % TL;
-    static_assert(Cfg::kSUB == 1, "sub-tile workgroups: fft_pass_kernel only");
-    const uint32_t w = logical_block<>(A) * Cfg::kG + g;
-    const bool tile_ok = w < A.ntiles;
-    TileCtx<TL> tc;
-    tc.a = !tile_ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
-    tc.b = !tile_ok ? 0 : (A.a_fastest ? w / A.na : w % A.nb);
-    tc.l = l;
-    const uint32_t rem = A.LB - tc.b * TL;
-    tc.tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;
-    const bool active = tile_ok && (uint32_t)l < tc.tw;
+    constexpr bool PF_FIRST = Cfg::kMAP == 1, PF_REST = Cfg::kMAP != 0 && Cfg::NPASS > 1 ? true : Cfg::kMAP == 1;
+    int lw, t, lw2, t2;
+    thread_map<Cfg, PF_FIRST>(tid, lw, t);
+    thread_map<Cfg, PF_REST>(tid, lw2, t2);
+    TileCtx<TL> tc, tc2;
+    const bool active = real_tile<Cfg>(A, lw, tc);
+    const bool active2 = real_tile<Cfg>(A, lw2, tc2);
     const C *__restrict__ in = reinterpret_cast<const C *>(A.in);
     C *__restrict__ out = reinterpret_cast<C *>(A.out);
     const C *__restrict__ W = reinterpret_cast<const C *>(A.tw);
@@ -856,10 +864,10 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
     } else {
         static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].x = 0; v[c].y = 0; });
     }
-    if (!(A.debug & 1)) transform<Cfg>(v, lds, W, t, lw, tid);
-    if (!active) return;
+    if (!(A.debug & 1)) transform<Cfg>(v, lds, W, t, lw, t2, lw2);
+    if (!active2) return;
     constexpr int RL = Cfg::RLAST, S = E / RL;
-    C *p = out + ((uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + l) * M + t;
+    C *p = out + ((uint64_t)tc2.a * A.LB + (uint64_t)tc2.b * TL + tc2.l) * M + t2;
     static_for<0, E>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
         constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (M / RL);

@@ -91,17 +91,24 @@ DFFT_SLICE_FUNCS(f32, 2, DFFT_F32_LIST_2048)
     X(128, 0, F32_128) X(256, 0, F32_256) X(512, 0, F32_512) X(1024, 0, F32_1024)
 #if DFFT_SLICE == 3
 // 512 and 1024 (Nz = 1024, 2048): two radix passes (one exchange) + one-plane split, measured +14 % / +5-10 %
-// over the three-pass configurations
+// over the three-pass configurations; point-fastest lane mappings on the natural-line side (PassCfg::MAP = 1 for
+// the R2C load, 2 for the C2R store): a line-fastest wave touches a real line in 32-byte pieces
 using F32_R512_32 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1>;
+using F32_R512_pf1 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1, 0, 1>;
+using F32_R512_pf2 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1, 0, 2>;
+using F32_R1024_pf1 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 1>;
+using F32_R1024_pf2 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 2>;
 #ifdef DFFT_EXPERIMENTS
 // A/B variants of the real z passes (option real_variant): 1 = three-pass configuration, two-plane split (the
-// round-1 baseline); 2 = three-pass configuration, one-plane split
+// round-1 baseline); 2 = three-pass configuration, one-plane split; 3 = two-pass line-fastest (round-1 final)
 static int launch_real_variant_f32(int M, int mode, int variant, const PassArgs &A, hipStream_t stream)
 {
     if (M == 512 && variant == 1) return mode == 1 ? launch_real_cfg<F32_512, 1>(A, stream) : launch_real_cfg<F32_512, 2>(A, stream);
     if (M == 512 && variant == 2) return mode == 1 ? launch_real_cfg<F32_512, 1, 1>(A, stream) : launch_real_cfg<F32_512, 2>(A, stream);
+    if (M == 512 && variant == 3) return mode == 1 ? launch_real_cfg<F32_R512_32, 1, 1>(A, stream) : launch_real_cfg<F32_R512_32, 2>(A, stream);
     if (M == 1024 && variant == 1) return mode == 1 ? launch_real_cfg<F32_1024, 1>(A, stream) : launch_real_cfg<F32_1024, 2>(A, stream);
     if (M == 1024 && variant == 2) return mode == 1 ? launch_real_cfg<F32_1024, 1, 1>(A, stream) : launch_real_cfg<F32_1024, 2>(A, stream);
+    if (M == 1024 && variant == 3) return mode == 1 ? launch_real_cfg<F32_1024_v6, 1, 1>(A, stream) : launch_real_cfg<F32_1024_v6, 2>(A, stream);
     return -2;
 }
 #endif
@@ -114,8 +121,8 @@ int launch_real_f32(int M, int mode, int variant, const PassArgs &A, hipStream_t
     }
 #endif
     (void)variant;
-    if (M == 512) return mode == 1 ? launch_real_cfg<F32_R512_32, 1, 1>(A, stream) : launch_real_cfg<F32_R512_32, 2>(A, stream);
-    if (M == 1024) return mode == 1 ? launch_real_cfg<F32_1024_v6, 1, 1>(A, stream) : launch_real_cfg<F32_1024_v6, 2>(A, stream);
+    if (M == 512) return mode == 1 ? launch_real_cfg<F32_R512_pf1, 1, 1>(A, stream) : launch_real_cfg<F32_R512_pf2, 2>(A, stream);
+    if (M == 1024) return mode == 1 ? launch_real_cfg<F32_R1024_pf1, 1, 1>(A, stream) : launch_real_cfg<F32_R1024_pf2, 2>(A, stream);
     switch (M) {
 #define X(n, v, cfg) case n: return mode == 1 ? launch_real_cfg<cfg, 1>(A, stream) : launch_real_cfg<cfg, 2>(A, stream);
         DFFT_F32_BASE(X)
@@ -124,7 +131,6 @@ int launch_real_f32(int M, int mode, int variant, const PassArgs &A, hipStream_t
     return -1;
 }
 
-#else
 // Bluestein passes for arbitrary line lengths: M = power of two >= 2*NL - 1
 int launch_bluestein_f32(int M, const PassArgs &A, hipStream_t stream)
 {

@@ -88,6 +88,10 @@ int dfft_rccl_unique_id(void *id128);
 int dfft_comm_create_rccl(const void *id128, int nranks, int rank, dfft_comm **comm);
 /* caller-supplied exchange (e.g. torch.distributed.all_to_all_single, MPI_Alltoallv) */
 int dfft_comm_create_callback(int nranks, int rank, dfft_alltoallv_fn fn, void *user, dfft_comm **comm);
+/* nranks = the size the communicator was created with; transport_nranks = what the transport itself reports
+ * (ncclCommCount for the RCCL transport, 0 for the others), so that a caller can verify that RCCL really
+ * spans the ranks it claims */
+int dfft_comm_info(const dfft_comm *comm, int *nranks, int *transport_nranks);
 /* destroy the plans that use a communicator before the communicator itself */
 int dfft_comm_destroy(dfft_comm *comm);
 

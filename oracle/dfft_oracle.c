@@ -164,16 +164,37 @@ void orc_fft1d_many(cplx *x, size_t n, size_t stride, size_t dist, size_t howman
  * ---------------------------------------------------------------------------------------- */
 
 /* lines of length n, element stride `stride`; line (i, j) starts at x + i*dist1 + j*dist2.
- * One parallel region and one twiddle table per thread for the whole batch. */
+ * One parallel region and one twiddle table per thread for the whole batch.  Strided power-of-two
+ * lines whose neighbours (j, j+1) are adjacent in memory are gathered four at a time, so that every
+ * 64-byte cache line fetched is used in full (the arithmetic per line is unchanged: same fft_pow2). */
+#define ORC_BLK 4
 static void fft_lines_2d(cplx *x, size_t n, size_t stride, size_t n1, size_t dist1, size_t n2, size_t dist2, int sign)
 {
+    const int blocked = stride > 1 && dist2 == 1 && is_pow2(n) && n > 1;
 #pragma omp parallel
     {
         line_plan lp; line_plan_init(&lp, n, sign);
+        if (!blocked) {
 #pragma omp for schedule(static) collapse(2)
-        for (long long i = 0; i < (long long)n1; i++)
-            for (long long j = 0; j < (long long)n2; j++)
-                line_exec(&lp, x + (size_t)i * dist1 + (size_t)j * dist2, stride);
+            for (long long i = 0; i < (long long)n1; i++)
+                for (long long j = 0; j < (long long)n2; j++)
+                    line_exec(&lp, x + (size_t)i * dist1 + (size_t)j * dist2, stride);
+        } else {
+            cplx *blk = (cplx *)malloc(sizeof(cplx) * n * ORC_BLK);
+            const long long nblk = (long long)((n2 + ORC_BLK - 1) / ORC_BLK);
+#pragma omp for schedule(static) collapse(2)
+            for (long long i = 0; i < (long long)n1; i++)
+                for (long long jb = 0; jb < nblk; jb++) {
+                    cplx *base = x + (size_t)i * dist1 + (size_t)jb * ORC_BLK;
+                    const size_t w = (size_t)jb * ORC_BLK + ORC_BLK <= n2 ? ORC_BLK : n2 - (size_t)jb * ORC_BLK;
+                    for (size_t k = 0; k < n; k++)
+                        for (size_t b = 0; b < w; b++) blk[b * n + k] = base[k * stride + b];
+                    for (size_t b = 0; b < w; b++) fft_pow2(blk + b * n, n, lp.w);
+                    for (size_t k = 0; k < n; k++)
+                        for (size_t b = 0; b < w; b++) base[k * stride + b] = blk[b * n + k];
+                }
+            free(blk);
+        }
         line_plan_free(&lp);
     }
 }
@@ -531,9 +552,10 @@ double orc_uniform255(uint64_t global_index, uint64_t seed)
 void orc_fill_block(double *dst, size_t Ny, size_t Nz, size_t x0, size_t y0, size_t z0,
                     size_t sx, size_t sy, size_t sz, int ncomp, uint64_t seed)
 {
-    for (size_t x = 0; x < sx; x++) for (size_t y = 0; y < sy; y++) for (size_t z = 0; z < sz; z++) {
-        uint64_t g = ((uint64_t)(x0 + x) * Ny + (y0 + y)) * Nz + (z0 + z);
-        double *d = dst + ((x * sy + y) * sz + z) * ncomp;
+#pragma omp parallel for schedule(static) collapse(2)
+    for (long long x = 0; x < (long long)sx; x++) for (long long y = 0; y < (long long)sy; y++) for (size_t z = 0; z < sz; z++) {
+        uint64_t g = ((uint64_t)(x0 + (size_t)x) * Ny + (y0 + (size_t)y)) * Nz + (z0 + z);
+        double *d = dst + (((size_t)x * sy + (size_t)y) * sz + z) * ncomp;
         for (int c = 0; c < ncomp; c++) d[c] = orc_uniform255(g * 2 + c, seed);
     }
 }

@@ -328,3 +328,18 @@ def test_transport_probe_failure_paths_without_a_gpu():
     import torch
     if not torch.cuda.is_available():
         assert tt._probe_native(1, 1, timeout=120) is False
+
+
+def test_bench_dry_run_plans_c4_and_c5_for_all_ranks():
+    """bench.py --dry-run builds BASELINE's multi-GPU plans for all 8 ranks on a host without a GPU: C4 = 2 GiB
+    domain, C5 = 8 GiB domain with a 3-slice work area, both far below the 288 GB of one MI355X"""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])["dry_run"]
+    assert d["C4"]["domain_GiB"] == 2.0 and d["C4"]["work_GiB"] == 6.0 and d["C4"]["fits_288_GB"]
+    assert d["C5"]["domain_GiB"] == 8.0 and d["C5"]["work_GiB"] == 24.0 and d["C5"]["fits_288_GB"]
+    assert d["C5"]["per_gpu_total_GiB (in + out + back + work)"] == 48.0
+    assert d["C3"]["partition"] == "2x1" and d["C4-slab"]["work_GiB"] == 4.0

@@ -131,3 +131,15 @@ def test_golden_fixtures():
         shape = tuple(int(v) for v in key.split("_")[1].split("x"))
         g = orc.fill_block(shape, (0, 0, 0), shape, 1, seed=int(d["seed"]))
         assert rel_linf(orc.fft3d_r2c(g), d[key]) < 1e-13
+
+
+def test_c1_128_cube_round_trip():
+    """BASELINE config 1: 128^3 fp64 complex forward + inverse on the CPU path, one rank; gate <= 1e-12
+    relative L-infinity, forward checked against numpy/pocketfft as well"""
+    n = 128
+    g = orc.fill_block((n, n, n), (0, 0, 0), (n, n, n), 2, seed=20260921)
+    X = orc.fft3d_c2c(g, -1)
+    want = np.fft.fftn(g)
+    assert np.max(np.abs(X - want)) / np.max(np.abs(want)) < 1e-12
+    back = orc.fft3d_c2c(X, +1) / float(n) ** 3
+    assert np.max(np.abs(back - g)) / np.max(np.abs(g)) < 1e-12

@@ -101,7 +101,40 @@ struct Args {
     int slab = 0;
     size_t delta = 0;
     std::string perm = "wiob";
+    // --vmm MiB: every buffer comes from the virtual-memory API in physical chunks of that size (0 = off);
+    // --shuffle: the chunks are mapped in a pseudo-random order
+    size_t vmm_mib = 0;
+    int shuffle = 0;
 };
+
+static char *vmm_alloc(size_t bytes, size_t chunk, bool shuffle)
+{
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    bytes = (bytes + chunk - 1) / chunk * chunk;
+    void *va = nullptr;
+    HIPCHK(hipMemAddressReserve(&va, bytes, chunk, nullptr, 0));
+    const size_t n = bytes / chunk;
+    std::vector<hipMemGenericAllocationHandle_t> h(n);
+    for (size_t i = 0; i < n; i++) HIPCHK(hipMemCreate(&h[i], chunk, &prop, 0));
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; i++) order[i] = i;
+    if (shuffle) {
+        uint64_t s = 0x9E3779B97F4A7C15ull;
+        for (size_t i = n - 1; i > 0; i--) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; std::swap(order[i], order[s % (i + 1)]); }
+    }
+    for (size_t i = 0; i < n; i++) {
+        HIPCHK(hipMemMap((char *)va + i * chunk, chunk, 0, h[order[i]], 0));
+        HIPCHK(hipMemRelease(h[order[i]]));
+    }
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    HIPCHK(hipMemSetAccess(va, bytes, &acc, 1));
+    return (char *)va;
+}
 
 static Args parse(int argc, char **argv)
 {
@@ -126,6 +159,8 @@ static Args parse(int argc, char **argv)
         else if (k == "--slab") a.slab = 1;
         else if (k == "--delta") { a.slab = 1; a.delta = (size_t)atoll(next()); }
         else if (k == "--perm") { a.slab = 1; a.perm = next(); }
+        else if (k == "--vmm") a.vmm_mib = (size_t)atoll(next());
+        else if (k == "--shuffle") a.shuffle = 1;
         else if (k == "--opt") {
             std::string kv = next();
             const size_t eq = kv.find('=');
@@ -181,7 +216,7 @@ template <typename R> static int run_plan(const Args &a)
     dfft_plan *plan;
     DCHK(dfft_plan_create(&plan, DFFT_PENCIL_OPT1, prec, nullptr, nullptr, 0, -1));
     for (auto &kv : a.opts) DCHK(dfft_set_option(plan, kv.first.c_str(), kv.second));
-    DCHK(dfft_init(plan, a.Nx, a.Ny, a.Nz, 1, 1, c2c ? 1 : 0, a.slab ? 0 : 1));
+    DCHK(dfft_init(plan, a.Nx, a.Ny, a.Nz, 1, 1, c2c ? 1 : 0, (a.slab || a.vmm_mib) ? 0 : 1));
     const size_t n = a.Nx * a.Ny * a.Nz;
     const size_t in_bytes = c2c ? n * esz : n * sizeof(R);
     const size_t dom = dfft_domain_size(plan);
@@ -195,6 +230,13 @@ template <typename R> static int run_plan(const Args &a)
         in = pos['i']; out = pos['o']; back = pos['b'];
         if (!in || !out || !back || !pos['w']) { fprintf(stderr, "--perm needs the letters i o w b\n"); exit(1); }
         DCHK(dfft_set_work_area(plan, pos['w'], nullptr));
+    } else if (a.vmm_mib) {
+        const size_t chunk = a.vmm_mib << 20;
+        char *w = vmm_alloc(dfft_work_size_device(plan), chunk, a.shuffle);
+        DCHK(dfft_set_work_area(plan, w, nullptr));
+        in = vmm_alloc(in_bytes, chunk, a.shuffle);
+        out = vmm_alloc(dom, chunk, a.shuffle);
+        back = vmm_alloc(in_bytes, chunk, a.shuffle);
     } else {
         HIPCHK(hipMalloc(&in, in_bytes));
         HIPCHK(hipMalloc(&out, dom));
@@ -251,6 +293,7 @@ template <typename R> static int run_plan(const Args &a)
     }
     std::string optstr;
     for (auto &kv : a.opts) optstr += " " + kv.first + "=" + std::to_string(kv.second);
+    if (a.vmm_mib) optstr += " vmm=" + std::to_string(a.vmm_mib) + "MiB" + (a.shuffle ? " shuffled" : "");
     if (a.slab) optstr += " slab perm=" + a.perm + " delta=" + std::to_string(a.delta);
     printf("PLAN %s %zux%zux%zu %s %s%s | wave_err %.2e roundtrip %.2e | wall %.3f ms/step\n", a.label.c_str(), a.Nx, a.Ny, a.Nz,
            a.prec.c_str(), a.mode.c_str(), optstr.c_str(), wave_err, rt_err, wall / a.iters);
@@ -272,6 +315,7 @@ template <typename R> static int run_plan(const Args &a)
     printf("  total passes %.3f ms\n", tot);
     DCHK(dfft_plan_destroy(plan));
     if (a.slab) HIPCHK(hipFree(slab));
+    else if (a.vmm_mib) { /* process exit unmaps */ }
     else {
         HIPCHK(hipFree(in)); HIPCHK(hipFree(out));
         if (!alias_back) HIPCHK(hipFree(back));
