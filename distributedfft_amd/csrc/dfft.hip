@@ -1309,26 +1309,25 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         p->pl.C = C;
     }
     TRY(zyx ? build_pipeline_zyx(p, p->pl) : yzx ? build_pipeline_yzx(p, p->pl) : build_pipeline(p, p->pl));
-    // the inverse x pass reads the point-major API layout: use the strided-read configuration
-    // (variant 1) where one exists for this length
+    // kernel configuration per pass, by role (PassRole); lengths without a configuration for a role use the default
     {
         PassInfo vi;
-        const bool has = p->prec == DFFT_F64 && !p->ax[2].bluestein ? pass_info_f64((int)Nx, 1, &vi) : false;
-        p->vinv[2] = has ? 1 : 0;
-        // passes that store long runs (tiled-transpose chunks, natural lines): nontemporal variant 3
-        auto nt = [&](const Axis &a) { return p->prec == DFFT_F64 && !a.bluestein && pass_info_f64((int)a.N, 3, &vi) ? 3 : 0; };
-        if (p->c2c) { p->vfwd[0] = nt(p->ax[0]); p->vinv[0] = nt(p->ax[0]); }
-        p->vinv[1] = nt(p->ax[1]);
-        // fp32: point-fastest lane mappings for the natural-line passes (variants 4 / 5, PassCfg::MAP)
-        if (p->prec == DFFT_F32 && p->c2c && !p->ax[0].bluestein) {
-            if (pass_info_f32((int)p->ax[0].N, 4, &vi)) p->vfwd[0] = 4;
-            if (pass_info_f32((int)p->ax[0].N, 5, &vi)) p->vinv[0] = 5;
-        }
-        // fp32 tiled passes (y, x): two radix passes with one LDS exchange where such a configuration
-        // exists (variant 6; 1024: y 4.84 -> 3.50 ms, x 4.10 -> 3.37 ms)
-        if (p->prec == DFFT_F32) {
+        auto has64 = [&](const Axis &a, int role) { return !a.bluestein && pass_info_f64((int)a.N, role, &vi); };
+        auto has32 = [&](const Axis &a, int role) { return !a.bluestein && pass_info_f32((int)a.N, role, &vi); };
+        for (int k = 0; k < 3; k++) p->vfwd[k] = p->vinv[k] = ROLE_DEFAULT;
+        if (p->prec == DFFT_F64) {
+            // the multi-rank inverse x pass reads the point-major API layout
+            if (has64(p->ax[2], ROLE_STRIDED_READ)) p->vinv[2] = ROLE_STRIDED_READ;
+            // complex z passes have natural lines on one side and long-run stores
+            const int zrole = has64(p->ax[0], ROLE_LINES) ? ROLE_LINES : has64(p->ax[0], ROLE_STREAM) ? ROLE_STREAM : ROLE_DEFAULT;
+            if (p->c2c) p->vfwd[0] = p->vinv[0] = zrole;
+            // the inverse y pass stores tiled-transpose chunks (1 KiB runs)
+            if (has64(p->ax[1], ROLE_STREAM)) p->vinv[1] = ROLE_STREAM;
+        } else {
+            if (p->c2c && has32(p->ax[0], ROLE_NATURAL_LOAD)) p->vfwd[0] = ROLE_NATURAL_LOAD;
+            if (p->c2c && has32(p->ax[0], ROLE_NATURAL_STORE)) p->vinv[0] = ROLE_NATURAL_STORE;
             for (int ax = 1; ax <= 2; ax++)
-                if (!p->ax[ax].bluestein && pass_info_f32((int)p->ax[ax].N, 6, &vi)) { p->vfwd[ax] = 6; p->vinv[ax] = 6; }
+                if (has32(p->ax[ax], ROLE_TILED)) p->vfwd[ax] = p->vinv[ax] = ROLE_TILED;
         }
     }
     {   // per-pass overrides (dfft_set_option): fz fy fx ix iy iz
@@ -1721,6 +1720,15 @@ int dfft_fft1d_batched_ex(int precision, size_t N, size_t batch, void *out, cons
         if (int r = axis_upload(precision, ax)) { axis_free(ax); ax = Axis(); return r; }
         axP = precision;
     }
+#ifdef DFFT_EXPERIMENTS
+    if ((variant == 15 || variant == 14) && precision == DFFT_F32 && !ax.bluestein) {      // A/B: the LDS-free shuffle pass (15 bpermute, 14 DPP)
+        PassArgs S;
+        memset(&S, 0, sizeof(S));
+        S.in = in; S.out = out; S.tw = ax.tw; S.na = 1; S.LB = (uint32_t)batch; S.swap = direction == DFFT_INVERSE;
+        const int r = launch_shfl_f32((int)N, variant == 14, S, (hipStream_t)hip_stream);
+        return r == 0 ? 0 : fail(r == -1 ? ERR_UNSUPPORTED : r, "shuffle pass launch failed");
+    }
+#endif
     PassInfo pi;
     const bool has = !ax.bluestein && variant ? (precision == DFFT_F64 ? pass_info_f64((int)ax.M, variant, &pi) : pass_info_f32((int)ax.M, variant, &pi)) : false;
     if (!has) {

@@ -11,6 +11,18 @@ struct PassArgs;
 
 struct PassInfo { int N, E, TL, G, threads, lds_bytes, npass, sub; };
 
+// The variant number of a kernel configuration is its role in a plan; a length that has no configuration for a
+// role falls back to ROLE_DEFAULT (launch_pass).  See the comments in kernels_f64.hip / kernels_f32.hip.
+enum PassRole {
+    ROLE_DEFAULT = 0,
+    ROLE_STRIDED_READ = 1,     // fp64: loads the point-major API layout (multi-rank inverse x pass)
+    ROLE_STREAM = 3,           // fp64: stores in long runs (tiled-transpose chunks, natural lines): nontemporal
+    ROLE_NATURAL_LOAD = 4,     // fp32: natural lines in (point-fastest mapping in every pass)
+    ROLE_NATURAL_STORE = 5,    // fp32: natural lines out (point-fastest mapping after the first pass)
+    ROLE_TILED = 6,            // fp32: tiled on both sides (two radix passes, one exchange)
+    ROLE_LINES = 7             // fp64: natural lines on one side where that differs from ROLE_STREAM (2048: sub-tiles)
+};
+
 // tile size (lines interleaved in the intermediate layouts) per precision: 128 B per run
 constexpr int TL_F64 = 8;
 constexpr int TL_F32 = 16;
@@ -26,6 +38,9 @@ int launch_real_f32(int M, int mode, int variant, const PassArgs &A, hipStream_t
 int launch_bluestein_f64(int M, const PassArgs &A, hipStream_t stream);
 int launch_bluestein_f32(int M, const PassArgs &A, hipStream_t stream);
 bool pass_info_f32(int N, int variant, PassInfo *pi);
+#ifdef DFFT_EXPERIMENTS
+int launch_shfl_f32(int N, int dpp, const PassArgs &A, hipStream_t stream);      // LDS-free shuffle pass (A/B only)
+#endif
 
 void set_error(const std::string &msg);
 

@@ -877,6 +877,84 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
 }
 
 
+#ifdef DFFT_EXPERIMENTS
+// ------------------------------------------------------------------------------------------
+// A/B only (north_star: "wavefront shuffles for the twiddle/radix stages"): an LDS-free pass.  A line of
+// N = 16*E points lives in one 16-lane row (lane t holds x[t + 16 c], c < E): radix-E butterflies in registers,
+// twiddles, then a 16-point decimation-in-frequency transform ACROSS the 16 lanes with xor shuffles (distances
+// 8, 4, 2, 1).  No LDS, no barriers, four lines per wave.  Its price is structural: lanes end up holding the HIGH
+// part of the output index (k = q + E*bitrev(t)), so one side of the pass is accessed with a stride of E points --
+// the register<->lane transposition that the LDS exchange of fft_pass_kernel gives for free.  Natural lines only.
+// Measured against the LDS configurations in profiles/r2_shuffle_stage.txt.
+// ------------------------------------------------------------------------------------------
+// xor shuffle inside a 16-lane row: DPP moves (quad_perm, row_mirror, row_half_mirror: gfx9 has no row_xmask) or
+// ds_bpermute through __shfl_xor
+template <int D, int DPP> __device__ __forceinline__ float row_xor(float x)
+{
+    if constexpr (!DPP) return __shfl_xor(x, D, 16);
+    else {
+        int v = __float_as_int(x);
+        if constexpr (D == 1) v = __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);                 // quad_perm [1,0,3,2]
+        if constexpr (D == 2) v = __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);                 // quad_perm [2,3,0,1]
+        if constexpr (D == 4) { v = __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true); v = __builtin_amdgcn_mov_dpp(v, 0x1B, 0xF, 0xF, true); }   // half mirror (^7), reverse quads (^3)
+        if constexpr (D == 8) { v = __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true); v = __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true); }  // mirror (^15), half mirror (^7)
+        return __int_as_float(v);
+    }
+}
+
+template <typename R, int N, int DPP> __global__ __launch_bounds__(256) void fft_shfl_kernel(const PassArgs A)
+{
+    using C = typename Vec2<R>::type;
+    constexpr int E = N / 16;
+    using Cfg = PassCfg<R, N, E, 16, 1, E, 1, 1, 1, 1>;        // only for pass_compute's register butterflies
+    const int tid = threadIdx.x, t = tid & 15;
+    const uint32_t line = blockIdx.x * 16 + (tid >> 4);
+    if (line >= A.LB * A.na) return;
+    const C *__restrict__ in = reinterpret_cast<const C *>(A.in) + (uint64_t)line * N;
+    C *__restrict__ out = reinterpret_cast<C *>(A.out) + (uint64_t)line * N;
+    const C *__restrict__ W = reinterpret_cast<const C *>(A.tw);
+    C v[E];
+    static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = in[t + 16 * c]; });
+    const R sgn = A.swap ? (R)-1 : (R)1;
+    static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].y *= sgn; });
+    Dif<E, 0, 1, C>::run(v);                    // slot m holds Y[t][q], q = brev(m, E)
+    static_for<1, E>([&](auto mc) {             // twiddle w_N^(t q)
+        constexpr int m = decltype(mc)::value;
+        constexpr int q = brev(m, E);
+        const C w = W[(t * q) & (N - 1)];
+        const C x = v[m];
+        v[m].x = x.x * w.x - x.y * w.y;
+        v[m].y = x.x * w.y + x.y * w.x;
+    });
+    static_for<0, 4>([&](auto sc) {             // 16-point DIF across the lanes of a row
+        constexpr int d = 8 >> decltype(sc)::value;
+        const bool upper = (t & d) != 0;
+        const R sg = upper ? (R)-1 : (R)1;
+        C tw; tw.x = 1; tw.y = 0;
+        if (d > 1 && upper) tw = W[(t & (d - 1)) * (N / (2 * d))];
+        static_for<0, E>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            C p;
+            p.x = row_xor<d, DPP>(v[m].x);
+            p.y = row_xor<d, DPP>(v[m].y);
+            C r;
+            r.x = p.x + sg * v[m].x;            // lower lane: v + partner, upper lane: partner - v
+            r.y = p.y + sg * v[m].y;
+            if (d > 1) { v[m].x = r.x * tw.x - r.y * tw.y; v[m].y = r.x * tw.y + r.y * tw.x; }
+            else v[m] = r;
+        });
+    });
+    const int k1 = ((t & 1) << 3) | ((t & 2) << 1) | ((t & 4) >> 1) | ((t & 8) >> 3);      // bit reversal of the lane
+    static_for<0, E>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int q = brev(m, E);
+        C r = v[m];
+        r.y *= sgn;
+        out[q + E * k1] = r;
+    });
+}
+#endif
+
 // ------------------------------------------------------------------------------------------
 // Arbitrary line lengths (the reference accepts any size through cuFFT): Bluestein's chirp-z
 // algorithm on top of the power-of-two Stockham chain, all inside one kernel and with the same

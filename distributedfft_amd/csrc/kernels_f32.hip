@@ -14,24 +14,23 @@ using F32_512  = PassCfg<float, 512, 16, 16, 1,  8, 8, 8, 1,   2>;
 // 32 points per thread: fp32 runs out of instruction issue, not bandwidth, at 16
 using F32_1024 = PassCfg<float, 1024, 32, 16, 1, 32, 8, 4, 1,  1, 1>;
 using F32_2048 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1,  1, 1>;
-// point-fastest lane mappings (see PassCfg::MAP): variant 4 = every pass (natural-line load + transposed-tile
-// store: forward z), variant 5 = from the first exchange on (tiled load + natural-line / transposed store)
+// The variant number of a configuration is its ROLE in a plan (dfft_init picks by role, see PassRole):
+//   4 = natural-line load: point-fastest lane mapping in every pass (PassCfg::MAP = 1; forward z pass)
+//   5 = natural-line store: line-fastest first pass (tiled load), point-fastest afterwards (MAP = 2; inverse z pass)
+//   6 = tiled passes (y, x): two radix passes with a single LDS exchange
 using F32_1024_v4 = PassCfg<float, 1024, 32, 16, 1, 32, 8, 4, 1, 1, 1, 0, 1>;
 using F32_1024_v5 = PassCfg<float, 1024, 32, 16, 1, 32, 8, 4, 1, 1, 1, 0, 2>;
-// two radix-32 passes (one LDS exchange instead of two): variant 6
 using F32_1024_v6 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1>;
 using F32_512_v6 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1>;
-using F32_512_v4 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1, 0, 1>;    // point-fastest forms, as for 1024
+using F32_512_v4 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1, 0, 1>;
 using F32_512_v5 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1, 0, 2>;
-// 2048: 16 lines x 2048 points are 256 KiB -- one workgroup per CU.  Variant 6 (as for 1024: the two-pass
-// configuration): 64 points per thread, radix 64.32 with a single LDS exchange on 512 threads; 4 / 5 its
-// point-fastest forms.  Variant 1: sub-tile workgroups of 8 lines (PassCfg::SUB = 2, 66 KiB LDS, two per
-// CU) with the three-pass chain, variant 3: sub-tiles with the two-pass chain (256 threads).
+// 2048: 16 lines x 2048 points are 256 KiB -- one workgroup per CU.  The natural-line passes (4, 5) run 64 points
+// per thread (radix 64.32, a single LDS exchange) on sub-tile workgroups of 8 lines (PassCfg::SUB = 2: 256 threads,
+// 66 KiB LDS, two per CU): 36.2 -> 30.4 ms per pass at 2048^3.  The tiled passes (6) keep whole tiles (a sub-tile's
+// 64-byte runs cost more than its occupancy gives) with the same two-pass chain on 512 threads.
+using F32_2048_v4 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3, 1, 2>;
+using F32_2048_v5 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 2, 2>;
 using F32_2048_v6 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1>;
-using F32_2048_v4 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 1>;
-using F32_2048_v5 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 2>;
-using F32_2048_v1 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 0, 2>;
-using F32_2048_v3 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 0, 2>;
 #ifdef DFFT_EXPERIMENTS
 // A/B-only configurations (tools/kbench --opt variant_*=N); not part of the shipped library
 using F32_1024_v1 = PassCfg<float, 1024, 16, 16, 1, 16, 16, 4, 1, 1>;   // round-1 baseline
@@ -45,19 +44,22 @@ using F32_1024_v10 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 3>;
 using F32_1024_v11 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 2>;
 using F32_1024_v12 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 1>;
 using F32_1024_v13 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 3, 1>;
-// 2048: nontemporal forms: 9 = variant 7 (natural lines), 10 = variant 6 (tiled), 11 = three-pass 1024 threads (tiled)
-using F32_2048_v9 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3, 1, 2>;
+// 2048: 1 = three-pass chain on sub-tiles, 2 = point-fastest three-pass on sub-tiles, 3 = two-pass on sub-tiles (line
+// fastest), 7 = variant 4 without nontemporal hints, 8 / 9 = whole-tile point-fastest forms, 10 / 11 nontemporal tiled
+using F32_2048_v1 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 0, 2>;
+using F32_2048_v2 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 1, 2>;
+using F32_2048_v3 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 0, 2>;
+using F32_2048_v7 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 1, 2>;
+using F32_2048_v8 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 1>;
+using F32_2048_v9 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 2>;
 using F32_2048_v10 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3>;
 using F32_2048_v11 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3>;
-// 2048: point-fastest forms of the two-pass sub-tile configuration
-using F32_2048_v7 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 1, 2>;
-using F32_2048_v8 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 2, 2>;
 #endif
 
 #ifdef DFFT_EXPERIMENTS
 #define DFFT_F32_EXP_SMALL(X) X(512, 1, F32_512_v1)
 #define DFFT_F32_EXP_1024(X) X(1024, 10, F32_1024_v10) X(1024, 11, F32_1024_v11) X(1024, 12, F32_1024_v12) X(1024, 13, F32_1024_v13) X(1024, 1, F32_1024_v1) X(1024, 7, F32_1024_v7) X(1024, 8, F32_1024_v8) X(1024, 9, F32_1024_v9)
-#define DFFT_F32_EXP_2048(X) X(2048, 9, F32_2048_v9) X(2048, 10, F32_2048_v10) X(2048, 11, F32_2048_v11) X(2048, 7, F32_2048_v7) X(2048, 8, F32_2048_v8)
+#define DFFT_F32_EXP_2048(X) X(2048, 1, F32_2048_v1) X(2048, 2, F32_2048_v2) X(2048, 3, F32_2048_v3) X(2048, 7, F32_2048_v7) X(2048, 8, F32_2048_v8) X(2048, 9, F32_2048_v9) X(2048, 10, F32_2048_v10) X(2048, 11, F32_2048_v11)
 #else
 #define DFFT_F32_EXP_SMALL(X)
 #define DFFT_F32_EXP_1024(X)
@@ -65,7 +67,7 @@ using F32_2048_v8 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 2, 2>
 #endif
 #define DFFT_F32_LIST_SMALL(X) X(512, 6, F32_512_v6) X(512, 4, F32_512_v4) X(512, 5, F32_512_v5) X(2, 0, F32_2) X(4, 0, F32_4) X(8, 0, F32_8) X(16, 0, F32_16) X(32, 0, F32_32) X(64, 0, F32_64) X(128, 0, F32_128) X(256, 0, F32_256) X(512, 0, F32_512) DFFT_F32_EXP_SMALL(X)
 #define DFFT_F32_LIST_1024(X) X(1024, 4, F32_1024_v4) X(1024, 5, F32_1024_v5) X(1024, 6, F32_1024_v6) X(1024, 0, F32_1024) DFFT_F32_EXP_1024(X)
-#define DFFT_F32_LIST_2048(X) X(2048, 1, F32_2048_v1) X(2048, 3, F32_2048_v3) X(2048, 4, F32_2048_v4) X(2048, 5, F32_2048_v5) X(2048, 6, F32_2048_v6) X(2048, 0, F32_2048) DFFT_F32_EXP_2048(X)
+#define DFFT_F32_LIST_2048(X) X(2048, 4, F32_2048_v4) X(2048, 5, F32_2048_v5) X(2048, 6, F32_2048_v6) X(2048, 0, F32_2048) DFFT_F32_EXP_2048(X)
 
 DFFT_SLICE_DECLS(f32)
 #if DFFT_SLICE == 0
@@ -81,6 +83,19 @@ bool pass_info_f32(int N, int variant, PassInfo *pi)
 }
 #elif DFFT_SLICE == 1
 DFFT_SLICE_FUNCS(f32, 1, DFFT_F32_LIST_1024)
+#ifdef DFFT_EXPERIMENTS
+// the LDS-free shuffle pass (A/B only; natural lines in and out)
+int launch_shfl_f32(int N, int dpp, const PassArgs &A, hipStream_t stream)
+{
+    const uint32_t lines = A.LB * A.na, grid = (lines + 15) / 16;
+    if (N == 512 && !dpp) hipLaunchKernelGGL((fft_shfl_kernel<float, 512, 0>), dim3(grid), dim3(256), 0, stream, A);
+    else if (N == 512) hipLaunchKernelGGL((fft_shfl_kernel<float, 512, 1>), dim3(grid), dim3(256), 0, stream, A);
+    else if (N == 1024 && !dpp) hipLaunchKernelGGL((fft_shfl_kernel<float, 1024, 0>), dim3(grid), dim3(256), 0, stream, A);
+    else if (N == 1024) hipLaunchKernelGGL((fft_shfl_kernel<float, 1024, 1>), dim3(grid), dim3(256), 0, stream, A);
+    else return -1;
+    return (int)hipGetLastError();
+}
+#endif
 #elif DFFT_SLICE == 2
 DFFT_SLICE_FUNCS(f32, 2, DFFT_F32_LIST_2048)
 #else

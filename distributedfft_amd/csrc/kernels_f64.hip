@@ -12,50 +12,45 @@ using F64_64   = PassCfg<double, 64,   8, 8, 4,  8, 8, 1, 1,   2>;
 using F64_128  = PassCfg<double, 128, 16, 8, 4,  16, 8, 1, 1,  2>;
 using F64_256  = PassCfg<double, 256, 16, 8, 2,  16, 16, 1, 1, 2>;
 using F64_512  = PassCfg<double, 512, 16, 8, 1,  8, 8, 8, 1,   1>;
-// 1024: 512 threads, 124 VGPRs, 68 KiB LDS -> two workgroups per CU (measured best)
+// 1024: 512 threads, <= 128 VGPRs, 68 KiB LDS -> two workgroups per CU (measured best)
 using F64_1024 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1>;
 using F64_2048 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1>;
-// variant 1 = "strided read" configuration for passes that load the point-major API layout
-// (inverse x pass): 16 lines per workgroup (256-B runs per row) and 32 points per thread (twice
-// the loads in flight); 4.18 vs 3.76 TB/s at 1024^3
-using F64_1024_v1 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1>;
-// variant 3 = nontemporal loads and stores, for passes whose stores come in long runs (tiled
-// 1 KiB chunks, natural lines): +2-3 %; it costs 10 % on the 128-B-run stores, so those keep 0
+// The variant number of a configuration is its ROLE in a plan (dfft_init picks by role, see PassRole):
+//   1 = strided read: passes that load the point-major API layout (multi-rank inverse x pass): 16 lines per workgroup
+//       (256-byte runs per row), 32 points per thread (twice the loads in flight), nontemporal loads and stores
+//       (7.9 -> 7.6 ms at 1024^3; 8.9 ms with the default configuration)
+//   3 = streaming: nontemporal loads and stores, for passes whose stores come in long runs (tiled 1 KiB chunks,
+//       natural lines): +2-3 %; it costs up to 10 % on 128-byte-run stores, so those keep 0
+//   7 = natural lines: a pass with natural lines on one side.  Only 2048 has its own: 8 lines x 2048 points are
+//       256 KiB, one workgroup per CU whatever the configuration, so every tile is split between two sibling
+//       workgroups of 4 lines (PassCfg::SUB, 68 KiB LDS, two per CU) -- 16.5 -> 12-13 ms on a 1024 x 1024 x 2048 grid.
+//       With a tiled side the half-width (64-byte) runs of a sub-tile cost more than the occupancy gives, so the
+//       tiled 2048-point passes keep whole tiles.
+using F64_1024_v1 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 3>;
 using F64_1024_v3 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 3>;
-using F64_512_v1 = PassCfg<double, 512, 32, 8, 2, 32, 16, 1, 1, 1, 1>;      // strided read, 512
-using F64_512_v3 = PassCfg<double, 512, 16, 8, 1, 8, 8, 8, 1, 1, 0, 3>;       // nontemporal, 512
-using F64_2048_v3 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 3>;   // nontemporal, 2048
-// 2048: 8 lines x 2048 points are 256 KiB, one workgroup per CU whatever the configuration.  Variants 5 / 6
-// split every tile between two sibling workgroups of 4 lines (PassCfg::SUB): 68 KiB LDS, two per CU
-// (5 = plain, 6 = nontemporal; same numbering as the 1024 sub-tile variants).
-using F64_2048_v5 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 0, 0, 2>;
-using F64_2048_v6 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 3, 0, 2>;
+using F64_512_v1 = PassCfg<double, 512, 32, 8, 2, 32, 16, 1, 1, 1, 1>;
+using F64_512_v3 = PassCfg<double, 512, 16, 8, 1, 8, 8, 8, 1, 1, 0, 3>;
+using F64_2048_v3 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 3>;
+using F64_2048_v7 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 3, 0, 2>;
 #ifdef DFFT_EXPERIMENTS
 // A/B-only configurations (tools/kbench --opt variant_*=N); not part of the shipped library
-// variant 2 = table-loaded twiddles (bit-for-bit the round-1 baseline)
-using F64_1024_v2 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 0>;
-// variant 4 = two radix-32 passes on 8 lines (256 threads, one LDS exchange)
-using F64_1024_v4 = PassCfg<double, 1024, 32, 8, 1, 32, 32, 1, 1, 1, 1>;
-// variants 5/6 = sub-tile workgroups (4 lines, 256 threads, 34 KiB LDS: four per CU), plain / nontemporal
-using F64_1024_v5 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 0, 0, 2>;
-using F64_1024_v6 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 3, 0, 2>;
-// variant 7 = strided-read configuration with nontemporal stores
-using F64_1024_v7 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 2>;
-// variants 8 / 9 = default configuration with nontemporal loads only / stores only
-using F64_1024_v8 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 1>;
-using F64_1024_v9 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 2>;
-// variants 10 / 11 = strided-read configuration with nontemporal loads only / loads and stores
-using F64_1024_v10 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 1>;
-using F64_1024_v11 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 3>;
-// 2048: 32 points per thread (512 threads, three passes 32.32.2), whole tiles / sub-tiles
-using F64_2048_v2 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1>;
-using F64_2048_v4 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 0, 0, 2>;
+using F64_1024_v2 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 0>;                 // table-loaded twiddles (round-1 baseline)
+using F64_1024_v4 = PassCfg<double, 1024, 32, 8, 1, 32, 32, 1, 1, 1, 1>;                 // two radix-32 passes on 8 lines
+using F64_1024_v5 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 0, 0, 2>;        // sub-tile workgroups (4 lines)
+using F64_1024_v6 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 3, 0, 2>;        // ... nontemporal
+using F64_1024_v8 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 1>;              // nontemporal loads only
+using F64_1024_v9 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 2>;              // nontemporal stores only
+using F64_1024_v10 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1>;                // strided read, no nontemporal hints
+using F64_1024_v11 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 2>;             // strided read, nontemporal stores only
+using F64_2048_v2 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1>;                 // 32 points per thread, 32.32.2
+using F64_2048_v4 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 0, 0, 2>;        // ... sub-tiles
+using F64_2048_v5 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 0, 0, 2>;        // sub-tiles without nontemporal hints
 #endif
 
 #ifdef DFFT_EXPERIMENTS
-#define DFFT_F64_EXP_SMALL(X) 
-#define DFFT_F64_EXP_1024(X) X(1024, 2, F64_1024_v2) X(1024, 4, F64_1024_v4) X(1024, 5, F64_1024_v5) X(1024, 6, F64_1024_v6) X(1024, 7, F64_1024_v7) X(1024, 8, F64_1024_v8) X(1024, 9, F64_1024_v9) X(1024, 10, F64_1024_v10) X(1024, 11, F64_1024_v11)
-#define DFFT_F64_EXP_2048(X) X(2048, 2, F64_2048_v2) X(2048, 4, F64_2048_v4)
+#define DFFT_F64_EXP_SMALL(X)
+#define DFFT_F64_EXP_1024(X) X(1024, 2, F64_1024_v2) X(1024, 4, F64_1024_v4) X(1024, 5, F64_1024_v5) X(1024, 6, F64_1024_v6) X(1024, 8, F64_1024_v8) X(1024, 9, F64_1024_v9) X(1024, 10, F64_1024_v10) X(1024, 11, F64_1024_v11)
+#define DFFT_F64_EXP_2048(X) X(2048, 2, F64_2048_v2) X(2048, 4, F64_2048_v4) X(2048, 5, F64_2048_v5)
 #else
 #define DFFT_F64_EXP_SMALL(X)
 #define DFFT_F64_EXP_1024(X)
@@ -63,7 +58,7 @@ using F64_2048_v4 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 0, 0, 2>
 #endif
 #define DFFT_F64_LIST_SMALL(X) X(512, 1, F64_512_v1) X(512, 3, F64_512_v3) X(2, 0, F64_2) X(4, 0, F64_4) X(8, 0, F64_8) X(16, 0, F64_16) X(32, 0, F64_32) X(64, 0, F64_64) X(128, 0, F64_128) X(256, 0, F64_256) X(512, 0, F64_512) DFFT_F64_EXP_SMALL(X)
 #define DFFT_F64_LIST_1024(X) X(1024, 1, F64_1024_v1) X(1024, 3, F64_1024_v3) X(1024, 0, F64_1024) DFFT_F64_EXP_1024(X)
-#define DFFT_F64_LIST_2048(X) X(2048, 3, F64_2048_v3) X(2048, 5, F64_2048_v5) X(2048, 6, F64_2048_v6) X(2048, 0, F64_2048) DFFT_F64_EXP_2048(X)
+#define DFFT_F64_LIST_2048(X) X(2048, 3, F64_2048_v3) X(2048, 7, F64_2048_v7) X(2048, 0, F64_2048) DFFT_F64_EXP_2048(X)
 
 DFFT_SLICE_DECLS(f64)
 #if DFFT_SLICE == 0

@@ -80,6 +80,24 @@ template <typename R> __global__ void check_random(const R *p, size_t n, double 
     if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
 }
 
+// block partial maxima of |a - b| (first gridDim entries) and |b| (next gridDim entries)
+template <typename R> __global__ void diff_kernel(const R *a, const R *b, size_t n, double *partial)
+{
+    double md = 0, mr = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        md = fmax(md, fabs((double)a[i] - (double)b[i]));
+        mr = fmax(mr, fabs((double)b[i]));
+    }
+    __shared__ double s0[256], s1[256];
+    s0[threadIdx.x] = md; s1[threadIdx.x] = mr;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { s0[threadIdx.x] = fmax(s0[threadIdx.x], s0[threadIdx.x + s]); s1[threadIdx.x] = fmax(s1[threadIdx.x], s1[threadIdx.x + s]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[blockIdx.x] = s0[0]; partial[gridDim.x + blockIdx.x] = s1[0]; }
+}
+
 static double reduce_partials(double *d_part, int nblk)
 {
     std::vector<double> h(nblk);
@@ -195,7 +213,21 @@ template <typename R> static int run_line(const Args &a)
         best = fmin(best, ms); sum += ms;
     }
     const double bytes = 2.0 * n * 2 * sizeof(R);
-    double rt = -1;
+    double rt = -1, dev = -1;
+    if (a.check && !a.debug && a.variant != 0) {      // forward result against the default configuration's
+        R *ref;
+        HIPCHK(hipMalloc(&ref, n * 2 * sizeof(R)));
+        DCHK(dfft_fft1d_batched_ex(prec, a.line, a.batch, ref, in, DFFT_FORWARD, nullptr, 0, 0));
+        double *part;
+        HIPCHK(hipMalloc(&part, 2 * 1024 * sizeof(double)));
+        diff_kernel<R><<<1024, 256>>>(out, ref, 2 * n, part);
+        std::vector<double> h(2048);
+        HIPCHK(hipMemcpy(h.data(), part, 2048 * sizeof(double), hipMemcpyDeviceToHost));
+        double md = 0, mr = 0;
+        for (int i = 0; i < 1024; i++) { md = fmax(md, h[i]); mr = fmax(mr, h[1024 + i]); }
+        dev = md / mr;
+        HIPCHK(hipFree(ref)); HIPCHK(hipFree(part));
+    }
     if (a.check && !a.debug) {      // inverse of the forward result must give N * input
         DCHK(dfft_fft1d_batched_ex(prec, a.line, a.batch, in, out, DFFT_INVERSE, nullptr, a.variant, 0));
         double *part;
@@ -203,8 +235,8 @@ template <typename R> static int run_line(const Args &a)
         check_random<R><<<1024, 256>>>(in, 2 * n, 1.0 / (double)a.line, part);
         rt = reduce_partials(part, 1024) / 255.0;
     }
-    printf("LINE %s N=%zu batch=%zu %s variant=%d debug=%d avg %.4f ms min %.4f ms  %.1f GB/s (min)  roundtrip %.2e\n", a.label.c_str(),
-           a.line, a.batch, a.prec.c_str(), a.variant, a.debug, sum / a.iters, best, bytes / best / 1e6, rt);
+    printf("LINE %s N=%zu batch=%zu %s variant=%d debug=%d avg %.4f ms min %.4f ms  %.1f GB/s (min)  roundtrip %.2e  vs-default %.2e\n", a.label.c_str(),
+           a.line, a.batch, a.prec.c_str(), a.variant, a.debug, sum / a.iters, best, bytes / best / 1e6, rt, dev);
     return 0;
 }
 

@@ -10,8 +10,7 @@ import sys
 
 def demangle(names):
     try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True,
-                             text=True, check=True).stdout.splitlines()
+        out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True, check=True).stdout.splitlines()
         return out if len(out) == len(names) else names
     except Exception:  # noqa: BLE001
         return names
@@ -31,11 +30,11 @@ def main():
         rows.append((name, g("VGPRs"), g("AGPRs"), g("SGPRs"), g("ScratchSize [bytes/lane]"),
                      g("Occupancy [waves/SIMD]"), g("LDS Size [bytes/block]")))
     names = demangle([r[0] for r in rows])
-    print(f"{'kernel':100s} {'vgpr':>5s} {'agpr':>5s} {'sgpr':>5s} {'scratch':>8s} {'occ':>4s} {'lds':>7s}")
+    print(f"{'kernel':118s} {'vgpr':>5s} {'agpr':>5s} {'sgpr':>5s} {'scratch':>8s} {'occ':>4s} {'lds':>7s}")
     for n, r in zip(names, rows):
         n = n.replace("dfft::", "").replace("void ", "")
         n = re.sub(r"\(dfft::PassArgs\)|\(PassArgs\)", "", n)
-        print(f"{n[:100]:100s} {r[1]:>5s} {r[2]:>5s} {r[3]:>5s} {r[4]:>8s} {r[5]:>4s} {r[6]:>7s}")
+        print(f"{n[:118]:118s} {r[1]:>5s} {r[2]:>5s} {r[3]:>5s} {r[4]:>8s} {r[5]:>4s} {r[6]:>7s}")
 
 
 if __name__ == "__main__":

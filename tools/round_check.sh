@@ -1,23 +1,57 @@
 #!/bin/bash
-# tools/round_check.sh -- the standard measurement set of a round in ONE gpurun call (≈ 3 GPU-minutes):
-#   gpurun --timeout 900 -- 'bash tools/round_check.sh'
-# GPU parity suite, bench line, rocprofv3 kernel stats of the bench, per-pass times (C2C fp64/fp32,
-# R2C fp64/fp32, chunked), R2C wall times.  Everything lands in gpurun_out/round_check/.
+# tools/round_check.sh [TAG] -- the standard measurement set of a round in ONE gpurun call:
+#   gpurun --timeout 1500 -- 'bash tools/round_check.sh r2'
+# GPU parity suite, the bench line (1024^3 fp64) and its rocprofv3 kernel stats, the 2048^3 fp32 bench line and
+# stats, per-pass times of every configuration DESIGN.md quotes (kbench, C ABI, no Python), PMC counters of the
+# headline kernels.  Everything lands in gpurun_out/round_check/; copy what DESIGN.md cites into profiles/.
+TAG=${1:-r2}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/round_check
 mkdir -p $OUT
 cd $R
-timeout 600 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.txt 2>&1; tail -2 $OUT/pytest_gpu.txt
-python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 600 $OUT/bench.json; echo
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $R/bench.py --no-cpu-baseline > $OUT/prof.log 2>&1 )
-cp $OUT/prof/bench_kernel_stats.csv $OUT/bench_kernel_stats.csv 2>/dev/null
+K=$R/tools/kbench
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.txt 2>&1; tail -2 $OUT/pytest_gpu.txt
+python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 300 $OUT/bench.json; echo
+prof() {  # name, command...: rocprofv3 kernel trace + stats of a command, stats csv copied next to the logs
+  local name=$1; shift
+  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o $name -- "$@" > $OUT/prof_$name.log 2>&1 )
+  find $OUT/prof_$name -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_${name}_kernel_stats.csv \;
+}
+prof bench python $R/bench.py --no-cpu-baseline
+python bench.py --size 2048 --precision float --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_f32_2048.json 2> $OUT/bench_f32_2048.err; tail -c 300 $OUT/bench_f32_2048.json; echo
+prof f32_2048 $K --size 2048 --prec f32 --iters 3
+prof f32_2048_multirank $K --size 2048 --prec f32 --iters 3 --opt mirror_inverse=1 --opt pipeline_chunks=8
+prof f64_2048z $K --size 1024x1024x2048 --prec f64 --iters 3
+prof f64_2048y $K --size 1024x2048x1024 --prec f64 --iters 3
+prof f64_2048x $K --size 2048x1024x1024 --prec f64 --iters 3
+prof f64_multirank $K --size 1024 --prec f64 --iters 5 --opt mirror_inverse=1 --opt pipeline_chunks=8
+prof f64_r2c $K --size 1024 --prec f64 --mode r2c --iters 5
+prof f32_r2c $K --size 1024 --prec f32 --mode r2c --iters 5
+prof f32_c2c $K --size 1024 --prec f32 --iters 5
+prof f64_bluestein1000 $K --size 1000 --prec f64 --iters 3
 {
-  echo "== c2c fp64";            python tools/phase_times.py 1024 double 3 | tail -7
-  echo "== c2c fp32";            python tools/phase_times.py 1024 float 3 | tail -7
-  echo "== c2c fp64 chunks 8";   DFFT_CHUNKS=8 python tools/phase_times.py 1024 double 3 | tail -7
-  echo "== c2c fp64 chunks 32";  DFFT_CHUNKS=32 python tools/phase_times.py 1024 double 3 | tail -7
-  echo "== r2c fp64";            python tools/phase_times_r2c.py 1024 double 3
-  echo "== r2c fp32";            python tools/phase_times_r2c.py 1024 float 3
-  echo "== r2c wall";            python tools/latency.py 2>&1 | grep R2C
-} > $OUT/phase_times.txt 2>&1
-grep -v amdgpu.ids $OUT/phase_times.txt
+  echo "== c2c fp64 1024";                 $K --size 1024 --prec f64 --iters 5 --check
+  echo "== c2c fp64 1024 multi-rank path"; $K --size 1024 --prec f64 --iters 5 --check --opt mirror_inverse=1 --opt pipeline_chunks=8
+  echo "== c2c fp64 1024 pattern roofs";   $K --size 1024 --prec f64 --iters 5 --opt debug_skip=1
+  echo "== c2c fp32 1024";                 $K --size 1024 --prec f32 --iters 5 --check
+  echo "== c2c fp32 1024 multi-rank path"; $K --size 1024 --prec f32 --iters 5 --check --opt mirror_inverse=1 --opt pipeline_chunks=8
+  echo "== r2c fp64 1024";                 $K --size 1024 --prec f64 --mode r2c --iters 5 --check
+  echo "== r2c fp32 1024";                 $K --size 1024 --prec f32 --mode r2c --iters 5 --check
+  echo "== c2c fp32 2048";                 $K --size 2048 --prec f32 --iters 3 --check
+  echo "== c2c fp32 2048 pattern roofs";   $K --size 2048 --prec f32 --iters 3 --opt debug_skip=1
+  echo "== c2c fp32 2048 multi-rank path"; $K --size 2048 --prec f32 --iters 3 --opt mirror_inverse=1 --opt pipeline_chunks=8
+  for sz in 1024x1024x2048 1024x2048x1024 2048x1024x1024; do
+    echo "== c2c fp64 $sz";                $K --size $sz --prec f64 --iters 3 --check
+    echo "== c2c fp64 $sz multi-rank path"; $K --size $sz --prec f64 --iters 3 --opt mirror_inverse=1
+  done
+  echo "== Bluestein 1000^3 fp64";         $K --size 1000 --prec f64 --iters 3 --check
+  for n in 128 256 512; do echo "== r2c fp64 $n^3 (wall = latency)"; $K --size $n --prec f64 --mode r2c --iters 20; done
+  echo "== c2c fp64 256^3 (C2), 512^3";    $K --size 256 --prec f64 --iters 20 --check; $K --size 512 --prec f64 --iters 10 --check
+} > $OUT/${TAG}_phase_times.txt 2>&1
+grep -E "^==|^PLAN|FFT" $OUT/${TAG}_phase_times.txt | head -150
+# PMC: LDS conflicts / activity of the 2048-point fp32 passes and the fp64 R2C passes (separate passes, kernel-trace only)
+bash tools/pmc_quick.sh ${TAG}_f32_2048 -- $K --size 2048 --prec f32 --iters 1 > /dev/null 2>&1
+bash tools/pmc_quick.sh ${TAG}_f64_r2c -- $K --size 1024 --prec f64 --mode r2c --iters 1 > /dev/null 2>&1
+python tools/pmc_summary.py $R/gpurun_out/pmcq_${TAG}_f32_2048 fft_ > $OUT/${TAG}_pmc_f32_2048.txt 2>&1
+python tools/pmc_summary.py $R/gpurun_out/pmcq_${TAG}_f64_r2c fft_ > $OUT/${TAG}_pmc_f64_r2c.txt 2>&1
