@@ -12,7 +12,15 @@ a timer CSV in the reference's format (`src/timer.cpp:58-101`: header row of ran
 
 Ranks: by default the P1*P2 ranks are virtual ranks sharing GPU 0 (one host thread each), the
 analogue of `mpiexec -n P` with `cudaSetDevice(rank % dev_count)` on a 1-GPU box.  Under
-`torch.distributed.run` (WORLD_SIZE set) every process is one rank on its own GPU.
+`torch.distributed.run` (WORLD_SIZE > 1) every process is ONE rank on GPU `LOCAL_RANK % device_count`
+-- the reference's `mpiexec -n P ./pencil ...` (tests/src/pencil/main.cpp:194-229):
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
+        -m distributedfft_amd.cli pencil -nx 1024 -ny 1024 -nz 1024 -p1 2 -p2 4 -o 1 -t 3 -i 20 -w 10 -d -c
+
+The exchange then runs over RCCL (`--backend nccl`, the library's own communicator or torch's, chosen like in
+bench.py) or, with `--backend gloo`, through host memory so that several ranks may share one GPU.  Error norms are
+reduced over the ranks, rank 0 prints them and writes the timer CSV with one column per rank.
 
 Test utilities only (random fill, the Laplacian multiplier, error norms use torch ops); the
 transforms go through the C ABI.
@@ -56,11 +64,14 @@ def parse(argv):
     ap.add_argument("--sequence", "-s", default="ZY_Then_X", choices=["ZY_Then_X", "Z_Then_YX", "Y_Then_ZX"],
                     help="slab only (tests/src/slab/main.cpp:138-140)")
     ap.add_argument("--complex", action="store_true", help="extension: complex-to-complex instead of R2C/C2R")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="one-process-per-rank runs: torch.distributed backend (gloo: ranks may share a GPU)")
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "torch"], help="one-process-per-rank runs, backend nccl")
     return ap.parse_args(argv)
 
 
 class Rank:
-    def __init__(self, args, comm, rank, P1, P2):
+    def __init__(self, args, comm, rank, P1, P2, register=None, own_stream=False):
         import torch
 
         import distributedfft_amd as dfft
@@ -80,13 +91,28 @@ class Rank:
         self.plan = kind(cfg, comm, precision=prec, rank=rank)
         t0 = time.perf_counter()
         self.N = (args.input_dim_x, args.input_dim_y, args.input_dim_z)
-        self.plan.initFFT(dfft.GlobalSize(*self.N), dfft.Partition(P1, P2), True, c2c=args.complex)
+        # one process per rank: the plan runs on a dedicated torch stream (the torch transport's collectives order
+        # themselves against torch's current stream) and exchanges only registered tensors
+        self.side = torch.cuda.Stream() if register is not None or own_stream else None
+        self.plan.initFFT(dfft.GlobalSize(*self.N), dfft.Partition(P1, P2), register is None, c2c=args.complex)
+        if self.side is not None:
+            self.plan.setStream(self.side.cuda_stream)
+        if register is not None:
+            self.work = torch.empty(self.plan.getWorkSizeDevice(), dtype=torch.uint8, device="cuda")
+            self.plan.setWorkArea(self.work)
+            register(self.work)
         self.plan.enablePhaseTiming(True)
         self.init_ms = (time.perf_counter() - t0) * 1e3
         self.isz, self.ist = self.plan.getInSize(), self.plan.getInStart()
         self.osz, self.ost = self.plan.getOutSize(), self.plan.getOutStart()
         self.out = torch.zeros(self.plan.getDomainSize() // self.esz, dtype=self.cdt, device="cuda")
+        if register is not None:
+            register(self.out)
         self.timings = []
+
+    def _on_stream(self):
+        import contextlib
+        return self.torch.cuda.stream(self.side) if self.side is not None else contextlib.nullcontext()
 
     def rand_input(self):
         """uniform (0,1] * 255 like initializeRandArray (tests/src/pencil/base.cu:39-58), but seeded"""
@@ -99,17 +125,19 @@ class Rank:
         return (t.rand(n, dtype=self.rdt, device="cuda", generator=g) * 255).reshape(self.isz)
 
     def forward(self, x, d=3):
-        if self.args.complex:
-            self.plan.execC2C(self.out, x, self.dfft.FORWARD, d=d)
-        else:
-            self.plan.execR2C(self.out, x, d)
+        with self._on_stream():
+            if self.args.complex:
+                self.plan.execC2C(self.out, x, self.dfft.FORWARD, d=d)
+            else:
+                self.plan.execR2C(self.out, x, d)
         self.record(self.dfft.FORWARD)
 
     def inverse(self, y, d=3):
-        if self.args.complex:
-            self.plan.execC2C(y, self.out, self.dfft.INVERSE, d=d)
-        else:
-            self.plan.execC2R(y, self.out, d)
+        with self._on_stream():
+            if self.args.complex:
+                self.plan.execC2C(y, self.out, self.dfft.INVERSE, d=d)
+            else:
+                self.plan.execC2R(y, self.out, d)
         self.record(self.dfft.INVERSE)
 
     def record(self, direction):
@@ -145,6 +173,11 @@ class Rank:
         k3 = wrapped(t.arange(self.ost[2], self.ost[2] + self.osz[2], device="cuda"), Nz, half=not self.args.complex).reshape(1, 1, -1)
         scale = -(k1 ** 2 + k2 ** 2 + k3 ** 2) / math.sqrt(float(Nx) * Ny * Nz)
         blk.mul_(scale.to(blk.real.dtype))
+
+
+class _Timings:      # what write_csv needs of a rank (the rank objects themselves, or what other processes sent to rank 0)
+    def __init__(self, init_ms, timings):
+        self.init_ms, self.timings = init_ms, timings
 
 
 def write_csv(args, ranks, P1, P2):
@@ -192,13 +225,51 @@ def run(argv=None):
     else:
         P1, P2 = (args.partition1 or 1), args.partition2
     P = P1 * P2
-    world = dfft.Comm.local(P) if P > 1 else None
-    ranks = [Rank(args, world, r, P1, P2) for r in range(P)]
-    pool = ThreadPoolExecutor(P)
+    nproc = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if nproc > 1:
+        # one process per rank (the reference's mpiexec -n P): this process is rank RANK of P
+        import torch.distributed as dist
+
+        from distributedfft_amd.torch_transport import make_comm
+        if nproc != P:
+            raise SystemExit(f"{nproc} processes but a {P1}x{P2} partition")
+        me = int(os.environ["RANK"])
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+        dist.init_process_group(args.backend)
+        comm, transport = make_comm(dist, me, nproc, P1, P2, "torch" if args.backend == "gloo" else args.transport)
+        register = comm.register if transport == "torch" else None
+        ranks = [Rank(args, comm, me, P1, P2, register=register, own_stream=True)]
+        pool = None
+    else:
+        me = 0
+        world = dfft.Comm.local(P) if P > 1 else None
+        ranks = [Rank(args, world, r, P1, P2) for r in range(P)]
+        pool = ThreadPoolExecutor(P)
+    root = me == 0
 
     def each(fn):
-        list(pool.map(fn, ranks))
-        torch.cuda.synchronize()
+        if pool is None:
+            fn(ranks[0])
+            torch.cuda.synchronize()
+            dist.barrier()
+        else:
+            list(pool.map(fn, ranks))
+            torch.cuda.synchronize()
+
+    def gsum(v):      # sum / max over all ranks (values of this process's ranks are already combined)
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def gmax(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     Nx, Ny, Nz = ranks[0].N
     n3 = float(Nx) * Ny * Nz
@@ -222,9 +293,13 @@ def run(argv=None):
         # distributed == single device (tests/src/pencil/random_dist_3D.cu:229-504); the coordinator's
         # one-GPU transform is a single-rank plan of this library on the same device
         xs = {rk.rank: rk.rand_input() for rk in ranks}
-        full = torch.zeros(ranks[0].N, dtype=xs[0].dtype, device="cuda")
+        full = torch.zeros(ranks[0].N, dtype=xs[ranks[0].rank].dtype, device="cuda")
         for rk in ranks:
             full[rk.ist[0]:rk.ist[0] + rk.isz[0], rk.ist[1]:rk.ist[1] + rk.isz[1], :] = xs[rk.rank]
+        if dist is not None:      # assemble the global input on every process (testcase 1 runs on small grids)
+            buf = full.cpu() if args.backend == "gloo" else full
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            full = buf.cuda()
         single = Rank(args, None, 0, 1, 1)
         torch.cuda.synchronize()
         single.forward(full.contiguous(), 3)
@@ -235,8 +310,10 @@ def run(argv=None):
             n = rk.osz[0] * rk.osz[1] * rk.osz[2]
             blk = rk.out[:n].reshape(rk.osz)
             tot += float((blk - ref[:, rk.ost[1]:rk.ost[1] + rk.osz[1], rk.ost[2]:rk.ost[2] + rk.osz[2]]).abs().sum())
+        tot = gsum(tot)
         result = {"sum": tot}
-        print(f"Result {tot}")
+        if root:
+            print(f"Result {tot}")
     elif args.testcase == 3:
         xs = {rk.rank: rk.rand_input() for rk in ranks}
         ys = {rk.rank: torch.zeros_like(xs[rk.rank]) for rk in ranks}
@@ -245,10 +322,11 @@ def run(argv=None):
             each(lambda rk: rk.forward(xs[rk.rank], 3))
             each(lambda rk: rk.inverse(ys[rk.rank], 3))
             diffs = [(ys[rk.rank] - n3 * xs[rk.rank]).abs() for rk in ranks]   # differenceInv(inv, in, n, N^3), :650
-            s, m = sum(float(v.sum()) for v in diffs), max(float(v.max()) for v in diffs)
+            s, m = gsum(sum(float(v.sum()) for v in diffs)), gmax(max(float(v.max()) for v in diffs))
             result = {"avg": s / n3, "max": m}
-            print(f"Result (avg): {s / n3}")
-            print(f"Result (max): {m}")
+            if root:
+                print(f"Result (avg): {s / n3}")
+                print(f"Result (max): {m}")
     elif args.testcase == 4:
         us, ders = {}, {}
         for rk in ranks:
@@ -266,14 +344,26 @@ def run(argv=None):
             torch.cuda.synchronize()
             each(lambda rk: rk.inverse(ys[rk.rank], 3))
             diffs = [(ys[rk.rank] - ders[rk.rank]).abs() for rk in ranks]
-            s, m = sum(float(v.sum()) for v in diffs), max(float(v.max()) for v in diffs)
+            s, m = gsum(sum(float(v.sum()) for v in diffs)), gmax(max(float(v.max()) for v in diffs))
             result = {"avg": s / n3, "max": m}
-            print(f"Result (avg): {s / n3}")
-            print(f"Result (max): {m}")
-    result["csv"] = write_csv(args, ranks, P1, P2)
-    pool.shutdown()
+            if root:
+                print(f"Result (avg): {s / n3}")
+                print(f"Result (max): {m}")
+    if dist is None:
+        result["csv"] = write_csv(args, ranks, P1, P2)
+        pool.shutdown()
+    else:
+        # the reference gathers the timings on rank 0 (MPI_Gatherv in src/timer.cpp:58-101) and writes one column per rank
+        gathered = [None] * nproc if root else None
+        dist.gather_object((ranks[0].init_ms, ranks[0].timings), gathered, dst=0)
+        if root:
+            result["csv"] = write_csv(args, [_Timings(i, t) for i, t in gathered], P1, P2)
+        dist.barrier()
+        dist.destroy_process_group()
     return result
 
 
 if __name__ == "__main__":
-    run()
+    r = run()
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("cli result:", {k: v for k, v in r.items()})

@@ -65,3 +65,29 @@ def test_slab_sequence_z_then_yx_testcases(tmp_path):
     assert os.path.dirname(r["csv"]).endswith("slab_y_then_zx")
     with pytest.raises(SystemExit):
         cli.run(base + ["-s", "Y_Then_ZX", "-t", "3"])
+
+
+@pytest.mark.parametrize("mode,extra,nproc", [("pencil", ["-p1", "2", "-p2", "2", "-o", "1", "-t", "3", "-i", "2", "-w", "1"], 4),
+                                              ("slab", ["-p", "3", "-t", "4"], 3),
+                                              ("pencil", ["-p1", "3", "-p2", "2", "-t", "1"], 6)])
+def test_one_process_per_rank_under_torch_distributed_run(tmp_path, mode, extra, nproc):
+    """the reference's `mpiexec -n P ./pencil ...` (tests/src/pencil/main.cpp:194-229): P processes, one rank each, here
+    sharing the single GPU of the test box over gloo; error norms reduced over ranks, rank 0 writes the CSV"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29600 + nproc
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "distributedfft_amd.cli", mode, "-nx", "48", "-ny", "32", "-nz", "40", "-d",
+           "-b", str(tmp_path), "--backend", "gloo"] + extra
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=root))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("cli result:")]
+    assert len(line) == 1, out.stdout
+    res = eval(line[0][len("cli result:"):])       # noqa: S307  (our own repr of a dict of floats and one path)
+    if "-t" in extra and extra[extra.index("-t") + 1] == "1":
+        assert res["sum"] < 1e-6
+    else:
+        assert res["max"] < 1e-6
+    hdr = open(res["csv"]).read().split("\n")[0]
+    assert hdr == "," + "".join(f"{i}," for i in range(nproc))
