@@ -264,7 +264,8 @@ struct dfft_plan {
     bool work_owned = false;
     Axis ax[3];                  // [0] = z, [1] = y, [2] = x
     bool zreal_native = false;   // R2C plan whose z axis uses the packed Nz/2-point kernels
-    void *tw_zr = nullptr;       // split/merge table exp(-2 pi i k / Nz) of the packed real kernels
+    bool yreal_native = false;   // Y_Then_ZX R2C plan whose y axis uses the packed Ny/2-point kernel (strided real lines)
+    void *tw_zr = nullptr;       // split/merge table exp(-2 pi i k / Nz) (or / Ny) of the packed real kernels
     void *tables_d = nullptr;    // segment tables of every launch, device copy
     hipStream_t stream = nullptr;
     bool stream_owned = false;
@@ -683,6 +684,13 @@ static int launch(dfft_plan *p, const Launch &L, int variant, int axis, const ch
     PassArgs A = L.args;
     A.in = in + L.in_off; A.out = out + L.out_off; A.tw = ax.tw; A.debug = p->opt.debug;
     fill_tables(p, L, A);
+    if (real_lines && p->yreal_native && axis == 1) {      // packed real kernel on strided lines (Y_Then_ZX)
+        A.tw2 = p->tw_zr;
+        const int M = (int)(p->Ny / 2);
+        const int r = p->prec == DFFT_F64 ? launch_real_f64(M, 1, 0, A, p->stream) : launch_real_f32(M, 1, 0, A, p->stream);
+        if (r != 0) return fail(r == -1 ? ERR_UNSUPPORTED : r, "real y pass launch failed for length " + std::to_string(p->Ny));
+        return 0;
+    }
     if (!ax.bluestein) return launch_pass(p->prec, (int)ax.N, variant, A, p->stream);
     A.tw2 = ax.chirp; A.tw3 = ax.bhat; A.NL = (uint32_t)ax.N; A.NK = (uint32_t)ax.N; A.real_mode = 0;
     if (real_lines) { A.real_mode = 1; A.NK = (uint32_t)(ax.N / 2 + 1); }     // real in, Hermitian half out
@@ -1237,17 +1245,21 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         const bool zr_native = !yzx && !c2c && is_pow2(Nz) && Nz >= 4 && Nz <= 2048;
         const size_t zlen = zr_native ? Nz / 2 : Nz;
         // Y_Then_ZX, R2C: the y pass reads real lines in place, which only the Bluestein kernel does
-        const bool yok = yzx && !c2c ? axis_plan_bluestein(p->prec, Ny, ay) : axis_plan(p->prec, Ny, ay);
+        // Y_Then_ZX, R2C: the y pass reads real lines in place.  Power-of-two Ny: the packed Ny/2-point real kernel
+        // with its strided-line load; any other Ny: the Bluestein kernel's real mode (Ny <= 1024)
+        const bool yr_native = yzx && !c2c && is_pow2(Ny) && Ny >= 4 && Ny <= 2048;
+        const bool yok = yr_native ? axis_plan(p->prec, Ny / 2, ay) : yzx && !c2c ? axis_plan_bluestein(p->prec, Ny, ay) : axis_plan(p->prec, Ny, ay);
         // a real z pass is either the packed Nz/2-point kernel or the Bluestein kernel's real modes: never
         // the plain complex chain (Nz == 2 would otherwise pick it and launch Bluestein without its tables)
         const bool zreal_generic = !yzx && !c2c && !zr_native;
         const bool zok = zreal_generic ? axis_plan_bluestein(p->prec, Nz, az) : axis_plan(p->prec, zlen, az);
         if (!zok || !yok || !axis_plan(p->prec, Nx, axx))
-            return fail(ERR_UNSUPPORTED, yzx && !c2c && Ny > 1024 ? "unsupported axis length (Y_Then_ZX R2C: Ny up to 1024)"
+            return fail(ERR_UNSUPPORTED, yzx && !c2c && Ny > 1024 ? "unsupported axis length (Y_Then_ZX R2C: powers of two up to 2048, other Ny up to 1024)"
                         : "unsupported axis length (powers of two up to 2048, any other length up to 1024)");
         for (auto &a : p->ax) axis_free(a);
         p->ax[0] = az; p->ax[1] = ay; p->ax[2] = axx;
         p->zreal_native = zr_native;
+        p->yreal_native = yr_native;
     }
     p->Nx = Nx; p->Ny = Ny; p->Nz = Nz; p->c2c = c2c != 0;
     p->Nzc = (c2c || yzx) ? Nz : Nz / 2 + 1;
@@ -1421,6 +1433,7 @@ static int ensure_device_state(dfft_plan *p)
     if (!p->tables_d) TRY(upload_tables(p));
     for (auto &a : p->ax) TRY(axis_upload(p->prec, a));
     if (p->zreal_native && !p->tw_zr) TRY(make_twiddles(p->prec, p->Nz, &p->tw_zr));
+    if (p->yreal_native && !p->tw_zr) TRY(make_twiddles(p->prec, p->Ny, &p->tw_zr));
     if (!p->stream && !p->stream_user) {
         HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
         p->stream_owned = true;

@@ -683,6 +683,31 @@ template <int TL> struct TransposeOne {
     }
 };
 
+// element offset of point n (k) of the calling lane's line for every load (store) address form
+template <int TL>
+__device__ __forceinline__ uint64_t generic_load_offset(const PassArgs &A, const TileCtx<TL> &c, uint32_t n, uint32_t NP)
+{
+    if (A.load_kind == LOAD_LINES) return ((uint64_t)c.a * A.LB + (uint64_t)c.b * TL + c.l) * NP + n;
+    if (A.load_kind == LOAD_KMAJOR) return (uint64_t)n * A.KS_in + (uint64_t)c.a * A.AS_in + (uint64_t)c.b * TL + c.l;
+    return tiled_load_offset<TL>(A, c, n);
+}
+template <int TL>
+__device__ __forceinline__ uint64_t generic_store_offset(const PassArgs &A, const TileCtx<TL> &c, uint32_t k, uint32_t NP)
+{
+    if (A.store_kind == STORE_LINES)
+        return (A.KS_out ? (uint64_t)c.a * A.AS_out + ((uint64_t)c.b * TL + c.l) * A.KS_out
+                         : ((uint64_t)c.a * A.LB + (uint64_t)c.b * TL + c.l) * NP) + k;
+    if (A.store_kind == STORE_KMAJOR) return (uint64_t)k * A.KS_out + (uint64_t)c.a * A.AS_out + (uint64_t)c.b * TL + c.l;
+    if (A.store_kind == STORE_TILED_TRANSPOSE) return tiled_transpose_store_offset<TL>(A, c, k);
+    if (A.stab) return seg_entry(A.stab + k).base + (uint64_t)c.b * TL * A.LA + (uint64_t)c.a * c.tw + c.l;
+    uint32_t s0 = A.sseg->start[0], ln = A.sseg->len[0];
+    uint64_t bs = A.sseg->base[0];
+    for (int s = 1; s < A.snseg; s++)
+        if (k >= A.sseg->start[s]) { s0 = A.sseg->start[s]; ln = A.sseg->len[s]; bs = A.sseg->base[s]; }
+    (void)ln;
+    return bs + (uint64_t)(k - s0) * A.LB * A.LA + (uint64_t)c.b * TL * A.LA + (uint64_t)c.a * c.tw + c.l;
+}
+
 // tile of the calling lane for the real-transform kernels; lw = the lane's line within the workgroup in
 // the coordinate set in use (first pass or later passes: they differ for the point-fastest mappings)
 template <typename Cfg> __device__ __forceinline__ bool real_tile(const PassArgs &A, int lw, TileCtx<Cfg::kTL> &tc)
@@ -723,7 +748,18 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
     const C *__restrict__ W2 = reinterpret_cast<const C *>(A.tw2);
 
     C v[E];
-    if (active) {
+    if (active && A.load_kind == LOAD_KMAJOR) {
+        // real lines with a stride, lanes along the contiguous axis (the y pass of the Y_Then_ZX sequence reads the
+        // input [x][y][z] in place): real point m of the line at a*AS_in + m*KS_in + b*TL + l, in REAL elements;
+        // complex point j of the packed transform is (x[2j], x[2j+1])
+        const R *rp = reinterpret_cast<const R *>(A.in) + (uint64_t)tc.a * A.AS_in + (uint64_t)tc.b * TL + tc.l;
+        static_for<0, E>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            const uint64_t m = 2 * (uint64_t)(t + NT * c);
+            v[c].x = rp[m * A.KS_in];
+            v[c].y = rp[(m + 1) * A.KS_in];
+        });
+    } else if (active) {
         const C *p = in + ((uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + tc.l) * M + t;
         static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = p[NT * c]; });
     } else {
@@ -731,11 +767,9 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
     }
     if (A.debug & 1) {          // measurement only: copy with this pass's access pattern
         if (!active) return;
-        const uint64_t row = ((uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + tc.l) * (uint64_t)(M + 1);
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
-            const uint32_t k = t + NT * c;
-            out[A.store_kind == STORE_LINES ? row + k : tiled_transpose_store_offset<TL>(A, tc, k)] = v[c];
+            out[generic_store_offset<TL>(A, tc, (uint32_t)(t + NT * c), M + 1)] = v[c];
         });
         return;
     }
@@ -802,6 +836,9 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
         // natural [line][M+1] rows (partial transform, d = 1)
         const uint64_t row = ((uint64_t)tc2.a * A.LB + (uint64_t)tc2.b * TL + tc2.l) * (uint64_t)(M + 1);
         emit([&](uint32_t k) { return row + k; });
+    } else if (A.store_kind != STORE_TILED_TRANSPOSE) {
+        // point-major or same-tile stores (Y_Then_ZX: the y pass writes [ky][z/TL][x][z%TL] blocks)
+        emit([&](uint32_t k) { return generic_store_offset<TL>(A, tc2, k, M + 1); });
     } else if (A.stab || A.snseg != 1) {
         emit([&](uint32_t k) { return tiled_transpose_store_offset<TL>(A, tc2, k); });
     } else {
@@ -906,7 +943,6 @@ template <typename R, int N, int DPP> __global__ __launch_bounds__(256) void fft
 {
     using C = typename Vec2<R>::type;
     constexpr int E = N / 16;
-    using Cfg = PassCfg<R, N, E, 16, 1, E, 1, 1, 1, 1>;        // only for pass_compute's register butterflies
     const int tid = threadIdx.x, t = tid & 15;
     const uint32_t line = blockIdx.x * 16 + (tid >> 4);
     if (line >= A.LB * A.na) return;
@@ -966,30 +1002,6 @@ template <typename R, int N, int DPP> __global__ __launch_bounds__(256) void fft
 // Real plans (real_mode 1/2) run the full complex transform of the real line and keep / rebuild
 // the Hermitian half, which also covers odd lengths.
 // ------------------------------------------------------------------------------------------
-template <int TL>
-__device__ __forceinline__ uint64_t generic_load_offset(const PassArgs &A, const TileCtx<TL> &c, uint32_t n, uint32_t NP)
-{
-    if (A.load_kind == LOAD_LINES) return ((uint64_t)c.a * A.LB + (uint64_t)c.b * TL + c.l) * NP + n;
-    if (A.load_kind == LOAD_KMAJOR) return (uint64_t)n * A.KS_in + (uint64_t)c.a * A.AS_in + (uint64_t)c.b * TL + c.l;
-    return tiled_load_offset<TL>(A, c, n);
-}
-template <int TL>
-__device__ __forceinline__ uint64_t generic_store_offset(const PassArgs &A, const TileCtx<TL> &c, uint32_t k, uint32_t NP)
-{
-    if (A.store_kind == STORE_LINES)
-        return (A.KS_out ? (uint64_t)c.a * A.AS_out + ((uint64_t)c.b * TL + c.l) * A.KS_out
-                         : ((uint64_t)c.a * A.LB + (uint64_t)c.b * TL + c.l) * NP) + k;
-    if (A.store_kind == STORE_KMAJOR) return (uint64_t)k * A.KS_out + (uint64_t)c.a * A.AS_out + (uint64_t)c.b * TL + c.l;
-    if (A.store_kind == STORE_TILED_TRANSPOSE) return tiled_transpose_store_offset<TL>(A, c, k);
-    if (A.stab) return seg_entry(A.stab + k).base + (uint64_t)c.b * TL * A.LA + (uint64_t)c.a * c.tw + c.l;
-    uint32_t s0 = A.sseg->start[0], ln = A.sseg->len[0];
-    uint64_t bs = A.sseg->base[0];
-    for (int s = 1; s < A.snseg; s++)
-        if (k >= A.sseg->start[s]) { s0 = A.sseg->start[s]; ln = A.sseg->len[s]; bs = A.sseg->base[s]; }
-    (void)ln;
-    return bs + (uint64_t)(k - s0) * A.LB * A.LA + (uint64_t)c.b * TL * A.LA + (uint64_t)c.a * c.tw + c.l;
-}
-
 // registers hold the outputs of a transform (slot c <-> index t + k0(c)); bring them back to the
 // input order of the next transform (slot c <-> index t + NT*c) through the LDS plane
 template <typename Cfg>

@@ -136,6 +136,11 @@ int launch_real_f32(int M, int mode, int variant, const PassArgs &A, hipStream_t
     }
 #endif
     (void)variant;
+    if (mode == 1 && A.load_kind == LOAD_KMAJOR) {
+        // strided real lines (Y_Then_ZX): the lanes run along the contiguous axis, i.e. the line-fastest mapping
+        if (M == 512) return launch_real_cfg<F32_R512_32, 1, 1>(A, stream);
+        if (M == 1024) return launch_real_cfg<F32_1024_v6, 1, 1>(A, stream);
+    }
     if (M == 512) return mode == 1 ? launch_real_cfg<F32_R512_pf1, 1, 1>(A, stream) : launch_real_cfg<F32_R512_pf2, 2>(A, stream);
     if (M == 1024) return mode == 1 ? launch_real_cfg<F32_R1024_pf1, 1, 1>(A, stream) : launch_real_cfg<F32_R1024_pf2, 2>(A, stream);
     switch (M) {
