@@ -21,6 +21,8 @@ class PassDesc(C.Structure):
     _fields_ = [("na", C.c_uint32), ("LB", C.c_uint32), ("nb", C.c_uint32), ("LA", C.c_uint32), ("T2shift", C.c_uint32),
                 ("load_kind", C.c_int32), ("store_kind", C.c_int32), ("swap", C.c_int32), ("shift", C.c_int32),
                 ("KS_in", C.c_uint64), ("KS_out", C.c_uint64), ("AS_in", C.c_uint64), ("AS_out", C.c_uint64),
+                ("IA", C.c_uint64), ("IB", C.c_uint64), ("SK", C.c_uint64), ("SB", C.c_uint64),
+                ("a_fastest", C.c_int32), ("xcd_swizzle", C.c_int32),
                 ("in_off", C.c_uint64), ("out_off", C.c_uint64),
                 ("lnseg", C.c_int32), ("snseg", C.c_int32),
                 ("lstart", C.c_uint32 * 32), ("llen", C.c_uint32 * 32), ("lbase", C.c_uint64 * 32),

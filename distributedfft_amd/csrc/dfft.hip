@@ -225,6 +225,10 @@ struct Pipeline {
     std::vector<Launch> zy, ziy;
     Launch zix;
     Launch yz;                                 // Y_Then_ZX: final z pass (x pass = fx, y chunks = fy)
+    // single-rank complex plans, pass order z, x, y (build_pipeline_single): natural lines -> L1 -> L2 -> natural
+    Launch sz, sx, sy;
+    bool single = false;
+    size_t single_work_elems = 0;              // size of the padded L2 buffer
     std::vector<A2A> f1, f2, i2, i1;          // per chunk exchange tables
     std::vector<hipEvent_t> ev;               // reusable events
     hipStream_t comm_stream = nullptr;
@@ -242,6 +246,10 @@ struct Options {
     int shift = -1;          // row-aligned tile windows of odd-pitch point-major stores: -1 auto (fp64), 0 off, 2 always
     int debug = 0;           // PassArgs::debug of every launch (measurement only; results are wrong when set)
     int real_variant = 0;    // A/B configurations of the real z passes (DFFT_EXPERIMENTS builds)
+    int single_order = -1;   // single-rank complex plans: 1 = pass order z, x, y with padded private layouts, 0 = z, y, x,
+                             // -1 = by measurement: z, x, y where it won (fp32 with x and y lines of 2048 points or more)
+    int single_layout = 1;   // L2 of the z, x, y order: 0 = [kx][kz/TL][y][l], 1 = tile-outer [kz/TL][kx][y][l]
+    int single_pad = 128;    // bytes added to every L2 row (a row stride that is an odd multiple of 128 B; 0 = packed)
     int order[6] = {-1, -1, -1, -1, -1, -1};     // workgroup->tile order per pass: fz fy fx ix iy iz; a_fastest + 2*xcd_swizzle
     int variant[6] = {-1, -1, -1, -1, -1, -1};   // kernel configuration per pass, same order (-1 = the plan's choice)
 };
@@ -667,6 +675,64 @@ static int build_pipeline_yzx(dfft_plan *p, Pipeline &pl)
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// One rank, complex plan: input and output are both the natural [x][y][z] array, so the pass order is free (the
+// reference's fft3d branch is one cuFFT plan, src/pencil/mpicufft_pencil_opt1.cpp:132-135).  Order z, x, y:
+//   z pass   lines along z, 8 lines adjacent in x (rows a*AS_in + line*KS_in)  -> L1 = [y][kz/TL][x][kz%TL]   1 KiB runs
+//   x pass   chunk (y, kz tile) of L1                                          -> L2 = rows of 128 B, PADDED
+//   y pass   chunk (kx, kz tile) of L2                                         -> natural [kx][ky][kz]: a workgroup's
+//            1024 rows of 128 B lie 16 KiB apart inside ONE 16 MiB plane (the x-last order puts them 16 MiB apart)
+// L2 is private, so its row stride is made an odd multiple of 128 B (profiles/r2_placement_probe.txt: strided 128-byte
+// rows whose stride is a multiple of 256 B lose 6 % as a scatter and 15 % as a gather on this part).
+// The inverse runs the same launches with conjugation.
+// ------------------------------------------------------------------------------------------
+static int build_pipeline_single(dfft_plan *p, Pipeline &pl)
+{
+    const int TL = p->TL;
+    const size_t Nx = p->Nx, Ny = p->Ny, Nz = p->Nzc;
+    pl.single = false;
+    // measured (profiles/r2_single_order.txt): the y-last pass gains (2048^3 fp32: 34.7 -> 25.1 ms) but the z pass loses
+    // its contiguous 128 KiB read (8 lines from 8 x planes instead): 1024^3 fp64 38.0-38.8 vs 37.5 ms per step, fp32 21.4
+    // vs 20.1, 2048^3 fp32 181 vs 192 ms
+    const int order = p->opt.single_order >= 0 ? p->opt.single_order : (p->prec == DFFT_F32 && Nx >= 2048 && Ny >= 2048 ? 1 : 0);
+    if (p->nranks != 1 || !p->c2c || p->zyx || p->yzx || !order) return 0;
+    const size_t nb = (Nz + TL - 1) / TL;
+    const size_t pad = (size_t)std::max(0, p->opt.single_pad) / p->esz;      // elements
+    pl.sz = Launch(); pl.sx = Launch(); pl.sy = Launch();
+    {   // z pass
+        PassArgs Z = pass_args(TL, Ny, Nx, LOAD_LINES, STORE_TILED_TRANSPOSE, 0);
+        Z.KS_in = (uint64_t)Ny * Nz;      // line stride: the 8 lines of a tile are adjacent in x
+        Z.AS_in = Nz;                      // a = y
+        Z.a_fastest = 1;                   // neighbouring workgroups read neighbouring (contiguous) lines
+        pl.sz.args = Z;
+        seg_push(pl.sz.sseg, 0, Nz, 0);
+    }
+    uint64_t SK, SB;
+    if (p->opt.single_layout == 1) { SK = (uint64_t)TL * Ny + pad; SB = (uint64_t)Nx * SK + pad; pl.single_work_elems = nb * SB; }
+    else { SK = (uint64_t)Nz * Ny + pad; SB = (uint64_t)TL * Ny; pl.single_work_elems = Nx * SK; }
+    {   // x pass: L1 chunk (y, kz tile) -> L2
+        PassArgs X = pass_args(TL, Ny, Nz, LOAD_TILED, STORE_TILED_SAME, 0);
+        X.LA = (uint32_t)Ny; X.SK = SK; X.SB = SB;
+        X.a_fastest = 1; X.xcd_swizzle = 1;      // neighbouring workgroups (y, y+1) write neighbouring 128-byte columns
+        pl.sx.args = X;
+        seg_push(pl.sx.lseg, 0, Nx, 0);
+        seg_push(pl.sx.sseg, 0, Nx, 0);
+    }
+    {   // y pass: L2 chunk (kx, kz tile) -> natural output
+        PassArgs Y = pass_args(TL, Nx, Nz, LOAD_TILED, STORE_KMAJOR, 0);
+        Y.IA = SK; Y.IB = SB;
+        Y.KS_out = Nz; Y.AS_out = (uint64_t)Ny * Nz;
+        Y.a_fastest = 0; Y.xcd_swizzle = 1;      // neighbouring workgroups (kz tiles) write neighbouring 128-byte columns of a row
+        if (!p->ax[1].bluestein && p->prec == DFFT_F64 && p->opt.shift != 0 && Y.AS_out % TL != 0 && Y.KS_out % TL == 0 && Y.LB >= (uint32_t)TL) {
+            Y.shift = 1; Y.nb += 1; Y.ntiles = Y.na * Y.nb;      // odd row pitch: row-aligned tile windows (see set_shift)
+        }
+        pl.sy.args = Y;
+        seg_push(pl.sy.lseg, 0, Ny, 0);
+    }
+    pl.single = true;
+    return 0;
+}
+
 static void fill_tables(dfft_plan *p, const Launch &L, PassArgs &A)
 {
     A.lseg = reinterpret_cast<const SegTable *>(static_cast<const char *>(p->tables_d) + L.ltab);
@@ -787,10 +853,36 @@ static int enqueue_forward_zyx(dfft_plan *p, void *out, const void *in);
 static int enqueue_forward_yzx(dfft_plan *p, void *out, const void *in);
 static int enqueue_inverse_zyx(dfft_plan *p, void *out, void *in);
 
+// one rank, complex, pass order z, x, y (build_pipeline_single).  Forward and inverse are the same three launches,
+// the inverse with conjugation:   z: in -> out (L1)   x: out -> W (L2)   y: W -> out
+static int enqueue_single(dfft_plan *p, void *out, const void *in, int swap)
+{
+    Pipeline &pl = p->pl;
+    char *O = static_cast<char *>(out), *W = static_cast<char *>(p->work_d);
+    const char *I = static_cast<const char *>(in);
+    hipStream_t Sc = p->stream;
+    p->nspans = 0; p->last_dir = swap ? DFFT_INVERSE : DFFT_FORWARD;
+    auto run = [&](const Launch &L, int variant, int axis, const char *src, char *dst, int phase) -> int {
+        Launch M = L;
+        M.args.swap = swap;
+        TRY(span_begin(p, phase, Sc));
+        TRY(launch(p, M, variant, axis, src, dst));
+        TRY(span_end(p, Sc));
+        return 0;
+    };
+    // phase slots follow the axis (0 z, 2 y, 4 x in forward naming; mirrored for the inverse naming) so that the
+    // per-phase report keeps its labels
+    TRY(run(pl.sz, p->vfwd[0], 0, I, O, swap ? 4 : 0));
+    TRY(run(pl.sx, p->vfwd[2], 2, O, W, swap ? 0 : 4));
+    TRY(run(pl.sy, p->vfwd[1], 1, W, O, 2));
+    return 0;
+}
+
 static int enqueue_forward(dfft_plan *p, void *out, const void *in)
 {
     if (p->zyx) return enqueue_forward_zyx(p, out, in);
     if (p->yzx) return enqueue_forward_yzx(p, out, in);
+    if (p->pl.single && !p->opt.mirror) return enqueue_single(p, out, in, 0);
     Pipeline &pl = p->pl;
     const int C = pl.C;
     char *A = static_cast<char *>(out), *W = static_cast<char *>(p->work_d);
@@ -860,6 +952,7 @@ static int enqueue_inverse(dfft_plan *p, void *out, void *in)
 {
     if (p->zyx) return enqueue_inverse_zyx(p, out, in);
     if (p->yzx) return fail(ERR_UNSUPPORTED, "the Y_Then_ZX sequence is forward only (as in the reference)");
+    if (p->pl.single && !p->opt.mirror) return enqueue_single(p, out, in, 1);
     Pipeline &pl = p->pl;
     const int C = pl.C;
     char *I = static_cast<char *>(in), *W = static_cast<char *>(p->work_d), *O = static_cast<char *>(out);
@@ -1118,6 +1211,7 @@ static void env_defaults(Options &o)
     geti("DFFT_TABLES", o.tables);
     geti("DFFT_SHIFT", o.shift);
     geti("DFFT_MIRROR", o.mirror);
+    geti("DFFT_SINGLE_ORDER", o.single_order);
 }
 
 extern "C" {
@@ -1189,6 +1283,9 @@ static int *option_slot(Options &o, const std::string &k)
     if (k == "shift") return &o.shift;
     if (k == "debug_skip") return &o.debug;
     if (k == "real_variant") return &o.real_variant;
+    if (k == "single_order") return &o.single_order;
+    if (k == "single_layout") return &o.single_layout;
+    if (k == "single_pad") return &o.single_pad;
     for (int i = 0; i < 6; i++) {
         if (k == std::string("variant_") + kPassNames[i]) return &o.variant[i];
         if (k == std::string("order_") + kPassNames[i]) return &o.order[i];
@@ -1321,6 +1418,11 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         p->pl.C = C;
     }
     TRY(zyx ? build_pipeline_zyx(p, p->pl) : yzx ? build_pipeline_yzx(p, p->pl) : build_pipeline(p, p->pl));
+    TRY(build_pipeline_single(p, p->pl));
+    if (p->pl.single) {
+        const size_t need = (p->pl.single_work_elems * p->esz + 255) & ~(size_t)255;
+        p->worksize_d = std::max(p->worksize_d, need);      // the padded L2 buffer lives in the work area
+    }
     // kernel configuration per pass, by role (PassRole); lengths without a configuration for a role use the default
     {
         PassInfo vi;
@@ -1352,6 +1454,10 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
                 if (k == 2) set(pl.fx); else for (auto &L : *vecs[k]) set(L);
             }
             if (p->opt.variant[k] >= 0) (k < 3 ? p->vfwd[k] : p->vinv[5 - k]) = p->opt.variant[k];
+            if (d >= 0 && pl.single && k < 3) {      // the z, x, y order of a single rank: fz / fy / fx name its z / y / x passes
+                Launch &L = k == 0 ? pl.sz : k == 1 ? pl.sy : pl.sx;
+                L.args.a_fastest = d & 1; L.args.xcd_swizzle = (d >> 1) & 1;
+            }
         }
     }
     for (auto &a : p->ax) axis_free(a);
@@ -1380,7 +1486,7 @@ static void point_table(const Launch &L, bool store, std::vector<SegEntry> &tab)
         if (!store) {
             e.base = T.base[s]; e.aux = (uint32_t)d;
         } else if (A.store_kind == STORE_TILED_SAME) {
-            e.base = T.base[s] + d * A.LB * A.LA; e.aux = 0;
+            e.base = T.base[s] + d * (A.SK ? A.SK : (uint64_t)A.LB * A.LA); e.aux = 0;
         } else {
             const uint64_t T2 = 1ull << A.T2shift, kt = d >> A.T2shift, kr = d & (T2 - 1);
             const uint64_t r2 = ln - kt * T2;
@@ -1400,6 +1506,7 @@ static int upload_tables(dfft_plan *p)
     std::vector<Launch *> all;
     for (auto *v : {&pl.fz, &pl.fy, &pl.ix, &pl.iy, &pl.iz, &pl.py2, &pl.qy2, &pl.zy, &pl.ziy}) for (auto &L : *v) all.push_back(&L);
     all.push_back(&pl.fx); all.push_back(&pl.pz1); all.push_back(&pl.qz1); all.push_back(&pl.zix); all.push_back(&pl.yz);
+    if (pl.single) { all.push_back(&pl.sz); all.push_back(&pl.sx); all.push_back(&pl.sy); }
     std::vector<char> host(all.size() * 2 * sizeof(SegTable));
     size_t off = 0;
     for (Launch *L : all) {
@@ -1415,6 +1522,7 @@ static int upload_tables(dfft_plan *p)
             const bool want = side == 0 ? tl : ts;
             const int nseg = side == 0 ? L->lseg.nseg : L->sseg.nseg;
             if (!want || mode == 0 || (mode == 1 && nseg < 2) || L->args.ntiles == 0) continue;
+            if ((side == 0 && L->args.IA) || (side == 1 && L->args.SK)) continue;      // explicit strides: closed form only
             point_table(*L, side == 1, tab);
             (side == 0 ? L->lent : L->sent) = host.size();
             const size_t bytes = tab.size() * sizeof(SegEntry);
@@ -1648,6 +1756,9 @@ static const Launch *find_launch(const dfft_plan *p, const char *name, int index
     if (n == "fx") return &pl.fx;
     if (n == "zix") return p->zyx ? &pl.zix : nullptr;
     if (n == "yz") return p->yzx ? &pl.yz : nullptr;
+    if (n == "sz") return pl.single ? &pl.sz : nullptr;
+    if (n == "sx") return pl.single ? &pl.sx : nullptr;
+    if (n == "sy") return pl.single ? &pl.sy : nullptr;
     if (n == "pz1") return &pl.pz1;
     if (n == "qz1") return &pl.qz1;
     return nullptr;
@@ -1664,6 +1775,7 @@ int dfft_debug_get_pass(const dfft_plan *p, const char *name, int index, dfft_pa
     d->na = A.na; d->LB = A.LB; d->nb = A.nb; d->LA = A.LA; d->T2shift = A.T2shift;
     d->load_kind = A.load_kind; d->store_kind = A.store_kind; d->swap = A.swap; d->shift = A.shift;
     d->KS_in = A.KS_in; d->KS_out = A.KS_out; d->AS_in = A.AS_in; d->AS_out = A.AS_out;
+    d->IA = A.IA; d->IB = A.IB; d->SK = A.SK; d->SB = A.SB; d->a_fastest = A.a_fastest; d->xcd_swizzle = A.xcd_swizzle;
     d->in_off = L->in_off; d->out_off = L->out_off;
     d->lnseg = L->lseg.nseg; d->snseg = L->sseg.nseg;
     for (int s = 0; s < L->lseg.nseg; s++) { d->lstart[s] = L->lseg.start[s]; d->llen[s] = L->lseg.len[s]; d->lbase[s] = L->lseg.base[s]; }

@@ -33,7 +33,7 @@ namespace dfft {
 constexpr int MAXSEG = 32;   // max segments of a gathered/scattered axis (peers x pipeline chunks)
 
 enum LoadKind : int {
-    LOAD_LINES = 0,    // natural lines:        (a*LB + b*TL + l)*N + n
+    LOAD_LINES = 0,    // natural lines:        (a*LB + b*TL + l)*N + n, or (KS_in != 0) rows a*AS_in + (b*TL + l)*KS_in + n
     LOAD_TILED = 1,    // tiled, segmented by source peer: base[s] + a*len[s]*LB + b*TL*len[s] + (n-start[s])*tw + l
     LOAD_KMAJOR = 2    // point-major:          n*KS + a*AS + b*TL + l
 };
@@ -91,6 +91,10 @@ struct PassArgs {
     uint64_t KS_out;       // STORE_KMAJOR point stride
     uint64_t AS_in;        // LOAD_KMAJOR stride of the outer axis a (LB for the API output layout)
     uint64_t AS_out;       // STORE_KMAJOR stride of the outer axis a
+    // explicit strides of the private tiled layouts (0 = the packed defaults).  They let a plan pad rows so that
+    // consecutive rows of a workgroup's scatter differ by an odd multiple of 128 B (profiles/r2_placement_probe.txt)
+    uint64_t IA, IB;       // LOAD_TILED, one segment: stride of the outer axis a (default len*LB) and of a tile along b (TL*len)
+    uint64_t SK, SB;       // STORE_TILED_SAME: stride of a point k (default LB*LA) and of a tile along b (TL*LA)
     // segment tables live in device memory (plan-owned): dynamically indexed by-value kernel
     // arguments would be copied to scratch
     const SegTable *lseg, *sseg;
@@ -515,7 +519,9 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
     // ------------------------------------------------------------------ load
     if (active) {
         if (A.load_kind == LOAD_LINES) {
-            const C *p = in + ((uint64_t)a * A.LB + (uint64_t)b * TL + l) * N + t;
+            const uint64_t row = A.KS_in ? (uint64_t)a * A.AS_in + ((uint64_t)b * TL + l) * A.KS_in
+                                         : ((uint64_t)a * A.LB + (uint64_t)b * TL + l) * N;
+            const C *p = in + row + t;
             static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = stream_load<Cfg>(p + NT * c); });
         } else if (A.load_kind == LOAD_KMAJOR) {
             const C *p = in + (uint64_t)a * A.AS_in + (uint64_t)b * TL + l + (uint64_t)t * A.KS_in;
@@ -530,7 +536,8 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
                 });
             } else if (A.lnseg == 1) {
                 const uint64_t len = A.lseg->len[0];
-                const C *p = in + A.lseg->base[0] + (uint64_t)a * len * A.LB + (uint64_t)b * TL * len + l + (uint64_t)t * tw;
+                const uint64_t ia = A.IA ? A.IA : len * A.LB, ib = A.IB ? A.IB : (uint64_t)TL * len;
+                const C *p = in + A.lseg->base[0] + (uint64_t)a * ia + (uint64_t)b * ib + l + (uint64_t)t * tw;
                 static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = stream_load<Cfg>(p + (uint64_t)(NT * c) * tw); });
             } else {
                 static_for<0, E>([&](auto cc) {
@@ -585,7 +592,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
     } else if (A.stab) {
         const bool same = A.store_kind == STORE_TILED_SAME;
         const uint32_t line = b2 * TL + l2;
-        const uint64_t fixed = same ? (uint64_t)b2 * TL * A.LA + (uint64_t)a2 * tws + l2 : 0;
+        const uint64_t fixed = same ? (uint64_t)b2 * (A.SB ? A.SB : (uint64_t)TL * A.LA) + (uint64_t)a2 * tws + l2 : 0;
         const uint32_t aLB = a2 * A.LB;
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
@@ -606,7 +613,8 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
             const uint32_t kl = k - s0;
             uint64_t off;
             if (A.store_kind == STORE_TILED_SAME) {
-                off = bs + (uint64_t)kl * A.LB * A.LA + (uint64_t)b2 * TL * A.LA + (uint64_t)a2 * tws + l2;
+                const uint64_t sk = A.SK ? A.SK : (uint64_t)A.LB * A.LA, sb = A.SB ? A.SB : (uint64_t)TL * A.LA;
+                off = bs + (uint64_t)kl * sk + (uint64_t)b2 * sb + (uint64_t)a2 * tws + l2;
             } else {
                 const uint32_t T2 = 1u << A.T2shift;
                 const uint32_t kt = kl >> A.T2shift, kr = kl & (T2 - 1);
@@ -647,6 +655,7 @@ __device__ __forceinline__ uint64_t tiled_load_offset(const PassArgs &A, const T
     uint64_t bs = A.lseg->base[0];
     for (int s = 1; s < A.lnseg; s++)
         if (n >= A.lseg->start[s]) { s0 = A.lseg->start[s]; ln = A.lseg->len[s]; bs = A.lseg->base[s]; }
+    if (A.IA) return bs + (uint64_t)c.a * A.IA + (uint64_t)c.b * A.IB + (uint64_t)(n - s0) * c.tw + c.l;      // one segment, explicit strides
     return bs + (uint64_t)c.a * ln * A.LB + (uint64_t)c.b * TL * ln + (uint64_t)(n - s0) * c.tw + c.l;
 }
 template <int TL>
@@ -687,7 +696,8 @@ template <int TL> struct TransposeOne {
 template <int TL>
 __device__ __forceinline__ uint64_t generic_load_offset(const PassArgs &A, const TileCtx<TL> &c, uint32_t n, uint32_t NP)
 {
-    if (A.load_kind == LOAD_LINES) return ((uint64_t)c.a * A.LB + (uint64_t)c.b * TL + c.l) * NP + n;
+    if (A.load_kind == LOAD_LINES)
+        return (A.KS_in ? (uint64_t)c.a * A.AS_in + ((uint64_t)c.b * TL + c.l) * A.KS_in : ((uint64_t)c.a * A.LB + (uint64_t)c.b * TL + c.l) * NP) + n;
     if (A.load_kind == LOAD_KMAJOR) return (uint64_t)n * A.KS_in + (uint64_t)c.a * A.AS_in + (uint64_t)c.b * TL + c.l;
     return tiled_load_offset<TL>(A, c, n);
 }
@@ -699,13 +709,14 @@ __device__ __forceinline__ uint64_t generic_store_offset(const PassArgs &A, cons
                          : ((uint64_t)c.a * A.LB + (uint64_t)c.b * TL + c.l) * NP) + k;
     if (A.store_kind == STORE_KMAJOR) return (uint64_t)k * A.KS_out + (uint64_t)c.a * A.AS_out + (uint64_t)c.b * TL + c.l;
     if (A.store_kind == STORE_TILED_TRANSPOSE) return tiled_transpose_store_offset<TL>(A, c, k);
-    if (A.stab) return seg_entry(A.stab + k).base + (uint64_t)c.b * TL * A.LA + (uint64_t)c.a * c.tw + c.l;
+    const uint64_t sk = A.SK ? A.SK : (uint64_t)A.LB * A.LA, sb = A.SB ? A.SB : (uint64_t)TL * A.LA;
+    if (A.stab) return seg_entry(A.stab + k).base + (uint64_t)c.b * sb + (uint64_t)c.a * c.tw + c.l;
     uint32_t s0 = A.sseg->start[0], ln = A.sseg->len[0];
     uint64_t bs = A.sseg->base[0];
     for (int s = 1; s < A.snseg; s++)
         if (k >= A.sseg->start[s]) { s0 = A.sseg->start[s]; ln = A.sseg->len[s]; bs = A.sseg->base[s]; }
     (void)ln;
-    return bs + (uint64_t)(k - s0) * A.LB * A.LA + (uint64_t)c.b * TL * A.LA + (uint64_t)c.a * c.tw + c.l;
+    return bs + (uint64_t)(k - s0) * sk + (uint64_t)c.b * sb + (uint64_t)c.a * c.tw + c.l;
 }
 
 // tile of the calling lane for the real-transform kernels; lw = the lane's line within the workgroup in
@@ -894,7 +905,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
         } else {
             // one peer: the tile is one contiguous [point][line] block
             const uint64_t len = A.lseg->len[0];
-            const uint64_t base = A.lseg->base[0] + (uint64_t)tc.a * len * A.LB + (uint64_t)tc.b * TL * len + tc.l;
+            const uint64_t base = A.lseg->base[0] + (uint64_t)tc.a * (A.IA ? A.IA : len * A.LB) + (uint64_t)tc.b * (A.IB ? A.IB : (uint64_t)TL * len) + tc.l;
             const uint32_t s0 = A.lseg->start[0], tw = tc.tw;
             fetch([&](uint32_t k) { return base + (uint64_t)(k - s0) * tw; });
         }
@@ -1094,7 +1105,10 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_bluestein_kernel(const PassA
         });
     };
     const uint64_t rowline = (uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + tc.l;
-    if (A.load_kind == LOAD_LINES) {
+    if (A.load_kind == LOAD_LINES && A.KS_in) {          // strided natural-line rows
+        const uint64_t row = (uint64_t)tc.a * A.AS_in + ((uint64_t)tc.b * TL + tc.l) * A.KS_in;
+        load_all([&](uint32_t n, uint32_t) { return row + n; });
+    } else if (A.load_kind == LOAD_LINES) {
         load_all([&](uint32_t n, uint32_t NP) { return rowline * NP + n; });
     } else if (A.load_kind == LOAD_KMAJOR) {
         const uint64_t base = (uint64_t)tc.a * A.AS_in + (uint64_t)tc.b * TL + tc.l, ks = A.KS_in;
@@ -1103,7 +1117,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_bluestein_kernel(const PassA
         load_all([&](uint32_t n, uint32_t) { return tiled_load_offset<TL>(A, tc, n); });
     } else {
         const uint64_t len = A.lseg->len[0];
-        const uint64_t base = A.lseg->base[0] + (uint64_t)tc.a * len * A.LB + (uint64_t)tc.b * TL * len + tc.l;
+        const uint64_t base = A.lseg->base[0] + (uint64_t)tc.a * (A.IA ? A.IA : len * A.LB) + (uint64_t)tc.b * (A.IB ? A.IB : (uint64_t)TL * len) + tc.l;
         const uint32_t s0 = A.lseg->start[0], tw = tc.tw;
         load_all([&](uint32_t n, uint32_t) { return base + (uint64_t)(n - s0) * tw; });
     }
@@ -1153,8 +1167,8 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_bluestein_kernel(const PassA
         const TransposeOne<TL> one(A, tc);
         store_all([&](uint32_t k) { return one(k); });
     } else {
-        const uint64_t base = A.sseg->base[0] + (uint64_t)tc.b * TL * A.LA + (uint64_t)tc.a * tc.tw + tc.l;
-        const uint64_t step = (uint64_t)A.LB * A.LA;
+        const uint64_t base = A.sseg->base[0] + (uint64_t)tc.b * (A.SB ? A.SB : (uint64_t)TL * A.LA) + (uint64_t)tc.a * tc.tw + tc.l;
+        const uint64_t step = A.SK ? A.SK : (uint64_t)A.LB * A.LA;
         const uint32_t s0 = A.sseg->start[0];
         store_all([&](uint32_t k) { return base + (uint64_t)(k - s0) * step; });
     }

@@ -31,35 +31,14 @@ using F32_512_v5 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1, 0, 2>;
 using F32_2048_v4 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3, 1, 2>;
 using F32_2048_v5 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 2, 2>;
 using F32_2048_v6 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1>;
-#ifdef DFFT_EXPERIMENTS
-// A/B-only configurations (tools/kbench --opt variant_*=N); not part of the shipped library
-using F32_1024_v1 = PassCfg<float, 1024, 16, 16, 1, 16, 16, 4, 1, 1>;   // round-1 baseline
-using F32_512_v1 = PassCfg<float, 512, 32, 16, 1, 32, 4, 4, 1, 1, 1>;
-using F32_1024_v7 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 1>;   // two passes, point-fastest forms
-using F32_1024_v8 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 2>;
-using F32_1024_v9 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 0, 2>;  // sub-tiles (8 lines, 256 threads)
-// nontemporal forms: 10 = two-pass line-fastest (tiled passes), loads and stores; 11 stores only; 12 loads only;
-// 13 = point-fastest two-pass (natural-line passes), loads and stores
-using F32_1024_v10 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 3>;
-using F32_1024_v11 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 2>;
-using F32_1024_v12 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 1>;
-using F32_1024_v13 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 3, 1>;
-// 2048: 1 = three-pass chain on sub-tiles, 2 = point-fastest three-pass on sub-tiles, 3 = two-pass on sub-tiles (line
-// fastest), 7 = variant 4 without nontemporal hints, 8 / 9 = whole-tile point-fastest forms, 10 / 11 nontemporal tiled
-using F32_2048_v1 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 0, 2>;
-using F32_2048_v2 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 1, 2>;
-using F32_2048_v3 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 0, 2>;
-using F32_2048_v7 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 1, 2>;
-using F32_2048_v8 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 1>;
-using F32_2048_v9 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 2>;
-using F32_2048_v10 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3>;
-using F32_2048_v11 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3>;
-#endif
+// A/B-only configurations of earlier measurements (sub-tile workgroups on tiled passes, nontemporal loads-only / stores-only,
+// whole-tile 64-point forms, 32-point fp64 2048, ...) were removed after they were measured: results in profiles/r2_*.txt and
+// DESIGN.md section 6, definitions in the git history (commit c38cf04).  New ones go here, under -DDFFT_EXPERIMENTS:
 
 #ifdef DFFT_EXPERIMENTS
-#define DFFT_F32_EXP_SMALL(X) X(512, 1, F32_512_v1)
-#define DFFT_F32_EXP_1024(X) X(1024, 10, F32_1024_v10) X(1024, 11, F32_1024_v11) X(1024, 12, F32_1024_v12) X(1024, 13, F32_1024_v13) X(1024, 1, F32_1024_v1) X(1024, 7, F32_1024_v7) X(1024, 8, F32_1024_v8) X(1024, 9, F32_1024_v9)
-#define DFFT_F32_EXP_2048(X) X(2048, 1, F32_2048_v1) X(2048, 2, F32_2048_v2) X(2048, 3, F32_2048_v3) X(2048, 7, F32_2048_v7) X(2048, 8, F32_2048_v8) X(2048, 9, F32_2048_v9) X(2048, 10, F32_2048_v10) X(2048, 11, F32_2048_v11)
+#define DFFT_F32_EXP_SMALL(X)
+#define DFFT_F32_EXP_1024(X)
+#define DFFT_F32_EXP_2048(X)
 #else
 #define DFFT_F32_EXP_SMALL(X)
 #define DFFT_F32_EXP_1024(X)
@@ -113,28 +92,8 @@ using F32_R512_pf1 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1, 0, 1>;
 using F32_R512_pf2 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1, 0, 2>;
 using F32_R1024_pf1 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 1>;
 using F32_R1024_pf2 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 2>;
-#ifdef DFFT_EXPERIMENTS
-// A/B variants of the real z passes (option real_variant): 1 = three-pass configuration, two-plane split (the
-// round-1 baseline); 2 = three-pass configuration, one-plane split; 3 = two-pass line-fastest (round-1 final)
-static int launch_real_variant_f32(int M, int mode, int variant, const PassArgs &A, hipStream_t stream)
-{
-    if (M == 512 && variant == 1) return mode == 1 ? launch_real_cfg<F32_512, 1>(A, stream) : launch_real_cfg<F32_512, 2>(A, stream);
-    if (M == 512 && variant == 2) return mode == 1 ? launch_real_cfg<F32_512, 1, 1>(A, stream) : launch_real_cfg<F32_512, 2>(A, stream);
-    if (M == 512 && variant == 3) return mode == 1 ? launch_real_cfg<F32_R512_32, 1, 1>(A, stream) : launch_real_cfg<F32_R512_32, 2>(A, stream);
-    if (M == 1024 && variant == 1) return mode == 1 ? launch_real_cfg<F32_1024, 1>(A, stream) : launch_real_cfg<F32_1024, 2>(A, stream);
-    if (M == 1024 && variant == 2) return mode == 1 ? launch_real_cfg<F32_1024, 1, 1>(A, stream) : launch_real_cfg<F32_1024, 2>(A, stream);
-    if (M == 1024 && variant == 3) return mode == 1 ? launch_real_cfg<F32_1024_v6, 1, 1>(A, stream) : launch_real_cfg<F32_1024_v6, 2>(A, stream);
-    return -2;
-}
-#endif
 int launch_real_f32(int M, int mode, int variant, const PassArgs &A, hipStream_t stream)
 {
-#ifdef DFFT_EXPERIMENTS
-    if (variant > 0) {
-        const int r = launch_real_variant_f32(M, mode, variant, A, stream);
-        if (r != -2) return r;
-    }
-#endif
     (void)variant;
     if (mode == 1 && A.load_kind == LOAD_KMAJOR) {
         // strided real lines (Y_Then_ZX): the lanes run along the contiguous axis, i.e. the line-fastest mapping

@@ -32,25 +32,14 @@ using F64_512_v1 = PassCfg<double, 512, 32, 8, 2, 32, 16, 1, 1, 1, 1>;
 using F64_512_v3 = PassCfg<double, 512, 16, 8, 1, 8, 8, 8, 1, 1, 0, 3>;
 using F64_2048_v3 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 3>;
 using F64_2048_v7 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 3, 0, 2>;
-#ifdef DFFT_EXPERIMENTS
-// A/B-only configurations (tools/kbench --opt variant_*=N); not part of the shipped library
-using F64_1024_v2 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 0>;                 // table-loaded twiddles (round-1 baseline)
-using F64_1024_v4 = PassCfg<double, 1024, 32, 8, 1, 32, 32, 1, 1, 1, 1>;                 // two radix-32 passes on 8 lines
-using F64_1024_v5 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 0, 0, 2>;        // sub-tile workgroups (4 lines)
-using F64_1024_v6 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 3, 0, 2>;        // ... nontemporal
-using F64_1024_v8 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 1>;              // nontemporal loads only
-using F64_1024_v9 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 2>;              // nontemporal stores only
-using F64_1024_v10 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1>;                // strided read, no nontemporal hints
-using F64_1024_v11 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 2>;             // strided read, nontemporal stores only
-using F64_2048_v2 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1>;                 // 32 points per thread, 32.32.2
-using F64_2048_v4 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 0, 0, 2>;        // ... sub-tiles
-using F64_2048_v5 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 0, 0, 2>;        // sub-tiles without nontemporal hints
-#endif
+// A/B-only configurations of earlier measurements (sub-tile workgroups on tiled passes, nontemporal loads-only / stores-only,
+// whole-tile 64-point forms, 32-point fp64 2048, ...) were removed after they were measured: results in profiles/r2_*.txt and
+// DESIGN.md section 6, definitions in the git history (commit c38cf04).  New ones go here, under -DDFFT_EXPERIMENTS:
 
 #ifdef DFFT_EXPERIMENTS
 #define DFFT_F64_EXP_SMALL(X)
-#define DFFT_F64_EXP_1024(X) X(1024, 2, F64_1024_v2) X(1024, 4, F64_1024_v4) X(1024, 5, F64_1024_v5) X(1024, 6, F64_1024_v6) X(1024, 8, F64_1024_v8) X(1024, 9, F64_1024_v9) X(1024, 10, F64_1024_v10) X(1024, 11, F64_1024_v11)
-#define DFFT_F64_EXP_2048(X) X(2048, 2, F64_2048_v2) X(2048, 4, F64_2048_v4) X(2048, 5, F64_2048_v5)
+#define DFFT_F64_EXP_1024(X)
+#define DFFT_F64_EXP_2048(X)
 #else
 #define DFFT_F64_EXP_SMALL(X)
 #define DFFT_F64_EXP_1024(X)
@@ -85,27 +74,8 @@ using F64_R512 = PassCfg<double, 512, 8, 8, 1, 8, 8, 8, 1, 1>;
 #define DFFT_F64_BASE(X) X(2, 0, F64_2) X(4, 0, F64_4) X(8, 0, F64_8) X(16, 0, F64_16) X(32, 0, F64_32) X(64, 0, F64_64) \
     X(128, 0, F64_128) X(256, 0, F64_256) X(512, 0, F64_R512) X(1024, 0, F64_1024)
 #if DFFT_SLICE == 3
-#ifdef DFFT_EXPERIMENTS
-// A/B variants of the real z passes (option real_variant): 1 = one-plane split, same configuration;
-// 2 = one-plane split with 16 points per thread x 16 lines (twice the bytes in flight per workgroup)
-using F64_R512_16 = PassCfg<double, 512, 16, 8, 2, 8, 8, 8, 1, 1>;
-static int launch_real_variant_f64(int M, int mode, int variant, const PassArgs &A, hipStream_t stream)
-{
-    if (M == 512 && variant == 1) return mode == 1 ? launch_real_cfg<F64_R512, 1, 1>(A, stream) : launch_real_cfg<F64_R512, 2>(A, stream);
-    if (M == 512 && variant == 2) return mode == 1 ? launch_real_cfg<F64_R512_16, 1, 1>(A, stream) : launch_real_cfg<F64_R512_16, 2>(A, stream);
-    if (M == 512 && variant == 3) return mode == 1 ? launch_real_cfg<F64_512, 1, 1>(A, stream) : launch_real_cfg<F64_512, 2>(A, stream);
-    if (M == 1024 && variant == 1) return mode == 1 ? launch_real_cfg<F64_1024, 1, 1>(A, stream) : launch_real_cfg<F64_1024, 2>(A, stream);
-    return -2;
-}
-#endif
 int launch_real_f64(int M, int mode, int variant, const PassArgs &A, hipStream_t stream)
 {
-#ifdef DFFT_EXPERIMENTS
-    if (variant > 0) {
-        const int r = launch_real_variant_f64(M, mode, variant, A, stream);
-        if (r != -2) return r;
-    }
-#endif
     (void)variant;
     switch (M) {
 #define X(n, v, cfg) case n: return mode == 1 ? launch_real_cfg<cfg, 1>(A, stream) : launch_real_cfg<cfg, 2>(A, stream);

@@ -128,6 +128,9 @@ int dfft_get_pipeline_chunks(const dfft_plan *plan);
  *                      env default DFFT_MIRROR)
  *   "point_tables"     per-point address tables: 0 never, 1 segmented sides (default), 2 always (DFFT_TABLES)
  *   "shift"            row-aligned tile windows for odd-pitch output rows: -1 auto, 0 off, 2 always (DFFT_SHIFT)
+ *   "single_order"     one rank, complex plan: 1 = pass order z, x, y through a padded private layout, 0 = z, y, x, -1 (default)
+ *                      = where it measured faster (env default DFFT_SINGLE_ORDER); "single_layout" (0 | 1) and "single_pad"
+ *                      (bytes) shape that layout
  *   "debug_skip"       measurement only: 1 = every pass skips its transform and becomes a copy with the same
  *                      access pattern (results are wrong); used to measure the pattern's own roofline
  *   "variant_<pass>", "order_<pass>", "real_variant"   kernel configuration / workgroup order per pass
@@ -225,7 +228,10 @@ typedef struct dfft_pass_desc {
     int32_t load_kind;      /* 0 natural lines, 1 tiled (segments), 2 point-major (KS_in, AS_in) */
     int32_t store_kind;     /* 0 lines (row strides if KS_out != 0), 1 point-major, 2 tiled-same, 3 tiled-transpose */
     int32_t swap, shift;
-    uint64_t KS_in, KS_out, AS_in, AS_out;
+    uint64_t KS_in, KS_out, AS_in, AS_out;      /* load_kind 0 with KS_in != 0: rows a*AS_in + line*KS_in (strided natural lines) */
+    uint64_t IA, IB;        /* tiled load, one segment: explicit strides of a and of a tile along b (0 = packed) */
+    uint64_t SK, SB;        /* tiled-same store: explicit strides of a point k and of a tile along b (0 = packed) */
+    int32_t a_fastest, xcd_swizzle;
     uint64_t in_off, out_off;
     int32_t lnseg, snseg;
     uint32_t lstart[32], llen[32];
@@ -234,7 +240,7 @@ typedef struct dfft_pass_desc {
     uint64_t sbase[32];
 } dfft_pass_desc;
 /* name: "fz" "fy" "ix" "iy" "iz" "py2" "qy2" "zy" "ziy" (index = chunk, or chunk*P + peer for zy/ziy)
- * and "fx" "zix" "yz" "pz1" "qz1" (index 0).  Returns nonzero if the plan has no such launch. */
+ * and "fx" "zix" "yz" "pz1" "qz1" "sz" "sx" "sy" (index 0; the last three: single-rank complex plans, order z, x, y).  Returns nonzero if the plan has no such launch. */
 int dfft_debug_get_pass(const dfft_plan *plan, const char *name, int index, dfft_pass_desc *desc);
 /* the per-point address table the kernels use for a segmented side of that launch (store = 0: load
  * side, 1: store side); entry i = {base[i], ln[i], aux[i]} as documented for SegEntry.  *count receives

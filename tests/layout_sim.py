@@ -51,10 +51,13 @@ class Pass:
         d, TL = self.d, self.TL
         b, l, tw = self.tile(line)
         if d.load_kind == LINES:
-            return (a * d.LB + line) * NP + n
+            return (a * d.AS_in + line * d.KS_in if d.KS_in else (a * d.LB + line) * NP) + n
         if d.load_kind == KMAJOR:
             return n * d.KS_in + a * d.AS_in + line
         s0, ln, bs = _seg(*self.l, n)
+        if d.IA:                                   # one segment with explicit (padded) strides: closed form only
+            assert d.lnseg == 1
+            return bs + a * d.IA + b * d.IB + (n - s0) * tw + l
         off = bs + a * ln * d.LB + b * TL * ln + (n - s0) * tw + l
         base, tln, aux = self.ltab[n]            # the per-point table must say the same
         assert off == base + tln * (a * d.LB + b * TL) + aux * tw + l
@@ -70,8 +73,9 @@ class Pass:
         s0, ln, bs = _seg(*self.s, k)
         base, tln, aux = self.stab[k]
         if d.store_kind == S_SAME:
-            off = bs + (k - s0) * d.LB * d.LA + b * TL * d.LA + a * tw + l
-            assert off == base + b * TL * d.LA + a * tw + l
+            sk, sb = (d.SK or d.LB * d.LA), (d.SB or TL * d.LA)
+            off = bs + (k - s0) * sk + b * sb + a * tw + l
+            assert off == base + b * sb + a * tw + l
             return off
         T2 = 1 << d.T2shift
         kt, kr = (k - s0) >> d.T2shift, (k - s0) & (T2 - 1)
@@ -104,7 +108,7 @@ class Pass:
 class World:
     """P virtual ranks of one plan class on a small fp64 grid"""
 
-    def __init__(self, cls, shape, P1, P2, c2c, chunks=None, precision="double"):
+    def __init__(self, cls, shape, P1, P2, c2c, chunks=None, precision="double", options=None):
         self.shape, self.P1, self.P2, self.c2c = shape, P1, P2, c2c
         self.esz = ESZ[precision]
         self.P = P1 * P2
@@ -114,13 +118,18 @@ class World:
             pl = cls(dfft.Configurations(), comm, precision=precision, rank=r)
             if chunks is not None:
                 pl.setPipelineChunks(chunks)
+            for k, v in (options or {}).items():
+                pl.setOption(k, v)
             pl.initFFT(dfft.GlobalSize(*shape), dfft.Partition(P1, P2), allocate=False, c2c=c2c)
             self.plans.append(pl)
         self.C = self.plans[0].getPipelineChunks()
         self.nel = [pl.getDomainSize() // self.esz for pl in self.plans]
+        # a work-area slice may be larger than the domain (padded private layouts of the single-rank z, x, y order)
+        self.wel = [max(pl.getDomainSize(), pl.getWorkSizeDevice() // max(1, (self.P1 > 1) + (self.P2 > 1) + 1)) // self.esz for pl in self.plans]
+        self.single = self.P == 1 and self.plans[0].debugPass("sz") is not None
 
     def buffers(self, n=3):
-        return [[np.full(self.nel[r], np.nan + 0j, dtype=np.complex128) for _ in range(n)] for r in range(self.P)]
+        return [[np.full(self.wel[r], np.nan + 0j, dtype=np.complex128) for _ in range(n)] for r in range(self.P)]
 
     def group(self, r, which):
         i, j = divmod(r, self.P2)
@@ -145,6 +154,13 @@ class World:
         outs = [np.full(n, np.nan + 0j, dtype=np.complex128) for n in self.nel]
         W = self.buffers()
         zmode = "c2c" if self.c2c else "r2c"
+        if kind == "default" and self.single:
+            # one rank, complex: pass order z, x, y through L1 (out) and the padded L2 (work), enqueue_single
+            pl = pls[0]
+            Pass(pl, "sz").run(ins[0], outs[0], Nz)
+            Pass(pl, "sx").run(outs[0], W[0][0], Nx)
+            Pass(pl, "sy").run(W[0][0], outs[0], Ny)
+            return outs
         if kind == "default":
             ysrc = [W[r][0] if P2 > 1 else outs[r] for r in range(self.P)]
             nxt = 1 if P2 > 1 else 0
@@ -200,6 +216,13 @@ class World:
         nin = [int(np.prod(pl.getInSize())) for pl in pls]
         outs = [np.full(n, np.nan, dtype=np.complex128 if self.c2c else np.float64) for n in nin]
         W = self.buffers(2)
+        if kind == "default" and self.single:
+            pl = pls[0]
+            for name, src, dst, N in (("sz", spec[0], outs[0], Nz), ("sx", outs[0], W[0][0], Nx), ("sy", W[0][0], outs[0], Ny)):
+                p = Pass(pl, name)
+                p.d.swap = 1
+                p.run(src, dst, N)
+            return outs
         if kind == "default" and self.P == 1 and self.c2c:
             # single rank, complex: forward pass order with conjugation (enqueue_inverse fast path)
             pl = pls[0]

@@ -125,3 +125,27 @@ def test_many_ranks_max_segments_and_fp32_tiles(cls, kind, shape, P1, P2, chunks
     outs = w.forward(ins, kind)
     check_spectrum(w, outs, np.fft.fftn(g) if c2c else np.fft.rfftn(g))
     check_round_trip(w, w.inverse(outs, kind), ins)
+
+
+@pytest.mark.parametrize("prec", ["double", "float"])
+@pytest.mark.parametrize("options", [{"single_order": 1}, {"single_order": 1, "single_layout": 0}, {"single_order": 1, "single_pad": 0},
+                                     {"single_order": 1, "single_layout": 0, "single_pad": 384}, {"single_order": 0}, {}])
+@pytest.mark.parametrize("shape", [(16, 8, 32), (6, 5, 9), (24, 16, 20), (9, 16, 33)])
+def test_single_rank_complex_orders_and_padded_layouts(shape, options, prec):
+    """one rank, complex: the z, x, y order (strided natural-line rows -> L1 -> padded L2 -> natural) in both L2 layouts
+    and with different row paddings, and the z, y, x order it replaces; forward == fftn, inverse round trip"""
+    w = World(dfft.MPIcuFFT_Pencil_Opt1, shape, 1, 1, True, precision=prec, options=options)
+    assert w.single == (options.get("single_order", 0) == 1)
+    if w.single:
+        d = w.plans[0].debugPass("sx")
+        esz = 16 if prec == "double" else 8
+        pad = options.get("single_pad", 128) // esz
+        TL = w.plans[0].getTileLines()
+        row = (TL * shape[1] if options.get("single_layout", 1) == 1 else shape[2] * shape[1]) + pad
+        assert d.SK == row and w.plans[0].debugPass("sy").IA == row
+        assert w.plans[0].getWorkSizeDevice() >= w.plans[0].getDomainSize()
+    g = global_field(shape, True)
+    ins = local_inputs(w, g)
+    outs = w.forward(ins)
+    check_spectrum(w, outs, np.fft.fftn(g))
+    check_round_trip(w, w.inverse(outs), ins)

@@ -102,14 +102,23 @@ static int sweep(int reps)
         {"rows 16 MiB apart (x pass, API layout)", 16 * M, 16384, 128},
         {"rows 16 MiB + 128 B", 16 * M + 128, 16384, 128},
         {"rows 16 MiB + 256 B", 16 * M + 256, 16384, 128},
+        {"rows 16 MiB + 384 B", 16 * M + 384, 16384, 128},
+        {"rows 16 MiB + 640 B", 16 * M + 640, 16384, 128},
         {"rows 16 MiB + 1 KiB", 16 * M + 1024, 16384, 128},
+        {"rows 16 MiB + 1 KiB + 128 B", 16 * M + 1152, 16384, 128},
+        {"rows 16 MiB + 2 KiB + 128 B", 16 * M + 2176, 16384, 128},
         {"rows 16 MiB + 4 KiB", 16 * M + 4096, 16384, 128},
+        {"rows 16 MiB + 4 KiB + 128 B", 16 * M + 4224, 16384, 128},
         {"rows 16 MiB + 16 KiB", 16 * M + 16384, 16384, 128},
+        {"rows 16 MiB + 16 KiB + 128 B", 16 * M + 16512, 16384, 128},
         {"rows 16 MiB + 64 KiB", 16 * M + 65536, 16384, 128},
+        {"rows 16 MiB + 64 KiB + 128 B", 16 * M + 65664, 16384, 128},
         {"rows 16 MiB + 1 MiB", 17 * M, 16384, 128},
         {"rows 16 MiB + 2 MiB + 4 KiB", 18 * M + 4096, 16384, 128},
         {"rows 16 KiB apart inside 16 MiB planes (y last)", 16384, 16 * M, 128},
+        {"rows 16 KiB + 128 B apart inside 16 MiB + 128 KiB planes", 16384 + 128, 16 * M + 131072, 128},
         {"rows 128 KiB apart, planes of 128 MiB (tile-outer)", 131072, 128 * M, 1024},
+        {"rows 128 KiB + 128 B apart, planes of 128 MiB + 128 KiB", 131072 + 128, 128 * M + 131072, 1024},
         {"rows 1 MiB apart, planes of 1 GiB", M, 1024 * M, 8192},
     };
     printf("%-52s %10s %10s %10s %10s   (ms for 16 GiB each way)\n", "strided side", "scatter", "scatter-nt", "gather", "gather-nt");
