@@ -103,9 +103,29 @@ struct PassArgs {
 };
 
 // ------------------------------------------------------------------------------------------
+// complex number = native 2-vector.  For fp32 that is the point: a <2 x float> lives in an aligned register pair and its
+// arithmetic selects the packed instructions of CDNA3/4 (v_pk_add_f32, v_pk_mul_f32, v_pk_fma_f32 with op_sel doing the
+// re/im broadcasts and swaps): a complex add is one instruction, a complex multiplication two.  (The SLP vectorizer tried
+// to find these pairs in scalar code and paid more in register shuffles than it gained; it is switched off, see Makefile.)
+typedef float cfloat_t __attribute__((ext_vector_type(2)));
+typedef double cdouble_t __attribute__((ext_vector_type(2)));
 template <typename R> struct Vec2;
-template <> struct Vec2<double> { using type = double2; };
-template <> struct Vec2<float> { using type = float2; };
+template <> struct Vec2<double> { using type = cdouble_t; };
+template <> struct Vec2<float> { using type = cfloat_t; };
+template <typename C> struct ScalarOf;
+template <> struct ScalarOf<cfloat_t> { using type = float; };
+template <> struct ScalarOf<cdouble_t> { using type = double; };
+template <typename C> using scalar_t = typename ScalarOf<C>::type;
+template <typename C> __device__ __forceinline__ C cswap(C d) { return __builtin_shufflevector(d, d, 1, 0); }      // (im, re)
+template <typename C> __device__ __forceinline__ C cmake(scalar_t<C> re, scalar_t<C> im) { C r; r.x = re; r.y = im; return r; }
+// x * w for a twiddle w given as the pair (w, iw) with iw = i*w = (-w.y, w.x): x.xx * w + x.yy * iw -- two packed
+// instructions at fp32.  Keeping iw next to w (instead of building it per multiplication) is what makes it two.
+template <typename C> __device__ __forceinline__ C cmul2(C x, C w, C iw)
+{
+    const C xx = __builtin_shufflevector(x, x, 0, 0), yy = __builtin_shufflevector(x, x, 1, 1);
+    return xx * w + yy * iw;
+}
+template <typename C> __device__ __forceinline__ C ci(C w) { C r; r.x = -w.y; r.y = w.x; return r; }            // i * w
 
 template <int I, int N, typename F> __device__ __forceinline__ void static_for(F &&f)
 {
@@ -150,24 +170,22 @@ constexpr double cos64(int j)
 }
 constexpr double sin64(int j) { return cos64((j + 48) & 63); }   // sin(x) = cos(x - pi/2)
 
-// multiply by exp(-2*pi*i*J/R) (forward kernel), compile-time J, trivial cases folded
+// multiply by exp(-2*pi*i*J/R) (forward kernel), compile-time J, trivial cases folded.  Vector form: with sw = (d.y, d.x),
+// d * (c - i s) = d * c + sw * (s, -s)
 template <int R, int J, typename C> __device__ __forceinline__ C mul_w(C d)
 {
-    using T = decltype(d.x);
+    using T = scalar_t<C>;
     static_assert(R <= 64, "radix-R butterflies up to 64");
     constexpr int j64 = (J * (64 / R)) & 63;
     if constexpr (j64 == 0) return d;
     else if constexpr (j64 == 16) { C r; r.x = d.y; r.y = -d.x; return r; }           // * -i
-    else if constexpr (j64 == 32) { C r; r.x = -d.x; r.y = -d.y; return r; }
+    else if constexpr (j64 == 32) return -d;
     else if constexpr (j64 == 48) { C r; r.x = -d.y; r.y = d.x; return r; }          // * +i
-    else if constexpr (j64 == 8) { constexpr T s = (T)0.70710678118654752440; C r; r.x = (d.x + d.y) * s; r.y = (d.y - d.x) * s; return r; }
-    else if constexpr (j64 == 24) { constexpr T s = (T)0.70710678118654752440; C r; r.x = (d.y - d.x) * s; r.y = -(d.x + d.y) * s; return r; }
+    else if constexpr (j64 == 8) { constexpr T s = (T)0.70710678118654752440; return (d + cswap(d) * cmake<C>((T)1, (T)-1)) * s; }     // (x+y, y-x) s
+    else if constexpr (j64 == 24) { constexpr T s = (T)0.70710678118654752440; return (cswap(d) * cmake<C>((T)1, (T)-1) - d) * s; }   // (y-x, -x-y) s
     else {
         constexpr T c = (T)cos64(j64), s = (T)sin64(j64);   // w = c - i s
-        C r;
-        r.x = d.x * c + d.y * s;
-        r.y = d.y * c - d.x * s;
-        return r;
+        return d * c + cswap(d) * cmake<C>(s, -s);
     }
 }
 
@@ -180,12 +198,9 @@ template <int R, int OFF, int STRIDE, typename C> struct Dif {
             constexpr int H = R / 2;
             static_for<0, H>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                C a = v[OFF + j * STRIDE], b = v[OFF + (j + H) * STRIDE];
-                C s, d;
-                s.x = a.x + b.x; s.y = a.y + b.y;
-                d.x = a.x - b.x; d.y = a.y - b.y;
-                v[OFF + j * STRIDE] = s;
-                v[OFF + (j + H) * STRIDE] = mul_w<R, j>(d);
+                const C a = v[OFF + j * STRIDE], b = v[OFF + (j + H) * STRIDE];
+                v[OFF + j * STRIDE] = a + b;
+                v[OFF + (j + H) * STRIDE] = mul_w<R, j>(a - b);
             });
             Dif<H, OFF, STRIDE, C>::run(v);
             Dif<H, OFF + H * STRIDE, STRIDE, C>::run(v);
@@ -256,18 +271,19 @@ __device__ __forceinline__ void pass_compute(typename Cfg::C *v, int t, const ty
             const int k = j & (NS - 1);
             constexpr int step = N / (NS * RP);
             if constexpr (Cfg::kTWCHAIN) {
-                const C w1 = W[k * step];
-                C cur = w1;
+                // w^m by successive multiplication; (cur, icur) advance together (i*cur obeys the same recurrence), so
+                // every product below is the two-instruction form
+                const C w1 = W[k * step], iw1 = ci(w1);
+                C cur = w1, icur = iw1;
                 static_for<1, RP>([&](auto mc) {
                     constexpr int m = decltype(mc)::value;
-                    C x = v[i + m * S], r;
-                    r.x = x.x * cur.x - x.y * cur.y;
-                    r.y = x.x * cur.y + x.y * cur.x;
-                    v[i + m * S] = r;
+                    v[i + m * S] = cmul2(v[i + m * S], cur, icur);
                     if constexpr (m + 1 < RP) {
-                        C nx;
-                        nx.x = cur.x * w1.x - cur.y * w1.y;
-                        nx.y = cur.x * w1.y + cur.y * w1.x;
+                        const C nx = cmul2(cur, w1, iw1);
+                        // fp32: advance i*cur by its own packed product (2 instructions); fp64 has no packed arithmetic and
+                        // the negation of ci() folds into the next multiplication's source modifiers
+                        if constexpr (std::is_same<scalar_t<C>, float>::value) icur = cmul2(icur, w1, iw1);
+                        else icur = ci(nx);
                         cur = nx;
                     }
                 });
@@ -275,10 +291,7 @@ __device__ __forceinline__ void pass_compute(typename Cfg::C *v, int t, const ty
                 static_for<1, RP>([&](auto mc) {
                     constexpr int m = decltype(mc)::value;
                     const C w = W[(m * k) * step];
-                    C x = v[i + m * S], r;
-                    r.x = x.x * w.x - x.y * w.y;
-                    r.y = x.x * w.y + x.y * w.x;
-                    v[i + m * S] = r;
+                    v[i + m * S] = cmul2(v[i + m * S], w, ci(w));
                 });
             }
         }
@@ -440,7 +453,7 @@ template <bool ALWAYS = false> __device__ __forceinline__ uint32_t logical_block
 template <typename Cfg, typename C> __device__ __forceinline__ C stream_load(const C *p)
 {
     if constexpr (Cfg::kNTMEM & 1) {
-        using T = decltype(C::x);
+        using T = scalar_t<C>;
         typedef T native2 __attribute__((ext_vector_type(2)));
         const native2 r = __builtin_nontemporal_load(reinterpret_cast<const native2 *>(p));
         C v; v.x = r.x; v.y = r.y;
@@ -450,7 +463,7 @@ template <typename Cfg, typename C> __device__ __forceinline__ C stream_load(con
 template <typename Cfg, typename C> __device__ __forceinline__ void stream_store(C *p, C v)
 {
     if constexpr (Cfg::kNTMEM & 2) {
-        using T = decltype(C::x);
+        using T = scalar_t<C>;
         typedef T native2 __attribute__((ext_vector_type(2)));
         native2 r; r.x = v.x; r.y = v.y;
         __builtin_nontemporal_store(r, reinterpret_cast<native2 *>(p));
