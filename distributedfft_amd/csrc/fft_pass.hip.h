@@ -257,8 +257,41 @@ template <typename Cfg> __device__ __forceinline__ int lds_pad(int idx)
     return idx + ((idx >> Cfg::PS) << Cfg::PWS);
 }
 
-// twiddle + butterflies of one Stockham pass: radix RP, previous sub-transform length NS
-template <typename Cfg, int RP, int NS>
+// value-level choice between two registers.  Written naively, `cond ? v[a] : v[b]` on a register array becomes a select
+// of POINTERS into the array, which keeps the whole array out of registers (scratch); passing both candidates through an
+// empty asm makes them values first.
+template <typename C> __device__ __forceinline__ C pick(bool cond, C a, C b)
+{
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(b.x), "+v"(b.y));
+    C r;
+    r.x = cond ? a.x : b.x;
+    r.y = cond ? a.y : b.y;
+    return r;
+}
+
+// Conjugate-pair assignment of the N/RP butterflies of a pass (real transforms): register block i < S/2 of thread t is
+// butterfly jA = t + NT*i as usual, block i + S/2 is its mirror N/RP - jA, so that points k and N - k -- which the
+// Hermitian split / merge of a packed real transform combines -- live in ONE thread and no extra trip through LDS is
+// needed.  Butterfly 0 is its own mirror; its slot in thread 0 takes the other self-mirrored butterfly N/(2 RP).
+template <typename Cfg, int RP, int I> __device__ __forceinline__ int pair_j(int t)
+{
+    constexpr int S = Cfg::kE / RP, H = S / 2, NB = Cfg::kN / RP;
+    static_assert(S % 2 == 0, "conjugate-pair assignment needs an even number of butterflies per thread");
+    if constexpr (I < H) return t + Cfg::NT * I;
+    else {
+        const int ja = t + Cfg::NT * (I - H);
+        return ja == 0 ? NB / 2 : NB - ja;
+    }
+}
+template <typename Cfg, int RP, int I, int JM> __device__ __forceinline__ int butterfly_j(int t)
+{
+    if constexpr (JM) return pair_j<Cfg, RP, I>(t);
+    else return t + Cfg::NT * I;
+}
+
+// twiddle + butterflies of one Stockham pass: radix RP, previous sub-transform length NS; JM = 1: conjugate-pair
+// assignment of the butterflies (pair_j)
+template <typename Cfg, int RP, int NS, int JM = 0>
 __device__ __forceinline__ void pass_compute(typename Cfg::C *v, int t, const typename Cfg::C *__restrict__ W)
 {
     using C = typename Cfg::C;
@@ -267,7 +300,7 @@ __device__ __forceinline__ void pass_compute(typename Cfg::C *v, int t, const ty
     static_for<0, S>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         if constexpr (NS > 1) {
-            const int j = t + Cfg::NT * i;
+            const int j = butterfly_j<Cfg, RP, i, JM>(t);
             const int k = j & (NS - 1);
             constexpr int step = N / (NS * RP);
             if constexpr (Cfg::kTWCHAIN) {
@@ -342,13 +375,13 @@ template <typename Cfg> constexpr bool gather_separable()
 }
 
 // scatter the outputs of pass (RP, NS) to LDS plane, Stockham output index
-template <typename Cfg, int RP, int NS, int COMP>
+template <typename Cfg, int RP, int NS, int COMP, int JM = 0>
 __device__ __forceinline__ void lds_scatter(const typename Cfg::C *v, typename Cfg::real *plane, int t, int lw)
 {
     constexpr int S = Cfg::kE / RP;
     static_for<0, S>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        const int j = t + Cfg::NT * i;
+        const int j = butterfly_j<Cfg, RP, i, JM>(t);
         const int k = j & (NS - 1);
         const int nbase = (j - k) * RP + k;       // (j/NS)*NS*RP + k
         const int base = lds_slot<Cfg>(lw, nbase);
@@ -359,6 +392,26 @@ __device__ __forceinline__ void lds_scatter(const typename Cfg::C *v, typename C
             if constexpr (scatter_separable<Cfg, RP, NS>()) idx = base + lds_slot_off<Cfg>(m * NS);
             else idx = lds_slot<Cfg>(lw, nbase + m * NS);
             plane[idx] = COMP == 0 ? v[i + mr * S].x : v[i + mr * S].y;
+        });
+    });
+}
+// gather for a consuming pass of radix RPN whose butterflies are assigned in conjugate pairs: register c = i + m*S holds
+// input leg m of butterfly pair_j(i), i.e. point pair_j(i) + m*(N/RPN)
+template <typename Cfg, int COMP, int RPN>
+__device__ __forceinline__ void lds_gather_paired(typename Cfg::C *v, const typename Cfg::real *plane, int t, int lw)
+{
+    constexpr int S = Cfg::kE / RPN, LEG = Cfg::kN / RPN;
+    constexpr bool SEP = Cfg::kMAP == 0 ? LEG % Cfg::r1 == 0 : LEG % 32 == 0;
+    static_for<0, S>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int j = pair_j<Cfg, RPN, i>(t);
+        const int base = lds_slot<Cfg>(lw, j);
+        static_for<0, RPN>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            int idx;
+            if constexpr (SEP) idx = base + lds_slot_off<Cfg>(m * LEG);
+            else idx = lds_slot<Cfg>(lw, j + m * LEG);
+            if (COMP == 0) v[i + m * S].x = plane[idx]; else v[i + m * S].y = plane[idx];
         });
     });
 }
@@ -376,50 +429,63 @@ __device__ __forceinline__ void lds_gather(typename Cfg::C *v, const typename Cf
 }
 
 // producer thread coordinates (t, lw), consumer coordinates (t2, lw2): they differ only across the
-// first exchange of a MAP == 2 kernel
-template <typename Cfg, int RP, int NS>
+// first exchange of a MAP == 2 kernel.  JS: the producing pass has the conjugate-pair butterfly assignment; JG: the
+// consuming pass (radix RPN) has it
+template <typename Cfg, int RP, int NS, int JS = 0, int JG = 0, int RPN = 1>
 __device__ __forceinline__ void exchange(typename Cfg::C *v, typename Cfg::real *lds, int t, int lw, int t2, int lw2, bool first)
 {
     using R = typename Cfg::real;
+    auto gather = [&](auto comp, const R *plane) {
+        constexpr int COMP = decltype(comp)::value;
+        if constexpr (JG) lds_gather_paired<Cfg, COMP, RPN>(v, plane, t2, lw2);
+        else lds_gather<Cfg, COMP>(v, plane, t2, lw2);
+    };
     if constexpr (Cfg::kPLANES == 2) {
         R *p0 = lds, *p1 = lds + Cfg::PLANE_SLOTS;
         if (!first) __syncthreads();
-        lds_scatter<Cfg, RP, NS, 0>(v, p0, t, lw);
-        lds_scatter<Cfg, RP, NS, 1>(v, p1, t, lw);
+        lds_scatter<Cfg, RP, NS, 0, JS>(v, p0, t, lw);
+        lds_scatter<Cfg, RP, NS, 1, JS>(v, p1, t, lw);
         __syncthreads();
-        lds_gather<Cfg, 0>(v, p0, t2, lw2);
-        lds_gather<Cfg, 1>(v, p1, t2, lw2);
+        gather(std::integral_constant<int, 0>{}, p0);
+        gather(std::integral_constant<int, 1>{}, p1);
     } else {
         if (!first) __syncthreads();
-        lds_scatter<Cfg, RP, NS, 0>(v, lds, t, lw);     // old re -> LDS
+        lds_scatter<Cfg, RP, NS, 0, JS>(v, lds, t, lw);     // old re -> LDS
         __syncthreads();
-        lds_gather<Cfg, 0>(v, lds, t2, lw2);            // new re (old im still live in v[].y)
+        gather(std::integral_constant<int, 0>{}, lds);      // new re (old im still live in v[].y)
         __syncthreads();
-        lds_scatter<Cfg, RP, NS, 1>(v, lds, t, lw);
+        lds_scatter<Cfg, RP, NS, 1, JS>(v, lds, t, lw);
         __syncthreads();
-        lds_gather<Cfg, 1>(v, lds, t2, lw2);
+        gather(std::integral_constant<int, 1>{}, lds);
     }
 }
 
 // the whole Stockham chain on the registers of one thread.  (t, lw): coordinates during the first
 // pass; (t2, lw2): coordinates from the first exchange on (identical unless MAP == 2)
-template <typename Cfg>
+// PAIR = 1: the LAST pass has the conjugate-pair butterfly assignment (R2C: split in registers afterwards);
+// PAIR = 2: the FIRST pass has it (C2R: merge in registers before)
+template <typename Cfg, int PAIR = 0>
 __device__ __forceinline__ void transform(typename Cfg::C *v, typename Cfg::real *lds,
                                           const typename Cfg::C *__restrict__ W, int t, int lw, int t2, int lw2)
 {
-    constexpr int R1 = Cfg::r1, R2 = Cfg::r2, R3 = Cfg::r3, R4 = Cfg::r4;
+    constexpr int R1 = Cfg::r1, R2 = Cfg::r2, R3 = Cfg::r3, R4 = Cfg::r4, NP = Cfg::NPASS;
+    static_assert(PAIR == 0 || NP >= 2, "paired butterflies need at least two passes");
+    constexpr int JS1 = PAIR == 2;
     pass_compute<Cfg, R1, 1>(v, t, W);
     if constexpr (R2 > 1) {
-        exchange<Cfg, R1, 1>(v, lds, t, lw, t2, lw2, true);
-        pass_compute<Cfg, R2, R1>(v, t2, W);
+        constexpr int L = PAIR == 1 && NP == 2;
+        exchange<Cfg, R1, 1, JS1, L, R2>(v, lds, t, lw, t2, lw2, true);
+        pass_compute<Cfg, R2, R1, L>(v, t2, W);
     }
     if constexpr (R3 > 1) {
-        exchange<Cfg, R2, R1>(v, lds, t2, lw2, t2, lw2, false);
-        pass_compute<Cfg, R3, R1 * R2>(v, t2, W);
+        constexpr int L = PAIR == 1 && NP == 3;
+        exchange<Cfg, R2, R1, 0, L, R3>(v, lds, t2, lw2, t2, lw2, false);
+        pass_compute<Cfg, R3, R1 * R2, L>(v, t2, W);
     }
     if constexpr (R4 > 1) {
-        exchange<Cfg, R3, R1 * R2>(v, lds, t2, lw2, t2, lw2, false);
-        pass_compute<Cfg, R4, R1 * R2 * R3>(v, t2, W);
+        constexpr int L = PAIR == 1 && NP == 4;
+        exchange<Cfg, R3, R1 * R2, 0, L, R4>(v, lds, t2, lw2, t2, lw2, false);
+        pass_compute<Cfg, R4, R1 * R2 * R3, L>(v, t2, W);
     }
 }
 // line-fastest kernels (r2c / c2r / Bluestein): one coordinate set
@@ -651,7 +717,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
 // ONEPLANE: the split step sends re and im through one LDS plane one after the other (two more
 // barriers, half the LDS: twice the workgroups or twice the lines per workgroup on a CU)
 template <typename Cfg, int ONEPLANE = 0> struct RealCfg {
-    static constexpr size_t SPLIT_BYTES = (ONEPLANE ? 1 : 2) * (size_t)Cfg::PLANE_SLOTS * sizeof(typename Cfg::real);
+    static constexpr size_t SPLIT_BYTES = (ONEPLANE == 2 ? 0 : ONEPLANE ? 1 : 2) * (size_t)Cfg::PLANE_SLOTS * sizeof(typename Cfg::real);
     static constexpr size_t LDS_BYTES = SPLIT_BYTES > Cfg::LDS_BYTES ? SPLIT_BYTES : Cfg::LDS_BYTES;
 };
 
@@ -751,7 +817,7 @@ template <typename Cfg> __device__ __forceinline__ bool real_tile(const PassArgs
 // forward z pass of an R2C plan: real lines [a][LB][2M] -> tiled send buffer with M+1 points.
 // Cfg::kMAP as in fft_pass_kernel: the natural-line load of a fp32 plan wants the point-fastest mapping.
 template <typename Cfg, int ONEPLANE = 0>
-__global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
+__global__ __launch_bounds__(Cfg::THREADS, ONEPLANE == 2 ? 4 : 1) void fft_r2c_kernel(const PassArgs A)
 {
     using C = typename Cfg::C;
     using R = typename Cfg::real;
@@ -797,10 +863,57 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
         });
         return;
     }
+    constexpr int RL = Cfg::RLAST, S = E / RL;
+    if constexpr (ONEPLANE == 2) {
+        // The last pass owns butterflies in conjugate pairs (pair_j), so Z[k] and Z[M-k] are registers of this thread and
+        // the Hermitian split needs no LDS: register c = i + mr*S holds Z[k], k = j(i) + brev(mr)*(M/RL); its partner
+        // Z[M-k] is leg RL-1-m of the mirror block i +- S/2 -- except in thread 0's first block pair, which holds the two
+        // self-mirrored butterflies 0 (legs m <-> RL-m) and M/(2 RL) (legs m <-> RL-1-m).
+        static_assert(S % 2 == 0 && Cfg::NPASS >= 2 && Cfg::kMAP == 0, "in-register split: even butterflies per thread, line-fastest mapping");
+        transform<Cfg, 1>(v, lds, W, t, lw, t2, lw2);
+        if (!active2) return;
+        constexpr int H = S / 2, LEG = M / RL;
+        const bool special = t2 == 0;
+        auto emit_paired = [&](auto offset_of) {
+            static_for<0, E>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                constexpr int i = c % S, mr = c / S, m = brev(mr, RL);
+                const int k = pair_j<Cfg, RL, i>(t2) + m * LEG;
+                constexpr int pn = (i < H ? i + H : i - H) + brev(RL - 1 - m, RL) * S;      // the mirror block's leg RL-1-m
+                constexpr int ps = i < H ? i + brev((RL - m) % RL, RL) * S : i + brev(RL - 1 - m, RL) * S;   // self-mirrored butterflies
+                C zm = v[pn];
+                if constexpr (i % H == 0) zm = pick(special, v[ps], v[pn]);
+                const C z = v[c];
+                const C wv = W2[k];
+                const R Ar = z.x + zm.x, Ai = z.y - zm.y, Br = z.x - zm.x, Bi = z.y + zm.y;
+                C x;
+                x.x = (R)0.5 * (Ar + wv.x * Bi + wv.y * Br);
+                x.y = (R)0.5 * (Ai - wv.x * Br + wv.y * Bi);
+                out[offset_of((uint32_t)k)] = x;
+                if constexpr (c == 0) {
+                    if (special) {          // k = M: X[M] = Re Z[0] - Im Z[0]
+                        C xm; xm.x = z.x - z.y; xm.y = 0;
+                        out[offset_of((uint32_t)M)] = xm;
+                    }
+                }
+            });
+        };
+        if (A.store_kind == STORE_LINES) {
+            const uint64_t row = ((uint64_t)tc2.a * A.LB + (uint64_t)tc2.b * TL + tc2.l) * (uint64_t)(M + 1);
+            emit_paired([&](uint32_t k) { return row + k; });
+        } else if (A.store_kind != STORE_TILED_TRANSPOSE) {
+            emit_paired([&](uint32_t k) { return generic_store_offset<TL>(A, tc2, k, M + 1); });
+        } else if (A.stab || A.snseg != 1) {
+            emit_paired([&](uint32_t k) { return tiled_transpose_store_offset<TL>(A, tc2, k); });
+        } else {
+            const TransposeOne<TL> one(A, tc2);
+            emit_paired([&](uint32_t k) { return one(k); });
+        }
+        return;
+    }
     transform<Cfg>(v, lds, W, t, lw, t2, lw2);
 
     // split step through LDS: scatter Z by natural index, gather the (k, M-k) pairs
-    constexpr int RL = Cfg::RLAST, S = E / RL;
     R *p0 = lds, *p1 = ONEPLANE ? lds : lds + Cfg::PLANE_SLOTS;
     R zr_[ONEPLANE ? E : 1], mr_[ONEPLANE ? E : 1];
     if (Cfg::NPASS > 1) __syncthreads();
@@ -873,7 +986,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_r2c_kernel(const PassArgs A)
 
 // inverse z pass of an R2C plan: tiled recv buffer with M+1 points -> real lines [a][LB][2M].
 // Cfg::kMAP == 2 (line-fastest tiled load, point-fastest natural-line store) is the fp32 form.
-template <typename Cfg>
+template <typename Cfg, int PAIRED = 0>
 __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
 {
     using C = typename Cfg::C;
@@ -895,6 +1008,56 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
     const C *__restrict__ W2 = reinterpret_cast<const C *>(A.tw2);
 
     C v[E];
+    if constexpr (PAIRED) {
+        // The FIRST pass owns butterflies in conjugate pairs (pair_j): every X[k] is loaded once, its partner X[M-k] is a
+        // register of the same thread (see fft_r2c_kernel), the merge happens in registers before the first butterflies.
+        constexpr int R1 = Cfg::r1, S1 = E / R1, H = S1 / 2, LEG = M / R1;
+        static_assert(S1 % 2 == 0 && Cfg::NPASS >= 2 && Cfg::kMAP == 0, "in-register merge: even butterflies per thread, line-fastest mapping");
+        C x[E];
+        C xM; xM.x = 0; xM.y = 0;
+        const bool special = t == 0;
+        auto fetch_paired = [&](auto offset_of) {
+            static_for<0, E>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                constexpr int i = c % S1, m = c / S1;                  // input leg m of block i (natural leg order)
+                const int k = pair_j<Cfg, R1, i>(t) + m * LEG;
+                x[c] = in[offset_of((uint32_t)k)];
+            });
+            if (special) xM = in[offset_of((uint32_t)M)];
+        };
+        if (active) {
+            if (A.load_kind == LOAD_LINES) {
+                const uint64_t row = ((uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + tc.l) * (uint64_t)(M + 1);
+                fetch_paired([&](uint32_t k) { return row + k; });
+            } else if (A.ltab || A.lnseg != 1) {
+                fetch_paired([&](uint32_t k) { return tiled_load_offset<TL>(A, tc, k); });
+            } else {
+                const uint64_t len = A.lseg->len[0];
+                const uint64_t base = A.lseg->base[0] + (uint64_t)tc.a * (A.IA ? A.IA : len * A.LB) + (uint64_t)tc.b * (A.IB ? A.IB : (uint64_t)TL * len) + tc.l;
+                const uint32_t s0 = A.lseg->start[0], tw = tc.tw;
+                fetch_paired([&](uint32_t k) { return base + (uint64_t)(k - s0) * tw; });
+            }
+        } else {
+            static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; x[c].x = 0; x[c].y = 0; });
+        }
+        static_for<0, E>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int i = c % S1, m = c / S1;
+            const int k = pair_j<Cfg, R1, i>(t) + m * LEG;
+            constexpr int pn = (i < H ? i + H : i - H) + (R1 - 1 - m) * S1;
+            constexpr int ps = i < H ? i + ((R1 - m) % R1) * S1 : i + (R1 - 1 - m) * S1;
+            C xk = x[c];
+            C xm = x[pn];
+            if constexpr (i == 0 && m == 0) xm = pick(special, xM, x[pn]);             // k = 0 pairs with X[M]
+            else if constexpr (i % H == 0) xm = pick(special, x[ps], x[pn]);
+            if (k == 0) { xk.y = 0; xm.y = 0; }      // imaginary parts of X[0], X[M] are ignored
+            const C wv = W2[k];
+            const R Ar = xk.x + xm.x, Ai = xk.y - xm.y, Br = xk.x - xm.x, Bi = xk.y + xm.y;
+            // swapped on the fly (inverse via re<->im swap): v = (Im Z', Re Z')
+            v[c].y = Ar - wv.x * Bi + wv.y * Br;
+            v[c].x = Ai + wv.x * Br + wv.y * Bi;
+        });
+    } else
     if (active) {
         auto fetch = [&](auto offset_of) {
             static_for<0, E>([&](auto cc) {
@@ -925,7 +1088,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
     } else {
         static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].x = 0; v[c].y = 0; });
     }
-    if (!(A.debug & 1)) transform<Cfg>(v, lds, W, t, lw, t2, lw2);
+    if (!(A.debug & 1)) transform<Cfg, PAIRED ? 2 : 0>(v, lds, W, t, lw, t2, lw2);
     if (!active2) return;
     constexpr int RL = Cfg::RLAST, S = E / RL;
     C *p = out + ((uint64_t)tc2.a * A.LB + (uint64_t)tc2.b * TL + tc2.l) * M + t2;

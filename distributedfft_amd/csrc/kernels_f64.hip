@@ -74,8 +74,16 @@ using F64_R512 = PassCfg<double, 512, 8, 8, 1, 8, 8, 8, 1, 1>;
 #define DFFT_F64_BASE(X) X(2, 0, F64_2) X(4, 0, F64_4) X(8, 0, F64_8) X(16, 0, F64_16) X(32, 0, F64_32) X(64, 0, F64_64) \
     X(128, 0, F64_128) X(256, 0, F64_256) X(512, 0, F64_R512) X(1024, 0, F64_1024)
 #if DFFT_SLICE == 3
+// 512 and 1024 (Nz = 1024, 2048): the Hermitian split / merge runs in registers -- the pass next to it assigns its
+// butterflies in conjugate pairs (pair_j), which needs an even number of butterflies per thread in that pass: 16 points
+// per thread with radix 8 (512) or radix 4 (1024: last for R2C, first for C2R)
+using F64_R1024_c2r = PassCfg<double, 1024, 16, 8, 1, 4, 16, 16, 1, 1, 1>;
 int launch_real_f64(int M, int mode, int variant, const PassArgs &A, hipStream_t stream)
 {
+    if (variant == 0 && A.load_kind != LOAD_KMAJOR) {
+        if (M == 512) return mode == 1 ? launch_real_cfg<F64_512, 1, 2>(A, stream) : launch_real_cfg<F64_512, 2, 2>(A, stream);
+        if (M == 1024) return mode == 1 ? launch_real_cfg<F64_1024, 1, 2>(A, stream) : launch_real_cfg<F64_R1024_c2r, 2, 2>(A, stream);
+    }
     (void)variant;
     switch (M) {
 #define X(n, v, cfg) case n: return mode == 1 ? launch_real_cfg<cfg, 1>(A, stream) : launch_real_cfg<cfg, 2>(A, stream);
