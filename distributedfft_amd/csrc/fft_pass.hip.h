@@ -816,7 +816,10 @@ template <typename Cfg> __device__ __forceinline__ bool real_tile(const PassArgs
 
 // forward z pass of an R2C plan: real lines [a][LB][2M] -> tiled send buffer with M+1 points.
 // Cfg::kMAP as in fft_pass_kernel: the natural-line load of a fp32 plan wants the point-fastest mapping.
-template <typename Cfg, int ONEPLANE = 0>
+// YLINES = 1 is the y pass of the Y_Then_ZX sequence (strided real lines in, point-major / same-tile blocks out), a
+// separate instantiation so that its address forms do not cost the z pass registers (fp32: 194 instead of 166 VGPRs,
+// i.e. 2 instead of 3 waves per SIMD, when both lived in one kernel).
+template <typename Cfg, int ONEPLANE = 0, int YLINES = 0>
 __global__ __launch_bounds__(Cfg::THREADS, ONEPLANE == 2 ? 4 : 1) void fft_r2c_kernel(const PassArgs A)
 {
     using C = typename Cfg::C;
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(Cfg::THREADS, ONEPLANE == 2 ? 4 : 1) void fft_r2c_k
     const C *__restrict__ W2 = reinterpret_cast<const C *>(A.tw2);
 
     C v[E];
-    if (active && A.load_kind == LOAD_KMAJOR) {
+    if (YLINES && active) {
         // real lines with a stride, lanes along the contiguous axis (the y pass of the Y_Then_ZX sequence reads the
         // input [x][y][z] in place): real point m of the line at a*AS_in + m*KS_in + b*TL + l, in REAL elements;
         // complex point j of the packed transform is (x[2j], x[2j+1])
@@ -849,7 +852,7 @@ __global__ __launch_bounds__(Cfg::THREADS, ONEPLANE == 2 ? 4 : 1) void fft_r2c_k
             v[c].x = rp[m * A.KS_in];
             v[c].y = rp[(m + 1) * A.KS_in];
         });
-    } else if (active) {
+    } else if (!YLINES && active) {
         const C *p = in + ((uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + tc.l) * M + t;
         static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = p[NT * c]; });
     } else {
@@ -869,7 +872,7 @@ __global__ __launch_bounds__(Cfg::THREADS, ONEPLANE == 2 ? 4 : 1) void fft_r2c_k
         // the Hermitian split needs no LDS: register c = i + mr*S holds Z[k], k = j(i) + brev(mr)*(M/RL); its partner
         // Z[M-k] is leg RL-1-m of the mirror block i +- S/2 -- except in thread 0's first block pair, which holds the two
         // self-mirrored butterflies 0 (legs m <-> RL-m) and M/(2 RL) (legs m <-> RL-1-m).
-        static_assert(S % 2 == 0 && Cfg::NPASS >= 2 && Cfg::kMAP == 0, "in-register split: even butterflies per thread, line-fastest mapping");
+        static_assert(S % 2 == 0 && Cfg::NPASS >= 2, "in-register split: even number of last-pass butterflies per thread");
         transform<Cfg, 1>(v, lds, W, t, lw, t2, lw2);
         if (!active2) return;
         constexpr int H = S / 2, LEG = M / RL;
@@ -898,11 +901,11 @@ __global__ __launch_bounds__(Cfg::THREADS, ONEPLANE == 2 ? 4 : 1) void fft_r2c_k
                 }
             });
         };
-        if (A.store_kind == STORE_LINES) {
+        if constexpr (YLINES) {
+            emit_paired([&](uint32_t k) { return generic_store_offset<TL>(A, tc2, k, M + 1); });
+        } else if (A.store_kind == STORE_LINES) {
             const uint64_t row = ((uint64_t)tc2.a * A.LB + (uint64_t)tc2.b * TL + tc2.l) * (uint64_t)(M + 1);
             emit_paired([&](uint32_t k) { return row + k; });
-        } else if (A.store_kind != STORE_TILED_TRANSPOSE) {
-            emit_paired([&](uint32_t k) { return generic_store_offset<TL>(A, tc2, k, M + 1); });
         } else if (A.stab || A.snseg != 1) {
             emit_paired([&](uint32_t k) { return tiled_transpose_store_offset<TL>(A, tc2, k); });
         } else {
@@ -969,13 +972,13 @@ __global__ __launch_bounds__(Cfg::THREADS, ONEPLANE == 2 ? 4 : 1) void fft_r2c_k
             }
         });
     };
-    if (A.store_kind == STORE_LINES) {
+    if constexpr (YLINES) {
+        // point-major or same-tile stores (Y_Then_ZX: the y pass writes [ky][z/TL][x][z%TL] blocks)
+        emit([&](uint32_t k) { return generic_store_offset<TL>(A, tc2, k, M + 1); });
+    } else if (A.store_kind == STORE_LINES) {
         // natural [line][M+1] rows (partial transform, d = 1)
         const uint64_t row = ((uint64_t)tc2.a * A.LB + (uint64_t)tc2.b * TL + tc2.l) * (uint64_t)(M + 1);
         emit([&](uint32_t k) { return row + k; });
-    } else if (A.store_kind != STORE_TILED_TRANSPOSE) {
-        // point-major or same-tile stores (Y_Then_ZX: the y pass writes [ky][z/TL][x][z%TL] blocks)
-        emit([&](uint32_t k) { return generic_store_offset<TL>(A, tc2, k, M + 1); });
     } else if (A.stab || A.snseg != 1) {
         emit([&](uint32_t k) { return tiled_transpose_store_offset<TL>(A, tc2, k); });
     } else {
@@ -1012,7 +1015,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
         // The FIRST pass owns butterflies in conjugate pairs (pair_j): every X[k] is loaded once, its partner X[M-k] is a
         // register of the same thread (see fft_r2c_kernel), the merge happens in registers before the first butterflies.
         constexpr int R1 = Cfg::r1, S1 = E / R1, H = S1 / 2, LEG = M / R1;
-        static_assert(S1 % 2 == 0 && Cfg::NPASS >= 2 && Cfg::kMAP == 0, "in-register merge: even butterflies per thread, line-fastest mapping");
+        static_assert(S1 % 2 == 0 && Cfg::NPASS >= 2, "in-register merge: even number of first-pass butterflies per thread");
         C x[E];
         C xM; xM.x = 0; xM.y = 0;
         const bool special = t == 0;

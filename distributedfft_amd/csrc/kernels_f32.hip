@@ -90,16 +90,27 @@ DFFT_SLICE_FUNCS(f32, 2, DFFT_F32_LIST_2048)
 using F32_R512_32 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1>;
 using F32_R512_pf1 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1, 0, 1>;
 using F32_R512_pf2 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1, 0, 2>;
+using F32_R512_c2r = PassCfg<float, 512, 32, 16, 1, 16, 32, 1, 1, 1, 1, 0, 2>;     // 16 first: two first-pass butterflies per thread (pairs)
+// 1024 (Nz = 2048): three passes so that the pass next to the split / merge has two butterflies per thread (pairs)
+using F32_R1024_r2c = PassCfg<float, 1024, 32, 16, 1, 8, 8, 16, 1, 1, 1, 0, 1>;
+using F32_R1024_c2r = PassCfg<float, 1024, 32, 16, 1, 16, 8, 8, 1, 1, 1, 0, 2>;
 using F32_R1024_pf1 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 1>;
 using F32_R1024_pf2 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 2>;
 int launch_real_f32(int M, int mode, int variant, const PassArgs &A, hipStream_t stream)
 {
-    (void)variant;
     if (mode == 1 && A.load_kind == LOAD_KMAJOR) {
         // strided real lines (Y_Then_ZX): the lanes run along the contiguous axis, i.e. the line-fastest mapping
-        if (M == 512) return launch_real_cfg<F32_R512_32, 1, 1>(A, stream);
-        if (M == 1024) return launch_real_cfg<F32_1024_v6, 1, 1>(A, stream);
+        if (M == 512) return launch_real_cfg<F32_R512_32, 3, 1>(A, stream);
+        if (M == 1024) return launch_real_cfg<F32_1024_v6, 3, 1>(A, stream);
+        switch (M) {
+#define X(n, v, cfg) case n: return launch_real_cfg<cfg, 3>(A, stream);
+            DFFT_F32_BASE(X)
+#undef X
+        }
+        return -1;
     }
+    if (M == 512 && variant == 0) return mode == 1 ? launch_real_cfg<F32_R512_pf1, 1, 2>(A, stream) : launch_real_cfg<F32_R512_c2r, 2, 2>(A, stream);
+    if (M == 1024 && variant == 0) return mode == 1 ? launch_real_cfg<F32_R1024_r2c, 1, 2>(A, stream) : launch_real_cfg<F32_R1024_c2r, 2, 2>(A, stream);
     if (M == 512) return mode == 1 ? launch_real_cfg<F32_R512_pf1, 1, 1>(A, stream) : launch_real_cfg<F32_R512_pf2, 2>(A, stream);
     if (M == 1024) return mode == 1 ? launch_real_cfg<F32_R1024_pf1, 1, 1>(A, stream) : launch_real_cfg<F32_R1024_pf2, 2>(A, stream);
     switch (M) {

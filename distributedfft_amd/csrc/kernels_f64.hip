@@ -84,7 +84,14 @@ int launch_real_f64(int M, int mode, int variant, const PassArgs &A, hipStream_t
         if (M == 512) return mode == 1 ? launch_real_cfg<F64_512, 1, 2>(A, stream) : launch_real_cfg<F64_512, 2, 2>(A, stream);
         if (M == 1024) return mode == 1 ? launch_real_cfg<F64_1024, 1, 2>(A, stream) : launch_real_cfg<F64_R1024_c2r, 2, 2>(A, stream);
     }
-    (void)variant;
+    if (mode == 1 && A.load_kind == LOAD_KMAJOR) {      // strided real lines (Y_Then_ZX)
+        switch (M) {
+#define X(n, v, cfg) case n: return launch_real_cfg<cfg, 3>(A, stream);
+            DFFT_F64_BASE(X)
+#undef X
+        }
+        return -1;
+    }
     switch (M) {
 #define X(n, v, cfg) case n: return mode == 1 ? launch_real_cfg<cfg, 1>(A, stream) : launch_real_cfg<cfg, 2>(A, stream);
         DFFT_F64_BASE(X)

@@ -180,7 +180,7 @@ def run_distributed_real(shape, P1, P2, prec, field=None, seed=13, modify=None):
 
 
 REAL = [((8, 8, 8), 1, 1), ((16, 16, 16), 1, 1), ((32, 16, 64), 1, 1), ((128, 128, 128), 1, 1),
-        ((4, 4, 2048), 1, 1), ((8, 8, 1024), 1, 1), ((8, 16, 1024), 2, 2), ((16, 8, 512), 1, 2), ((16, 16, 16), 2, 2), ((32, 32, 32), 2, 4), ((64, 32, 16), 4, 2),
+        ((4, 4, 2048), 1, 1), ((16, 8, 2048), 2, 2), ((8, 8, 1024), 1, 1), ((8, 16, 1024), 2, 2), ((16, 8, 512), 1, 2), ((16, 16, 16), 2, 2), ((32, 32, 32), 2, 4), ((64, 32, 16), 4, 2),
         ((16, 16, 16), 3, 2), ((32, 16, 64), 2, 1), ((64, 64, 64), 3, 5), ((128, 64, 32), 2, 4)]
 
 
