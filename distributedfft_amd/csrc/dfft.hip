@@ -153,11 +153,12 @@ static void axis_free(Axis &a)
 }
 
 // decide how an axis of length N is transformed; returns false if unsupported
-static bool axis_plan(int prec, size_t N, Axis &a)
+static bool axis_plan(int prec, size_t N, Axis &a, bool mixed = true)
 {
     PassInfo pi;
     a.N = N;
-    if (is_pow2(N) && pass_info(prec, (int)N, &pi)) { a.bluestein = false; a.M = N; return true; }
+    // native chain: powers of two 2..2048 and the mixed-radix lengths of kernels_mixed.inc (2^a 3^b 5^c 7^d <= 2048)
+    if ((is_pow2(N) || mixed) && N <= 2048 && pass_info(prec, (int)N, &pi)) { a.bluestein = false; a.M = N; return true; }
     const size_t M = next_pow2(2 * N - 1);
     if (N < 2 || !pass_info(prec, (int)M, &pi)) return false;
     a.bluestein = true; a.M = M;
@@ -250,6 +251,7 @@ struct Options {
                              // -1 = by measurement: z, x, y where it won (fp32 with x and y lines of 2048 points or more)
     int single_layout = 1;   // L2 of the z, x, y order: 0 = [kx][kz/TL][y][l], 1 = tile-outer [kz/TL][kx][y][l]
     int single_pad = 128;    // bytes added to every L2 row (a row stride that is an odd multiple of 128 B; 0 = packed)
+    int native_mixed = 1;    // lengths 2^a 3^b 5^c 7^d with a configuration run the native chain (0: Bluestein, for A/B runs and tests)
     int order[6] = {-1, -1, -1, -1, -1, -1};     // workgroup->tile order per pass: fz fy fx ix iy iz; a_fastest + 2*xcd_swizzle
     int variant[6] = {-1, -1, -1, -1, -1, -1};   // kernel configuration per pass, same order (-1 = the plan's choice)
 };
@@ -1286,6 +1288,7 @@ static int *option_slot(Options &o, const std::string &k)
     if (k == "single_order") return &o.single_order;
     if (k == "single_layout") return &o.single_layout;
     if (k == "single_pad") return &o.single_pad;
+    if (k == "native_mixed") return &o.native_mixed;
     for (int i = 0; i < 6; i++) {
         if (k == std::string("variant_") + kPassNames[i]) return &o.variant[i];
         if (k == std::string("order_") + kPassNames[i]) return &o.order[i];
@@ -1345,14 +1348,15 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         // Y_Then_ZX, R2C: the y pass reads real lines in place.  Power-of-two Ny: the packed Ny/2-point real kernel
         // with its strided-line load; any other Ny: the Bluestein kernel's real mode (Ny <= 1024)
         const bool yr_native = yzx && !c2c && is_pow2(Ny) && Ny >= 4 && Ny <= 2048;
-        const bool yok = yr_native ? axis_plan(p->prec, Ny / 2, ay) : yzx && !c2c ? axis_plan_bluestein(p->prec, Ny, ay) : axis_plan(p->prec, Ny, ay);
+        const bool mixed = p->opt.native_mixed != 0;
+        const bool yok = yr_native ? axis_plan(p->prec, Ny / 2, ay) : yzx && !c2c ? axis_plan_bluestein(p->prec, Ny, ay) : axis_plan(p->prec, Ny, ay, mixed);
         // a real z pass is either the packed Nz/2-point kernel or the Bluestein kernel's real modes: never
         // the plain complex chain (Nz == 2 would otherwise pick it and launch Bluestein without its tables)
         const bool zreal_generic = !yzx && !c2c && !zr_native;
-        const bool zok = zreal_generic ? axis_plan_bluestein(p->prec, Nz, az) : axis_plan(p->prec, zlen, az);
-        if (!zok || !yok || !axis_plan(p->prec, Nx, axx))
+        const bool zok = zreal_generic ? axis_plan_bluestein(p->prec, Nz, az) : axis_plan(p->prec, zlen, az, mixed);
+        if (!zok || !yok || !axis_plan(p->prec, Nx, axx, mixed))
             return fail(ERR_UNSUPPORTED, yzx && !c2c && Ny > 1024 ? "unsupported axis length (Y_Then_ZX R2C: powers of two up to 2048, other Ny up to 1024)"
-                        : "unsupported axis length (powers of two up to 2048, any other length up to 1024)");
+                        : "unsupported axis length (powers of two and the mixed-radix lengths of kernels_mixed.inc up to 2048, any other length up to 1024)");
         for (auto &a : p->ax) axis_free(a);
         p->ax[0] = az; p->ax[1] = ay; p->ax[2] = axx;
         p->zreal_native = zr_native;
@@ -1837,13 +1841,17 @@ int dfft_fft1d_batched_ex(int precision, size_t N, size_t batch, void *out, cons
 {
     static thread_local Axis ax;
     static thread_local int axP = -1;
-    if (ax.N != N || axP != precision) {
+    static thread_local bool axB = false;
+    const bool force_bluestein = variant < 0;      // variant -1: the Bluestein kernel even where a native configuration exists
+    if (force_bluestein) variant = 0;
+    if (ax.N != N || axP != precision || axB != force_bluestein) {
         axis_free(ax);
         ax = Axis();
         axP = -1;
-        if (!axis_plan(precision, N, ax)) { ax = Axis(); return fail(ERR_UNSUPPORTED, "unsupported line length"); }
+        if (!(force_bluestein ? axis_plan_bluestein(precision, N, ax) : axis_plan(precision, N, ax))) { ax = Axis(); return fail(ERR_UNSUPPORTED, "unsupported line length"); }
         if (int r = axis_upload(precision, ax)) { axis_free(ax); ax = Axis(); return r; }
         axP = precision;
+        axB = force_bluestein;
     }
 #ifdef DFFT_EXPERIMENTS
     if ((variant == 15 || variant == 14) && precision == DFFT_F32 && !ax.bluestein) {      // A/B: the LDS-free shuffle pass (15 bpermute, 14 DPP)

@@ -116,18 +116,18 @@ template <typename C> struct ScalarOf;
 template <> struct ScalarOf<cfloat_t> { using type = float; };
 template <> struct ScalarOf<cdouble_t> { using type = double; };
 template <typename C> using scalar_t = typename ScalarOf<C>::type;
-template <typename C> __device__ __forceinline__ C cswap(C d) { return __builtin_shufflevector(d, d, 1, 0); }      // (im, re)
-template <typename C> __device__ __forceinline__ C cmake(scalar_t<C> re, scalar_t<C> im) { C r; r.x = re; r.y = im; return r; }
+template <typename C> __host__ __device__ __forceinline__ C cswap(C d) { return __builtin_shufflevector(d, d, 1, 0); }      // (im, re)
+template <typename C> __host__ __device__ __forceinline__ C cmake(scalar_t<C> re, scalar_t<C> im) { C r; r.x = re; r.y = im; return r; }
 // x * w for a twiddle w given as the pair (w, iw) with iw = i*w = (-w.y, w.x): x.xx * w + x.yy * iw -- two packed
 // instructions at fp32.  Keeping iw next to w (instead of building it per multiplication) is what makes it two.
-template <typename C> __device__ __forceinline__ C cmul2(C x, C w, C iw)
+template <typename C> __host__ __device__ __forceinline__ C cmul2(C x, C w, C iw)
 {
     const C xx = __builtin_shufflevector(x, x, 0, 0), yy = __builtin_shufflevector(x, x, 1, 1);
     return xx * w + yy * iw;
 }
-template <typename C> __device__ __forceinline__ C ci(C w) { C r; r.x = -w.y; r.y = w.x; return r; }            // i * w
+template <typename C> __host__ __device__ __forceinline__ C ci(C w) { C r; r.x = -w.y; r.y = w.x; return r; }            // i * w
 
-template <int I, int N, typename F> __device__ __forceinline__ void static_for(F &&f)
+template <int I, int N, typename F> __host__ __device__ __forceinline__ void static_for(F &&f)
 {
     if constexpr (I < N) {
         f(std::integral_constant<int, I>{});
@@ -136,15 +136,26 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 }
 
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
+constexpr bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+// the in-register butterflies split a radix R by its smallest prime factor (2, 3, 5, 7) until nothing is left
+constexpr int smallest_factor(int R) { return R % 2 == 0 ? 2 : R % 3 == 0 ? 3 : R % 5 == 0 ? 5 : R % 7 == 0 ? 7 : R; }
+// Output index held by register slot m after Dif<R>: digit reversal in the mixed radix system of R's prime factors,
+// smallest first (out_R(m) = p * out_{R/p}(m % (R/p)) + m / (R/p)); for a power of two that is the bit reversal.
 constexpr int brev(int m, int R)
 {
-    int r = 0;
-    for (int b = 1; b < R; b <<= 1) { r = (r << 1) | (m & 1); m >>= 1; }
+    int r = 0, w = 1;
+    while (R > 1) {
+        const int p = smallest_factor(R), H = R / p;
+        r += w * (m / H);
+        m %= H;
+        w *= p;
+        R = H;
+    }
     return r;
 }
 
 // cos(2*pi*j/64), j = 0..16 (one octant + 1); everything else by symmetry
-__device__ constexpr double kCos64[17] = {1.0,
+constexpr double kCos64[17] = {1.0,
                                           0.99518472667219688624,
                                           0.98078528040323044913,
                                           0.95694033573220886494,
@@ -170,40 +181,119 @@ constexpr double cos64(int j)
 }
 constexpr double sin64(int j) { return cos64((j + 48) & 63); }   // sin(x) = cos(x - pi/2)
 
+// cos and sin of 2*pi*j/R for any R (mixed-radix butterflies), evaluated at compile time: the angle is reduced to
+// [0, pi/4] exactly (integer arithmetic on the fraction j/R), then a Taylor polynomial in Horner form (error ~1 ulp)
+struct CosSin { double c, s; };
+constexpr double taylor_sin(double x)
+{
+    const double x2 = x * x;
+    double r = 1.0;
+    for (int k = 13; k >= 1; k--) r = 1.0 - x2 / (double)((2 * k) * (2 * k + 1)) * r;
+    return x * r;
+}
+constexpr double taylor_cos(double x)
+{
+    const double x2 = x * x;
+    double r = 1.0;
+    for (int k = 13; k >= 1; k--) r = 1.0 - x2 / (double)((2 * k - 1) * (2 * k)) * r;
+    return r;
+}
+constexpr CosSin cossin_frac(int j, int R)
+{
+    long n = (long)(((j % R) + R) % R) * 8;      // angle = 2*pi*n/D with D = 8R, so that D/8 is an integer
+    const long D = (long)R * 8;
+    bool sneg = false, cneg = false, swp = false;
+    if (n > D / 2) { n = D - n; sneg = true; }
+    if (n > D / 4) { n = D / 2 - n; cneg = true; }
+    if (n > D / 8) { n = D / 4 - n; swp = true; }
+    const double x = 0.78539816339744830962 * ((double)n / (double)R);     // (pi/4) * n/R, n <= R
+    double c = taylor_cos(x), s = taylor_sin(x);
+    if (swp) { const double t = c; c = s; s = t; }
+    if (cneg) c = -c;
+    if (sneg) s = -s;
+    return CosSin{c, s};
+}
+
 // multiply by exp(-2*pi*i*J/R) (forward kernel), compile-time J, trivial cases folded.  Vector form: with sw = (d.y, d.x),
 // d * (c - i s) = d * c + sw * (s, -s)
-template <int R, int J, typename C> __device__ __forceinline__ C mul_w(C d)
+template <int R, int J, typename C> __host__ __device__ __forceinline__ C mul_w(C d)
 {
     using T = scalar_t<C>;
-    static_assert(R <= 64, "radix-R butterflies up to 64");
-    constexpr int j64 = (J * (64 / R)) & 63;
-    if constexpr (j64 == 0) return d;
-    else if constexpr (j64 == 16) { C r; r.x = d.y; r.y = -d.x; return r; }           // * -i
-    else if constexpr (j64 == 32) return -d;
-    else if constexpr (j64 == 48) { C r; r.x = -d.y; r.y = d.x; return r; }          // * +i
-    else if constexpr (j64 == 8) { constexpr T s = (T)0.70710678118654752440; return (d + cswap(d) * cmake<C>((T)1, (T)-1)) * s; }     // (x+y, y-x) s
-    else if constexpr (j64 == 24) { constexpr T s = (T)0.70710678118654752440; return (cswap(d) * cmake<C>((T)1, (T)-1) - d) * s; }   // (y-x, -x-y) s
-    else {
+    constexpr int j = ((J % R) + R) % R;
+    if constexpr (j == 0) return d;
+    else if constexpr (4 * j == R) { C r; r.x = d.y; r.y = -d.x; return r; }           // * -i
+    else if constexpr (2 * j == R) return -d;
+    else if constexpr (4 * j == 3 * R) { C r; r.x = -d.y; r.y = d.x; return r; }      // * +i
+    else if constexpr (8 * j == R) { constexpr T s = (T)0.70710678118654752440; return (d + cswap(d) * cmake<C>((T)1, (T)-1)) * s; }     // (x+y, y-x) s
+    else if constexpr (8 * j == 3 * R) { constexpr T s = (T)0.70710678118654752440; return (cswap(d) * cmake<C>((T)1, (T)-1) - d) * s; }   // (y-x, -x-y) s
+    else if constexpr (64 % R == 0) {
+        constexpr int j64 = (j * (64 / R)) & 63;
         constexpr T c = (T)cos64(j64), s = (T)sin64(j64);   // w = c - i s
+        return d * c + cswap(d) * cmake<C>(s, -s);
+    } else {
+        constexpr CosSin w = cossin_frac(j, R);
+        constexpr T c = (T)w.c, s = (T)w.s;
         return d * c + cswap(d) * cmake<C>(s, -s);
     }
 }
 
-// radix-R decimation-in-frequency FFT on registers v[OFF + m*STRIDE], m = 0..R-1.
-// On return slot m holds X[brev(m, R)].
+// P-point DFT for an odd prime P (3, 5, 7) on x[0..P-1] in place, natural order, forward sign:
+//   y_s = a_s - i b_s,  y_{P-s} = a_s + i b_s,   a_s = x_0 + sum_q cos(2 pi q s / P) (x_q + x_{P-q}),
+//                                               b_s =       sum_q sin(2 pi q s / P) (x_q - x_{P-q}),   q, s = 1..(P-1)/2
+template <int P, typename C> __host__ __device__ __forceinline__ void dft_prime(C *x)
+{
+    using T = scalar_t<C>;
+    constexpr int Hh = (P - 1) / 2;
+    C tp[Hh], tm[Hh];
+    static_for<0, Hh>([&](auto qc) {
+        constexpr int q = decltype(qc)::value + 1;
+        tp[q - 1] = x[q] + x[P - q];
+        tm[q - 1] = x[q] - x[P - q];
+    });
+    const C x0 = x[0];
+    C y0 = x0;
+    static_for<0, Hh>([&](auto qc) { y0 = y0 + tp[decltype(qc)::value]; });
+    x[0] = y0;
+    static_for<0, Hh>([&](auto sc) {
+        constexpr int s = decltype(sc)::value + 1;
+        C a = x0, b;
+        b.x = 0; b.y = 0;
+        static_for<0, Hh>([&](auto qc) {
+            constexpr int q = decltype(qc)::value + 1;
+            constexpr CosSin w = cossin_frac(q * s, P);
+            a = a + tp[q - 1] * (T)w.c;
+            b = b + tm[q - 1] * (T)w.s;
+        });
+        C lo, hi;
+        lo.x = a.x + b.y; lo.y = a.y - b.x;      // a - i b
+        hi.x = a.x - b.y; hi.y = a.y + b.x;      // a + i b
+        x[s] = lo;
+        x[P - s] = hi;
+    });
+}
+
+// radix-R decimation-in-frequency FFT on registers v[OFF + m*STRIDE], m = 0..R-1; R = 2^a 3^b 5^c 7^d.
+// Each level splits by the smallest prime factor P of R: P-point DFTs over the legs j + q*R/P, twiddles w_R^(j s)
+// on output s, then P sub-transforms of length R/P.  On return slot m holds X[brev(m, R)].
 template <int R, int OFF, int STRIDE, typename C> struct Dif {
-    static __device__ __forceinline__ void run(C *v)
+    static __host__ __device__ __forceinline__ void run(C *v)
     {
         if constexpr (R >= 2) {
-            constexpr int H = R / 2;
+            constexpr int P = smallest_factor(R), H = R / P;
             static_for<0, H>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                const C a = v[OFF + j * STRIDE], b = v[OFF + (j + H) * STRIDE];
-                v[OFF + j * STRIDE] = a + b;
-                v[OFF + (j + H) * STRIDE] = mul_w<R, j>(a - b);
+                if constexpr (P == 2) {
+                    const C a = v[OFF + j * STRIDE], b = v[OFF + (j + H) * STRIDE];
+                    v[OFF + j * STRIDE] = a + b;
+                    v[OFF + (j + H) * STRIDE] = mul_w<R, j>(a - b);
+                } else {
+                    C x[P];
+                    static_for<0, P>([&](auto qc) { constexpr int q = decltype(qc)::value; x[q] = v[OFF + (j + q * H) * STRIDE]; });
+                    dft_prime<P>(x);
+                    static_for<0, P>([&](auto sc) { constexpr int s = decltype(sc)::value; v[OFF + (j + s * H) * STRIDE] = mul_w<R, j * s>(x[s]); });
+                }
             });
-            Dif<H, OFF, STRIDE, C>::run(v);
-            Dif<H, OFF + H * STRIDE, STRIDE, C>::run(v);
+            static_for<0, P>([&](auto sc) { Dif<H, OFF + decltype(sc)::value * H * STRIDE, STRIDE, C>::run(v); });
         }
     }
 };
@@ -301,7 +391,7 @@ __device__ __forceinline__ void pass_compute(typename Cfg::C *v, int t, const ty
         constexpr int i = decltype(ic)::value;
         if constexpr (NS > 1) {
             const int j = butterfly_j<Cfg, RP, i, JM>(t);
-            const int k = j & (NS - 1);
+            const int k = j % NS;      // NS is a compile-time constant (a mask for powers of two)
             constexpr int step = N / (NS * RP);
             if constexpr (Cfg::kTWCHAIN) {
                 // w^m by successive multiplication; (cur, icur) advance together (i*cur obeys the same recurrence), so
@@ -364,13 +454,15 @@ template <typename Cfg> constexpr int lds_slot_off(int dn)
 // RP == R1 and m*TW stays below the padded block) or a multiple of R1.  Line-major plane: 32-point pad blocks.
 template <typename Cfg, int RP, int NS> constexpr bool scatter_separable()
 {
-    if constexpr (Cfg::kMAP == 0) return NS == 1 ? RP == Cfg::r1 : NS % Cfg::r1 == 0;
+    if constexpr (!is_pow2(Cfg::kN)) return false;      // mixed radix: the pad blocks are not aligned to the radices
+    else if constexpr (Cfg::kMAP == 0) return NS == 1 ? RP == Cfg::r1 : NS % Cfg::r1 == 0;
     else return NS == 1 ? RP % 32 == 0 : NS % 32 == 0;
 }
 // gather: point offsets are NT*c
 template <typename Cfg> constexpr bool gather_separable()
 {
-    if constexpr (Cfg::kMAP == 0) return Cfg::NT % Cfg::r1 == 0;
+    if constexpr (!is_pow2(Cfg::kN)) return false;
+    else if constexpr (Cfg::kMAP == 0) return Cfg::NT % Cfg::r1 == 0;
     else return Cfg::NT % 32 == 0;
 }
 
@@ -382,7 +474,7 @@ __device__ __forceinline__ void lds_scatter(const typename Cfg::C *v, typename C
     static_for<0, S>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const int j = butterfly_j<Cfg, RP, i, JM>(t);
-        const int k = j & (NS - 1);
+        const int k = j % NS;      // NS is a compile-time constant (a mask for powers of two)
         const int nbase = (j - k) * RP + k;       // (j/NS)*NS*RP + k
         const int base = lds_slot<Cfg>(lw, nbase);
         static_for<0, RP>([&](auto mc) {

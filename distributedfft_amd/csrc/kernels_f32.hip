@@ -48,16 +48,22 @@ using F32_2048_v6 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1>;
 #define DFFT_F32_LIST_1024(X) X(1024, 4, F32_1024_v4) X(1024, 5, F32_1024_v5) X(1024, 6, F32_1024_v6) X(1024, 0, F32_1024) DFFT_F32_EXP_1024(X)
 #define DFFT_F32_LIST_2048(X) X(2048, 4, F32_2048_v4) X(2048, 5, F32_2048_v5) X(2048, 6, F32_2048_v6) X(2048, 0, F32_2048) DFFT_F32_EXP_2048(X)
 
+// lengths that are not powers of two (mixed radix 2, 3, 5, 7): generated list, slices 5 (N < 512) and 6
+#define DFFT_MIXED_F32
+#include "kernels_mixed.inc"
+
 DFFT_SLICE_DECLS(f32)
 #if DFFT_SLICE == 0
 DFFT_SLICE_FUNCS(f32, 0, DFFT_F32_LIST_SMALL)
 int launch_pass_f32(int N, int variant, const PassArgs &A, hipStream_t stream)
 {
+    if (!is_pow2(N)) return N < 512 ? launch_pass_f32_s5(N, variant, A, stream) : launch_pass_f32_s6(N, variant, A, stream);
     return N <= 512 ? launch_pass_f32_s0(N, variant, A, stream) : N == 1024 ? launch_pass_f32_s1(N, variant, A, stream)
                                                                           : launch_pass_f32_s2(N, variant, A, stream);
 }
 bool pass_info_f32(int N, int variant, PassInfo *pi)
 {
+    if (!is_pow2(N)) return N < 512 ? pass_info_f32_s5(N, variant, pi) : pass_info_f32_s6(N, variant, pi);
     return N <= 512 ? pass_info_f32_s0(N, variant, pi) : N == 1024 ? pass_info_f32_s1(N, variant, pi) : pass_info_f32_s2(N, variant, pi);
 }
 #elif DFFT_SLICE == 1
@@ -77,6 +83,10 @@ int launch_shfl_f32(int N, int dpp, const PassArgs &A, hipStream_t stream)
 #endif
 #elif DFFT_SLICE == 2
 DFFT_SLICE_FUNCS(f32, 2, DFFT_F32_LIST_2048)
+#elif DFFT_SLICE == 5
+DFFT_SLICE_FUNCS(f32, 5, DFFT_F32_LIST_MIXED0)
+#elif DFFT_SLICE == 6
+DFFT_SLICE_FUNCS(f32, 6, DFFT_F32_LIST_MIXED1)
 #else
 // slices 3 (real z passes) and 4 (Bluestein) share the base list
 

@@ -49,22 +49,32 @@ using F64_2048_v7 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 3, 0, 2>
 #define DFFT_F64_LIST_1024(X) X(1024, 1, F64_1024_v1) X(1024, 3, F64_1024_v3) X(1024, 0, F64_1024) DFFT_F64_EXP_1024(X)
 #define DFFT_F64_LIST_2048(X) X(2048, 3, F64_2048_v3) X(2048, 7, F64_2048_v7) X(2048, 0, F64_2048) DFFT_F64_EXP_2048(X)
 
+// lengths that are not powers of two (mixed radix 2, 3, 5, 7): generated list, slices 5 (N < 512) and 6
+#define DFFT_MIXED_F64
+#include "kernels_mixed.inc"
+
 DFFT_SLICE_DECLS(f64)
 #if DFFT_SLICE == 0
 DFFT_SLICE_FUNCS(f64, 0, DFFT_F64_LIST_SMALL)
 int launch_pass_f64(int N, int variant, const PassArgs &A, hipStream_t stream)
 {
+    if (!is_pow2(N)) return N < 512 ? launch_pass_f64_s5(N, variant, A, stream) : launch_pass_f64_s6(N, variant, A, stream);
     return N <= 512 ? launch_pass_f64_s0(N, variant, A, stream) : N == 1024 ? launch_pass_f64_s1(N, variant, A, stream)
                                                                           : launch_pass_f64_s2(N, variant, A, stream);
 }
 bool pass_info_f64(int N, int variant, PassInfo *pi)
 {
+    if (!is_pow2(N)) return N < 512 ? pass_info_f64_s5(N, variant, pi) : pass_info_f64_s6(N, variant, pi);
     return N <= 512 ? pass_info_f64_s0(N, variant, pi) : N == 1024 ? pass_info_f64_s1(N, variant, pi) : pass_info_f64_s2(N, variant, pi);
 }
 #elif DFFT_SLICE == 1
 DFFT_SLICE_FUNCS(f64, 1, DFFT_F64_LIST_1024)
 #elif DFFT_SLICE == 2
 DFFT_SLICE_FUNCS(f64, 2, DFFT_F64_LIST_2048)
+#elif DFFT_SLICE == 5
+DFFT_SLICE_FUNCS(f64, 5, DFFT_F64_LIST_MIXED0)
+#elif DFFT_SLICE == 6
+DFFT_SLICE_FUNCS(f64, 6, DFFT_F64_LIST_MIXED1)
 #else
 // slices 3 (real z passes) and 4 (Bluestein) share the base list
 

@@ -106,8 +106,8 @@ int dfft_plan_destroy(dfft_plan *plan);
 
 /* initFFT(GlobalSize*, Partition*, bool allocate)   include/mpicufft.hpp:60,
  * src/pencil/mpicufft_pencil_opt1.cpp:46-326, src/slab/default/mpicufft_slab.cpp:97-281.
- * P1*P2 must equal the number of ranks.  Axis lengths: powers of two up to 2048 (native) or any
- * other length up to 1024 (Bluestein).  c2c = 0: R2C/C2R plan (Nz_out = Nz/2+1,
+ * P1*P2 must equal the number of ranks.  Axis lengths: powers of two up to 2048 and the lengths 2^a 3^b 5^c 7^d
+ * <= 2048 listed in csrc/kernels_mixed.inc (native mixed-radix chain), or any other length up to 1024 (Bluestein).  c2c = 0: R2C/C2R plan (Nz_out = Nz/2+1,
  * include/params.hpp:30); c2c = 1: complex plan (Nz_out = Nz). */
 int dfft_init(dfft_plan *plan, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int c2c, int allocate);
 /* setWorkArea(void *device, void *host)   mpicufft_pencil_opt1.cpp:329-387.  NULL device =
@@ -131,6 +131,8 @@ int dfft_get_pipeline_chunks(const dfft_plan *plan);
  *   "single_order"     one rank, complex plan: 1 = pass order z, x, y through a padded private layout, 0 = z, y, x, -1 (default)
  *                      = where it measured faster (env default DFFT_SINGLE_ORDER); "single_layout" (0 | 1) and "single_pad"
  *                      (bytes) shape that layout
+ *   "native_mixed"     1 (default): lengths that are not powers of two but have a mixed-radix configuration run the
+ *                      native chain; 0: they run the Bluestein kernel like every other length (A/B runs, tests)
  *   "debug_skip"       measurement only: 1 = every pass skips its transform and becomes a copy with the same
  *                      access pattern (results are wrong); used to measure the pattern's own roofline
  *   "variant_<pass>", "order_<pass>", "real_variant"   kernel configuration / workgroup order per pass
@@ -214,8 +216,8 @@ int dfft_enable_phase_timing(dfft_plan *plan, int enable);
 int dfft_fft1d_batched(int precision, size_t N, size_t batch, void *out, const void *in,
                        int direction, void *hip_stream);
 
-/* same with an explicit kernel configuration (0 = default; unknown values fall back to 0) and the
- * measurement-only debug flags of "debug_skip" */
+/* same with an explicit kernel configuration (0 = default; unknown values fall back to 0; -1 = the Bluestein kernel
+ * even where the length has a native configuration) and the measurement-only debug flags of "debug_skip" */
 int dfft_fft1d_batched_ex(int precision, size_t N, size_t batch, void *out, const void *in, int direction,
                           void *hip_stream, int variant, int debug);
 

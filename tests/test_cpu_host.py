@@ -38,9 +38,33 @@ def test_kernel_table():
             info = dfft.kernel_info(n, prec)
             assert info and info["threads"] <= 1024 and info["lds_bytes"] <= 160 * 1024
             assert info["lines_per_workgroup"] % (8 if prec == "double" else 16) == 0
-        # other lengths run through Bluestein on the next power of two >= 2N-1 (N <= 1024)
-        assert dfft.kernel_info(3, prec)["points_per_thread"] == 8 and dfft.kernel_info(1000, prec)["threads"] > 0
+        # lengths 2^a 3^b 5^c 7^d with a configuration in csrc/kernels_mixed.inc run the native chain too
+        inc = open(os.path.join(os.path.dirname(dfft.__file__), "csrc", "kernels_mixed.inc")).read()
+        tag = "F64" if prec == "double" else "F32"
+        mixed = sorted({int(m) for m in re.findall(r"using %s_M(\d+) =" % tag, inc)})
+        assert len(mixed) >= 40 and 1000 in mixed and 1536 in mixed and 2000 in mixed
+        for n in mixed:
+            info = dfft.kernel_info(n, prec)
+            assert info and info["threads"] <= 1024 and info["lds_bytes"] <= 160 * 1024
+            assert info["threads"] * info["points_per_thread"] == n * info["lines_per_workgroup"], (n, info)
+        # every other length runs through Bluestein on the next power of two >= 2N-1 (N <= 1024)
+        assert dfft.kernel_info(3, prec)["points_per_thread"] == 8 and dfft.kernel_info(1023, prec)["threads"] > 0
         assert dfft.kernel_info(4096, prec) is None and dfft.kernel_info(1025, prec) is None
+
+
+def test_in_register_butterflies_on_the_host(tmp_path):
+    """tests/cpp/butterfly_check.hip: the mixed-radix butterflies of fft_pass.hip.h (Dif, dft_prime, the compile-time
+    trigonometry, the slot -> output index map) compiled for the host and checked against a long-double DFT"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(os.path.dirname(__file__), "cpp", "butterfly_check.hip")
+    exe = str(tmp_path / "butterfly_check")
+    subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", src, "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout + out.stderr
 
 
 CASES = [((12, 10, 14), 2, 4, False), ((9, 7, 10), 3, 2, True), ((1000, 100, 30), 4, 2, False), ((1024, 1024, 1024), 2, 4, False), ((1024, 1024, 1024), 2, 4, True), ((512, 512, 512), 2, 1, True),

@@ -78,7 +78,7 @@ def test_golden_fixture_single_rank():
     assert rel(got, d["c2c_8x8x8"]) < 1e-11
 
 
-def run_distributed(shape, P1, P2, prec, seed=7, chunks=None):
+def run_distributed(shape, P1, P2, prec, seed=7, chunks=None, options=None):
     """P1*P2 virtual ranks on one GPU (one host thread per rank, like MPI ranks sharing a
     device: tests/src/pencil/random_dist_3D.cu:175-177)."""
     P = P1 * P2
@@ -89,6 +89,8 @@ def run_distributed(shape, P1, P2, prec, seed=7, chunks=None):
         pl = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), world, precision=prec, rank=r)
         if chunks is not None:
             pl.setPipelineChunks(chunks)
+        for k, v in (options or {}).items():
+            pl.setOption(k, v)
         pl.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(P1, P2), True, c2c=True)
         size, start = pl.getInSize(), pl.getInStart()
         blk = orc.fill_block(shape, start, size, 2, seed=seed).astype(NPDT[prec])
@@ -319,6 +321,7 @@ def test_partial_dimension_transforms(shape, P1, P2, d, c2c):
 @pytest.mark.parametrize("prec", ["double", "float"])
 @pytest.mark.parametrize("N", [3, 5, 6, 7, 9, 10, 12, 15, 17, 30, 100, 127, 243, 250, 384, 500, 1000, 1023])
 def test_fft1d_any_length_vs_oracle(N, prec):
+    """variant -1 = the Bluestein kernel for every length (also those that have a native mixed-radix configuration)"""
     batch = 45
     rng = np.random.default_rng(N)
     x = (rng.uniform(0, 255, (batch, N)) + 1j * rng.uniform(0, 255, (batch, N))).astype(NPDT[prec])
@@ -326,10 +329,64 @@ def test_fft1d_any_length_vs_oracle(N, prec):
     d_out = torch.zeros_like(d_in)
     for direction in (dfft.FORWARD, dfft.INVERSE):
         torch.cuda.synchronize()
-        dfft.fft1d_batched(d_out, d_in, N, batch, direction, prec)
+        dfft.fft1d_batched(d_out, d_in, N, batch, direction, prec, variant=-1)
         torch.cuda.synchronize()
         want = orc.fft1d(x.astype(np.complex128), direction)
         assert rel(d_out.cpu().numpy(), want) < (2e-11 if prec == "double" else 2e-4)
+
+
+def mixed_lengths(prec):
+    """the lengths of csrc/kernels_mixed.inc (generated by tools/gen_mixed_configs.py)"""
+    import re
+    inc = os.path.join(os.path.dirname(dfft.__file__), "csrc", "kernels_mixed.inc")
+    tag = "F64" if prec == "double" else "F32"
+    return sorted({int(m) for m in re.findall(r"using %s_M(\d+) =" % tag, open(inc).read())})
+
+
+@pytest.mark.parametrize("prec", ["double", "float"])
+def test_fft1d_mixed_radix_lengths_vs_oracle(prec):
+    """every natively supported length that is not a power of two (radix 2, 3, 5, 7 butterflies in the Stockham chain;
+    the reference takes any length through cufftMakePlanMany64, mpicufft_pencil_opt1.cpp:165-197): ragged batch, both
+    directions, against the oracle; and the kernel info confirms the native chain (threads * points == N * lines)"""
+    lengths = mixed_lengths(prec)
+    assert len(lengths) >= 40
+    for N in lengths:
+        info = dfft.kernel_info(N, prec)
+        assert info is not None and info["threads"] * info["points_per_thread"] == N * info["lines_per_workgroup"], (N, info)
+        batch = 19 if N >= 256 else 77
+        rng = np.random.default_rng(N)
+        x = (rng.uniform(0, 255, (batch, N)) + 1j * rng.uniform(0, 255, (batch, N))).astype(NPDT[prec])
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.zeros_like(d_in)
+        for direction in (dfft.FORWARD, dfft.INVERSE):
+            torch.cuda.synchronize()
+            dfft.fft1d_batched(d_out, d_in, N, batch, direction, prec)
+            torch.cuda.synchronize()
+            want = orc.fft1d(x.astype(np.complex128), direction)
+            assert rel(d_out.cpu().numpy(), want) < (2e-11 if prec == "double" else 2e-4), (N, direction)
+
+
+@pytest.mark.parametrize("prec", ["double", "float"])
+@pytest.mark.parametrize("shape,P1,P2", [((12, 20, 24), 1, 1), ((48, 36, 40), 2, 3), ((96, 100, 72), 2, 2), ((6, 1536, 10), 1, 2),
+                                         ((2000, 6, 12), 2, 1), ((24, 12, 1000), 1, 3), ((160, 144, 120), 4, 2)])
+def test_mixed_radix_grids_vs_oracle_and_bluestein(shape, P1, P2, prec):
+    """distributed complex transform on grids whose axes run the native mixed-radix chain: against the oracle, and
+    against the same plan with option native_mixed=0 (Bluestein on every axis it can serve)"""
+    if prec == "float" and not all(n in mixed_lengths("float") for n in shape):
+        pytest.skip("length without fp32 configuration")
+    plans, ins, spec, backs = run_distributed(shape, P1, P2, prec)
+    want = orc.fft3d_c2c(orc.fill_block(shape, (0, 0, 0), shape, 2, seed=7), -1)
+    n3 = float(np.prod(shape))
+    tol_f, tol_r = (2e-11, 1e-10) if prec == "double" else (2e-4, 5e-5)
+    for r, pl in enumerate(plans):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        ref = want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]]
+        assert np.max(np.abs(spec[r] - ref)) / np.max(np.abs(want)) < tol_f
+        assert rel(backs[r] / n3, ins[r]) < tol_r
+    if max(shape) <= 1024:
+        plans_b, _, spec_b, _ = run_distributed(shape, P1, P2, prec, options={"native_mixed": 0})
+        for r in range(len(plans)):
+            assert np.max(np.abs(spec[r] - spec_b[r])) / np.max(np.abs(want)) < tol_f
 
 
 @pytest.mark.parametrize("shape", [(12, 10, 14), (9, 7, 10), (30, 16, 50), (100, 3, 24), (5, 384, 6)])
