@@ -1342,13 +1342,16 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
     // axis plans: native power-of-two chain (2..2048) or Bluestein (any length with 2N-1 <= 2048)
     {
         Axis az, ay, axx;
-        const bool zr_native = !yzx && !c2c && is_pow2(Nz) && Nz >= 4 && Nz <= 2048;
+        const bool mixed = p->opt.native_mixed != 0;
+        // packed real z pass: Nz/2-point complex transform + Hermitian split / merge (powers of two, and even lengths whose
+        // half has a mixed-radix configuration)
+        const bool zr_native = !yzx && !c2c && Nz >= 4 && Nz <= 2048 && Nz % 2 == 0 && (is_pow2(Nz) || mixed) &&
+                               (p->prec == DFFT_F64 ? real_supported_f64((int)(Nz / 2)) : real_supported_f32((int)(Nz / 2)));
         const size_t zlen = zr_native ? Nz / 2 : Nz;
         // Y_Then_ZX, R2C: the y pass reads real lines in place, which only the Bluestein kernel does
         // Y_Then_ZX, R2C: the y pass reads real lines in place.  Power-of-two Ny: the packed Ny/2-point real kernel
         // with its strided-line load; any other Ny: the Bluestein kernel's real mode (Ny <= 1024)
         const bool yr_native = yzx && !c2c && is_pow2(Ny) && Ny >= 4 && Ny <= 2048;
-        const bool mixed = p->opt.native_mixed != 0;
         const bool yok = yr_native ? axis_plan(p->prec, Ny / 2, ay) : yzx && !c2c ? axis_plan_bluestein(p->prec, Ny, ay) : axis_plan(p->prec, Ny, ay, mixed);
         // a real z pass is either the packed Nz/2-point kernel or the Bluestein kernel's real modes: never
         // the plain complex chain (Nz == 2 would otherwise pick it and launch Bluestein without its tables)
@@ -1895,7 +1898,7 @@ int dfft_kernel_info(int precision, size_t N, int *threads, int *lds_bytes, int 
     if (threads) *threads = pi.threads;
     if (lds_bytes) *lds_bytes = pi.lds_bytes;
     if (points_per_thread) *points_per_thread = pi.E;
-    if (lines_per_workgroup) *lines_per_workgroup = pi.TL * pi.G;
+    if (lines_per_workgroup) *lines_per_workgroup = pi.TL * pi.G / (pi.sub > 1 ? pi.sub : 1);      // sub-tile workgroups: part of a tile
     return 0;
 }
 

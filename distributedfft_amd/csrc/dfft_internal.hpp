@@ -34,6 +34,8 @@ bool pass_info_f64(int N, int variant, PassInfo *pi);
 // real-transform z pass on M = Nz/2 complex points: mode 1 = R2C (forward), 2 = C2R (inverse)
 int launch_real_f64(int M, int mode, int variant, const PassArgs &A, hipStream_t stream);
 int launch_real_f32(int M, int mode, int variant, const PassArgs &A, hipStream_t stream);
+bool real_supported_f64(int M);
+bool real_supported_f32(int M);
 // Bluestein pass with an M-point inner transform (M = power of two >= 2*A.NL - 1)
 int launch_bluestein_f64(int M, const PassArgs &A, hipStream_t stream);
 int launch_bluestein_f32(int M, const PassArgs &A, hipStream_t stream);

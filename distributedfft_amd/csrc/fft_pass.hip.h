@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(Cfg::THREADS, ONEPLANE == 2 ? 4 : 1) void fft_r2c_k
         __syncthreads();
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
-            const int k = t2 + NT * c, km = (M - k) & (M - 1);
+            const int k = t2 + NT * c, km = is_pow2(M) ? (M - k) & (M - 1) : (k == 0 ? 0 : M - k);
             zr_[c] = lds[lds_slot<Cfg>(lw2, k)];
             mr_[c] = lds[lds_slot<Cfg>(lw2, km)];
         });
@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(Cfg::THREADS, ONEPLANE == 2 ? 4 : 1) void fft_r2c_k
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             const int k = t2 + NT * c;
-            const int km = (M - k) & (M - 1);
+            const int km = is_pow2(M) ? (M - k) & (M - 1) : (k == 0 ? 0 : M - k);      // (M - k) mod M
             const int i0 = lds_slot<Cfg>(lw2, k), i1 = lds_slot<Cfg>(lw2, km);
             const R zr = ONEPLANE ? zr_[ONEPLANE ? c : 0] : p0[i0], mr = ONEPLANE ? mr_[ONEPLANE ? c : 0] : p0[i1];
             const R zi = p1[i0], mi = p1[i1];

@@ -87,6 +87,10 @@ DFFT_SLICE_FUNCS(f32, 2, DFFT_F32_LIST_2048)
 DFFT_SLICE_FUNCS(f32, 5, DFFT_F32_LIST_MIXED0)
 #elif DFFT_SLICE == 6
 DFFT_SLICE_FUNCS(f32, 6, DFFT_F32_LIST_MIXED1)
+#elif DFFT_SLICE == 7
+DFFT_REAL_MIXED_FUNCS(f32, 7, DFFT_F32_LIST_RMIXED0)
+#elif DFFT_SLICE == 8
+DFFT_REAL_MIXED_FUNCS(f32, 8, DFFT_F32_LIST_RMIXED1)
 #else
 // slices 3 (real z passes) and 4 (Bluestein) share the base list
 
@@ -106,8 +110,23 @@ using F32_R1024_r2c = PassCfg<float, 1024, 32, 16, 1, 8, 8, 16, 1, 1, 1, 0, 1>;
 using F32_R1024_c2r = PassCfg<float, 1024, 32, 16, 1, 16, 8, 8, 1, 1, 1, 0, 2>;
 using F32_R1024_pf1 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 1>;
 using F32_R1024_pf2 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 2>;
+// is there a packed real z pass for M = Nz/2 complex points?
+bool real_supported_f32(int M)
+{
+    if (!is_pow2(M)) return M < 320 ? real_mixed_info_f32_s7(M) : real_mixed_info_f32_s8(M);
+    switch (M) {
+#define X(n, v, cfg) case n: return true;
+        DFFT_F32_BASE(X)
+#undef X
+    }
+    return false;
+}
 int launch_real_f32(int M, int mode, int variant, const PassArgs &A, hipStream_t stream)
 {
+    if (!is_pow2(M)) {      // mixed-radix lengths (kernels_mixed.inc); no strided-real-line (Y_Then_ZX) form
+        if (A.load_kind == LOAD_KMAJOR && mode == 1) return -1;
+        return M < 320 ? launch_real_mixed_f32_s7(M, mode, A, stream) : launch_real_mixed_f32_s8(M, mode, A, stream);
+    }
     if (mode == 1 && A.load_kind == LOAD_KMAJOR) {
         // strided real lines (Y_Then_ZX): the lanes run along the contiguous axis, i.e. the line-fastest mapping
         if (M == 512) return launch_real_cfg<F32_R512_32, 3, 1>(A, stream);

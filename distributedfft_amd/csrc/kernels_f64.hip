@@ -75,6 +75,10 @@ DFFT_SLICE_FUNCS(f64, 2, DFFT_F64_LIST_2048)
 DFFT_SLICE_FUNCS(f64, 5, DFFT_F64_LIST_MIXED0)
 #elif DFFT_SLICE == 6
 DFFT_SLICE_FUNCS(f64, 6, DFFT_F64_LIST_MIXED1)
+#elif DFFT_SLICE == 7
+DFFT_REAL_MIXED_FUNCS(f64, 7, DFFT_F64_LIST_RMIXED0)
+#elif DFFT_SLICE == 8
+DFFT_REAL_MIXED_FUNCS(f64, 8, DFFT_F64_LIST_RMIXED1)
 #else
 // slices 3 (real z passes) and 4 (Bluestein) share the base list
 
@@ -88,8 +92,23 @@ using F64_R512 = PassCfg<double, 512, 8, 8, 1, 8, 8, 8, 1, 1>;
 // butterflies in conjugate pairs (pair_j), which needs an even number of butterflies per thread in that pass: 16 points
 // per thread with radix 8 (512) or radix 4 (1024: last for R2C, first for C2R)
 using F64_R1024_c2r = PassCfg<double, 1024, 16, 8, 1, 4, 16, 16, 1, 1, 1>;
+// is there a packed real z pass for M = Nz/2 complex points?
+bool real_supported_f64(int M)
+{
+    if (!is_pow2(M)) return M < 320 ? real_mixed_info_f64_s7(M) : real_mixed_info_f64_s8(M);
+    switch (M) {
+#define X(n, v, cfg) case n: return true;
+        DFFT_F64_BASE(X)
+#undef X
+    }
+    return false;
+}
 int launch_real_f64(int M, int mode, int variant, const PassArgs &A, hipStream_t stream)
 {
+    if (!is_pow2(M)) {      // mixed-radix lengths (kernels_mixed.inc); no strided-real-line (Y_Then_ZX) form
+        if (A.load_kind == LOAD_KMAJOR && mode == 1) return -1;
+        return M < 320 ? launch_real_mixed_f64_s7(M, mode, A, stream) : launch_real_mixed_f64_s8(M, mode, A, stream);
+    }
     if (variant == 0 && A.load_kind != LOAD_KMAJOR) {
         if (M == 512) return mode == 1 ? launch_real_cfg<F64_512, 1, 2>(A, stream) : launch_real_cfg<F64_512, 2, 2>(A, stream);
         if (M == 1024) return mode == 1 ? launch_real_cfg<F64_1024, 1, 2>(A, stream) : launch_real_cfg<F64_R1024_c2r, 2, 2>(A, stream);

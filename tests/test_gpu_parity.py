@@ -144,13 +144,15 @@ RDT = {"double": torch.float64, "float": torch.float32}
 NPR = {"double": np.float64, "float": np.float32}
 
 
-def run_distributed_real(shape, P1, P2, prec, field=None, seed=13, modify=None):
+def run_distributed_real(shape, P1, P2, prec, field=None, seed=13, modify=None, options=None):
     P = P1 * P2
     world = dfft.Comm.local(P) if P > 1 else None
     esz = 16 if prec == "double" else 8
     plans, ins, outs, backs = [], [], [], []
     for r in range(P):
         pl = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), world, precision=prec, rank=r)
+        for k, v in (options or {}).items():
+            pl.setOption(k, v)
         pl.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(P1, P2), True)      # R2C plan
         size, start = pl.getInSize(), pl.getInStart()
         if field is None:
@@ -364,6 +366,30 @@ def test_fft1d_mixed_radix_lengths_vs_oracle(prec):
             torch.cuda.synchronize()
             want = orc.fft1d(x.astype(np.complex128), direction)
             assert rel(d_out.cpu().numpy(), want) < (2e-11 if prec == "double" else 2e-4), (N, direction)
+
+
+@pytest.mark.parametrize("prec", ["double", "float"])
+@pytest.mark.parametrize("shape,P1,P2", [((6, 10, 12), 1, 1), ((12, 20, 24), 2, 2), ((10, 12, 200), 1, 2), ((24, 6, 1000), 2, 1),
+                                         ((6, 12, 1536), 1, 1), ((8, 6, 2000), 2, 3), ((20, 36, 1200), 1, 2), ((48, 40, 144), 3, 2)])
+def test_mixed_radix_r2c_c2r_vs_oracle_and_bluestein(shape, P1, P2, prec):
+    """R2C / C2R with a z axis whose half length runs the native mixed-radix chain (packed real pass: Nz/2-point complex
+    transform + Hermitian split / merge): against the oracle, the round trip, and -- where the Bluestein kernel can serve
+    the axis (Nz <= 1024) -- against the same plan with native_mixed = 0"""
+    plans, ins, spec, backs = run_distributed_real(shape, P1, P2, prec)
+    g = orc.fill_block(shape, (0, 0, 0), shape, 1, seed=13).astype(NPR[prec]).astype(np.float64)
+    want = orc.fft3d_r2c(g)
+    n3 = float(np.prod(shape))
+    scale = np.max(np.abs(want))
+    tol_f, tol_r = (2e-11, 1e-10) if prec == "double" else (2e-4, 5e-5)
+    for r, pl in enumerate(plans):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        ref = want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]]
+        assert np.max(np.abs(spec[r] - ref)) / scale < tol_f
+        assert rel(backs[r] / n3, ins[r]) < tol_r
+    if max(shape) <= 1024:
+        _, _, spec_b, _ = run_distributed_real(shape, P1, P2, prec, options={"native_mixed": 0})
+        for r in range(len(plans)):
+            assert np.max(np.abs(spec[r] - spec_b[r])) / scale < tol_f
 
 
 @pytest.mark.parametrize("prec", ["double", "float"])
