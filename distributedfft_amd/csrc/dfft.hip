@@ -157,10 +157,10 @@ static bool axis_plan(int prec, size_t N, Axis &a, bool mixed = true)
 {
     PassInfo pi;
     a.N = N;
-    // native chain: powers of two 2..2048 and the mixed-radix lengths of kernels_mixed.inc (2^a 3^b 5^c 7^d <= 2048)
-    if ((is_pow2(N) || mixed) && N <= 2048 && pass_info(prec, (int)N, &pi)) { a.bluestein = false; a.M = N; return true; }
+    // native chain: powers of two 2..8192 and the mixed-radix lengths of kernels_mixed.inc (2^a 3^b 5^c 7^d <= 2048)
+    if ((is_pow2(N) || mixed) && N <= 8192 && pass_info(prec, (int)N, &pi)) { a.bluestein = false; a.M = N; return true; }
     const size_t M = next_pow2(2 * N - 1);
-    if (N < 2 || !pass_info(prec, (int)M, &pi)) return false;
+    if (N < 2 || M > 2048 || !pass_info(prec, (int)M, &pi)) return false;      // the Bluestein kernel has whole-tile configurations only
     a.bluestein = true; a.M = M;
     return true;
 }
@@ -171,7 +171,7 @@ static bool axis_plan_bluestein(int prec, size_t N, Axis &a)
     PassInfo pi;
     a.N = N;
     const size_t M = next_pow2(2 * N - 1);
-    if (N < 2 || !pass_info(prec, (int)M, &pi)) return false;
+    if (N < 2 || M > 2048 || !pass_info(prec, (int)M, &pi)) return false;      // the Bluestein kernel has whole-tile configurations only
     a.bluestein = true; a.M = M;
     return true;
 }
@@ -1339,13 +1339,13 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
     const bool zyx = zyx_kind && P1 > 1;
     if (P1 > MAXSEG || P2 > MAXSEG) return fail(ERR_UNSUPPORTED, "more than 32 ranks per exchange group");
     if ((size_t)P1 > Nx || (!zyx && (size_t)P1 > Ny) || (size_t)P2 > Ny) return fail(ERR_ARG, "partition larger than the grid");
-    // axis plans: native power-of-two chain (2..2048) or Bluestein (any length with 2N-1 <= 2048)
+    // axis plans: native chain (powers of two 2..8192, mixed-radix lengths up to 2048) or Bluestein (any length with 2N-1 <= 2048)
     {
         Axis az, ay, axx;
         const bool mixed = p->opt.native_mixed != 0;
         // packed real z pass: Nz/2-point complex transform + Hermitian split / merge (powers of two, and even lengths whose
         // half has a mixed-radix configuration)
-        const bool zr_native = !yzx && !c2c && Nz >= 4 && Nz <= 2048 && Nz % 2 == 0 && (is_pow2(Nz) || mixed) &&
+        const bool zr_native = !yzx && !c2c && Nz >= 4 && Nz <= 4096 && Nz % 2 == 0 && (is_pow2(Nz) || mixed) &&
                                (p->prec == DFFT_F64 ? real_supported_f64((int)(Nz / 2)) : real_supported_f32((int)(Nz / 2)));
         const size_t zlen = zr_native ? Nz / 2 : Nz;
         // Y_Then_ZX, R2C: the y pass reads real lines in place, which only the Bluestein kernel does
@@ -1359,7 +1359,7 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         const bool zok = zreal_generic ? axis_plan_bluestein(p->prec, Nz, az) : axis_plan(p->prec, zlen, az, mixed);
         if (!zok || !yok || !axis_plan(p->prec, Nx, axx, mixed))
             return fail(ERR_UNSUPPORTED, yzx && !c2c && Ny > 1024 ? "unsupported axis length (Y_Then_ZX R2C: powers of two up to 2048, other Ny up to 1024)"
-                        : "unsupported axis length (powers of two and the mixed-radix lengths of kernels_mixed.inc up to 2048, any other length up to 1024)");
+                        : "unsupported axis length (powers of two up to 8192 -- 4096 on the real axis of an R2C plan --, the mixed-radix lengths of kernels_mixed.inc up to 2048, any other length up to 1024)");
         for (auto &a : p->ax) axis_free(a);
         p->ax[0] = az; p->ax[1] = ay; p->ax[2] = axx;
         p->zreal_native = zr_native;

@@ -31,6 +31,9 @@ using F32_512_v5 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1, 0, 2>;
 using F32_2048_v4 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3, 1, 2>;
 using F32_2048_v5 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 2, 2>;
 using F32_2048_v6 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1>;
+// 4096 and 8192 points: sub-tile workgroups of 4 / 2 lines (see kernels_f64.hip), 512 threads, 64 KiB of LDS
+using F32_4096 = PassCfg<float, 4096, 32, 16, 1, 32, 16, 8, 1, 1, 1, 0, 0, 4>;
+using F32_8192 = PassCfg<float, 8192, 32, 16, 1, 32, 16, 16, 1, 1, 1, 0, 0, 8>;
 // A/B-only configurations of earlier measurements (sub-tile workgroups on tiled passes, nontemporal loads-only / stores-only,
 // whole-tile 64-point forms, 32-point fp64 2048, ...) were removed after they were measured: results in profiles/r2_*.txt and
 // DESIGN.md section 6, definitions in the git history (commit c38cf04).  New ones go here, under -DDFFT_EXPERIMENTS:
@@ -46,7 +49,7 @@ using F32_2048_v6 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1>;
 #endif
 #define DFFT_F32_LIST_SMALL(X) X(512, 6, F32_512_v6) X(512, 4, F32_512_v4) X(512, 5, F32_512_v5) X(2, 0, F32_2) X(4, 0, F32_4) X(8, 0, F32_8) X(16, 0, F32_16) X(32, 0, F32_32) X(64, 0, F32_64) X(128, 0, F32_128) X(256, 0, F32_256) X(512, 0, F32_512) DFFT_F32_EXP_SMALL(X)
 #define DFFT_F32_LIST_1024(X) X(1024, 4, F32_1024_v4) X(1024, 5, F32_1024_v5) X(1024, 6, F32_1024_v6) X(1024, 0, F32_1024) DFFT_F32_EXP_1024(X)
-#define DFFT_F32_LIST_2048(X) X(2048, 4, F32_2048_v4) X(2048, 5, F32_2048_v5) X(2048, 6, F32_2048_v6) X(2048, 0, F32_2048) DFFT_F32_EXP_2048(X)
+#define DFFT_F32_LIST_2048(X) X(2048, 4, F32_2048_v4) X(2048, 5, F32_2048_v5) X(2048, 6, F32_2048_v6) X(2048, 0, F32_2048) X(4096, 0, F32_4096) X(8192, 0, F32_8192) DFFT_F32_EXP_2048(X)
 
 // lengths that are not powers of two (mixed radix 2, 3, 5, 7): generated list, slices 5 (N < 512) and 6
 #define DFFT_MIXED_F32
@@ -117,6 +120,7 @@ bool real_supported_f32(int M)
     switch (M) {
 #define X(n, v, cfg) case n: return true;
         DFFT_F32_BASE(X)
+        X(2048, 0, F32_2048)
 #undef X
     }
     return false;
@@ -127,6 +131,7 @@ int launch_real_f32(int M, int mode, int variant, const PassArgs &A, hipStream_t
         if (A.load_kind == LOAD_KMAJOR && mode == 1) return -1;
         return M < 320 ? launch_real_mixed_f32_s7(M, mode, A, stream) : launch_real_mixed_f32_s8(M, mode, A, stream);
     }
+    if (M == 2048 && A.load_kind != LOAD_KMAJOR) return mode == 1 ? launch_real_cfg<F32_2048, 1, 1>(A, stream) : launch_real_cfg<F32_2048, 2>(A, stream);      // Nz = 4096
     if (mode == 1 && A.load_kind == LOAD_KMAJOR) {
         // strided real lines (Y_Then_ZX): the lanes run along the contiguous axis, i.e. the line-fastest mapping
         if (M == 512) return launch_real_cfg<F32_R512_32, 3, 1>(A, stream);

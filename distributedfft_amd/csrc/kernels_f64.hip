@@ -32,6 +32,13 @@ using F64_512_v1 = PassCfg<double, 512, 32, 8, 2, 32, 16, 1, 1, 1, 1>;
 using F64_512_v3 = PassCfg<double, 512, 16, 8, 1, 8, 8, 8, 1, 1, 0, 3>;
 using F64_2048_v3 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 3>;
 using F64_2048_v7 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 3, 0, 2>;
+// 4096 and 8192 points: a whole tile of 8 lines does not fit a CU, so a workgroup transforms 2 lines (4096) or 1 line
+// (8192) of a tile (PassCfg::SUB = 4 / 8; 64 KiB of LDS, two workgroups per CU) and its siblings -- consecutive logical
+// workgroups on one XCD -- the rest.  Natural lines are unaffected; a tiled side is accessed in 32- / 16-byte pieces that
+// L2 puts together: these lengths run for completeness (the reference takes any length, mpicufft_pencil_opt1.cpp:165-197),
+// not at the speed of the shorter ones.
+using F64_4096 = PassCfg<double, 4096, 16, 8, 1, 16, 16, 16, 1, 1, 1, 0, 0, 4>;
+using F64_8192 = PassCfg<double, 8192, 32, 8, 1, 32, 16, 16, 1, 1, 1, 0, 0, 8>;
 // A/B-only configurations of earlier measurements (sub-tile workgroups on tiled passes, nontemporal loads-only / stores-only,
 // whole-tile 64-point forms, 32-point fp64 2048, ...) were removed after they were measured: results in profiles/r2_*.txt and
 // DESIGN.md section 6, definitions in the git history (commit c38cf04).  New ones go here, under -DDFFT_EXPERIMENTS:
@@ -47,7 +54,7 @@ using F64_2048_v7 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 3, 0, 2>
 #endif
 #define DFFT_F64_LIST_SMALL(X) X(512, 1, F64_512_v1) X(512, 3, F64_512_v3) X(2, 0, F64_2) X(4, 0, F64_4) X(8, 0, F64_8) X(16, 0, F64_16) X(32, 0, F64_32) X(64, 0, F64_64) X(128, 0, F64_128) X(256, 0, F64_256) X(512, 0, F64_512) DFFT_F64_EXP_SMALL(X)
 #define DFFT_F64_LIST_1024(X) X(1024, 1, F64_1024_v1) X(1024, 3, F64_1024_v3) X(1024, 0, F64_1024) DFFT_F64_EXP_1024(X)
-#define DFFT_F64_LIST_2048(X) X(2048, 3, F64_2048_v3) X(2048, 7, F64_2048_v7) X(2048, 0, F64_2048) DFFT_F64_EXP_2048(X)
+#define DFFT_F64_LIST_2048(X) X(2048, 3, F64_2048_v3) X(2048, 7, F64_2048_v7) X(2048, 0, F64_2048) X(4096, 0, F64_4096) X(8192, 0, F64_8192) DFFT_F64_EXP_2048(X)
 
 // lengths that are not powers of two (mixed radix 2, 3, 5, 7): generated list, slices 5 (N < 512) and 6
 #define DFFT_MIXED_F64
@@ -99,6 +106,7 @@ bool real_supported_f64(int M)
     switch (M) {
 #define X(n, v, cfg) case n: return true;
         DFFT_F64_BASE(X)
+        X(2048, 0, F64_2048)
 #undef X
     }
     return false;
@@ -109,6 +117,8 @@ int launch_real_f64(int M, int mode, int variant, const PassArgs &A, hipStream_t
         if (A.load_kind == LOAD_KMAJOR && mode == 1) return -1;
         return M < 320 ? launch_real_mixed_f64_s7(M, mode, A, stream) : launch_real_mixed_f64_s8(M, mode, A, stream);
     }
+    // Nz = 4096: 8 lines x 2048 points fill the LDS with one plane, so the split runs one plane after the other
+    if (M == 2048 && A.load_kind != LOAD_KMAJOR) return mode == 1 ? launch_real_cfg<F64_2048, 1, 1>(A, stream) : launch_real_cfg<F64_2048, 2>(A, stream);
     if (variant == 0 && A.load_kind != LOAD_KMAJOR) {
         if (M == 512) return mode == 1 ? launch_real_cfg<F64_512, 1, 2>(A, stream) : launch_real_cfg<F64_512, 2, 2>(A, stream);
         if (M == 1024) return mode == 1 ? launch_real_cfg<F64_1024, 1, 2>(A, stream) : launch_real_cfg<F64_R1024_c2r, 2, 2>(A, stream);

@@ -38,6 +38,10 @@ def test_kernel_table():
             info = dfft.kernel_info(n, prec)
             assert info and info["threads"] <= 1024 and info["lds_bytes"] <= 160 * 1024
             assert info["lines_per_workgroup"] % (8 if prec == "double" else 16) == 0
+        for n in (4096, 8192):      # sub-tile workgroups: a few lines of a tile per workgroup
+            info = dfft.kernel_info(n, prec)
+            assert info and info["threads"] <= 512 and info["lds_bytes"] <= 80 * 1024
+            assert info["threads"] * info["points_per_thread"] == n * info["lines_per_workgroup"]
         # lengths 2^a 3^b 5^c 7^d with a configuration in csrc/kernels_mixed.inc run the native chain too
         inc = open(os.path.join(os.path.dirname(dfft.__file__), "csrc", "kernels_mixed.inc")).read()
         tag = "F64" if prec == "double" else "F32"
@@ -49,7 +53,7 @@ def test_kernel_table():
             assert info["threads"] * info["points_per_thread"] == n * info["lines_per_workgroup"], (n, info)
         # every other length runs through Bluestein on the next power of two >= 2N-1 (N <= 1024)
         assert dfft.kernel_info(3, prec)["points_per_thread"] == 8 and dfft.kernel_info(1023, prec)["threads"] > 0
-        assert dfft.kernel_info(4096, prec) is None and dfft.kernel_info(1025, prec) is None
+        assert dfft.kernel_info(16384, prec) is None and dfft.kernel_info(1025, prec) is None and dfft.kernel_info(4095, prec) is None
 
 
 def test_in_register_butterflies_on_the_host(tmp_path):

@@ -26,7 +26,7 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("prec", ["double", "float"])
-@pytest.mark.parametrize("N", [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048])
+@pytest.mark.parametrize("N", [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192])
 def test_fft1d_batched_vs_oracle(N, prec):
     """kernel-level: batched axis pass on natural lines, ragged batch (not a multiple of the
     lines-per-workgroup), both directions"""
@@ -62,7 +62,8 @@ def run_single(shape, prec, seed=5):
 
 @pytest.mark.parametrize("prec", ["double", "float"])
 @pytest.mark.parametrize("shape", [(8, 8, 8), (2, 4, 8), (16, 16, 16), (32, 16, 64), (64, 64, 64),
-                                   (16, 128, 32), (128, 128, 128), (256, 8, 512), (4, 1024, 16), (2048, 4, 4)])
+                                   (16, 128, 32), (128, 128, 128), (256, 8, 512), (4, 1024, 16), (2048, 4, 4),
+                                   (4096, 4, 6), (3, 8192, 20), (5, 4, 4096), (16, 20, 8192)])
 def test_single_rank_3d_vs_oracle(shape, prec):
     """fft3d branch (one rank): three local axis passes == oracle 3-D transform"""
     g, got, back = run_single(shape, prec)
@@ -111,7 +112,7 @@ def run_distributed(shape, P1, P2, prec, seed=7, chunks=None, options=None):
     return plans, [t.cpu().numpy() for t in ins], spec, [t.cpu().numpy() for t in backs]
 
 
-DIST = [((16, 16, 16), 2, 2), ((32, 32, 32), 2, 4), ((64, 32, 16), 4, 2), ((16, 16, 16), 3, 2),
+DIST = [((4096, 16, 8), 2, 2), ((8, 8192, 48), 3, 2), ((16, 16, 16), 2, 2), ((32, 32, 32), 2, 4), ((64, 32, 16), 4, 2), ((16, 16, 16), 3, 2),
         ((32, 16, 64), 2, 1), ((32, 64, 32), 8, 1), ((16, 32, 16), 1, 4), ((64, 64, 64), 3, 5),
         ((128, 64, 32), 2, 4)]
 
@@ -184,7 +185,7 @@ def run_distributed_real(shape, P1, P2, prec, field=None, seed=13, modify=None, 
 
 
 REAL = [((8, 8, 8), 1, 1), ((16, 16, 16), 1, 1), ((32, 16, 64), 1, 1), ((128, 128, 128), 1, 1),
-        ((4, 4, 2048), 1, 1), ((16, 8, 2048), 2, 2), ((8, 8, 1024), 1, 1), ((8, 16, 1024), 2, 2), ((16, 8, 512), 1, 2), ((16, 16, 16), 2, 2), ((32, 32, 32), 2, 4), ((64, 32, 16), 4, 2),
+        ((4, 4, 2048), 1, 1), ((4, 6, 4096), 1, 1), ((4, 512, 4096), 2, 2), ((16, 8, 2048), 2, 2), ((8, 8, 1024), 1, 1), ((8, 16, 1024), 2, 2), ((16, 8, 512), 1, 2), ((16, 16, 16), 2, 2), ((32, 32, 32), 2, 4), ((64, 32, 16), 4, 2),
         ((16, 16, 16), 3, 2), ((32, 16, 64), 2, 1), ((64, 64, 64), 3, 5), ((128, 64, 32), 2, 4)]
 
 
