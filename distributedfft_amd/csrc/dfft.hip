@@ -160,7 +160,7 @@ static bool axis_plan(int prec, size_t N, Axis &a, bool mixed = true)
     // native chain: powers of two 2..8192 and the mixed-radix lengths of kernels_mixed.inc (2^a 3^b 5^c 7^d <= 2048)
     if ((is_pow2(N) || mixed) && N <= 8192 && pass_info(prec, (int)N, &pi)) { a.bluestein = false; a.M = N; return true; }
     const size_t M = next_pow2(2 * N - 1);
-    if (N < 2 || M > 2048 || !pass_info(prec, (int)M, &pi)) return false;      // the Bluestein kernel has whole-tile configurations only
+    if (N < 2 || M > 8192 || !pass_info(prec, (int)M, &pi)) return false;
     a.bluestein = true; a.M = M;
     return true;
 }
@@ -171,7 +171,7 @@ static bool axis_plan_bluestein(int prec, size_t N, Axis &a)
     PassInfo pi;
     a.N = N;
     const size_t M = next_pow2(2 * N - 1);
-    if (N < 2 || M > 2048 || !pass_info(prec, (int)M, &pi)) return false;      // the Bluestein kernel has whole-tile configurations only
+    if (N < 2 || M > 8192 || !pass_info(prec, (int)M, &pi)) return false;
     a.bluestein = true; a.M = M;
     return true;
 }
@@ -1339,7 +1339,7 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
     const bool zyx = zyx_kind && P1 > 1;
     if (P1 > MAXSEG || P2 > MAXSEG) return fail(ERR_UNSUPPORTED, "more than 32 ranks per exchange group");
     if ((size_t)P1 > Nx || (!zyx && (size_t)P1 > Ny) || (size_t)P2 > Ny) return fail(ERR_ARG, "partition larger than the grid");
-    // axis plans: native chain (powers of two 2..8192, mixed-radix lengths up to 2048) or Bluestein (any length with 2N-1 <= 2048)
+    // axis plans: native chain (powers of two 2..8192, mixed-radix lengths up to 2048) or Bluestein (any length with 2N-1 <= 8192)
     {
         Axis az, ay, axx;
         const bool mixed = p->opt.native_mixed != 0;
@@ -1359,7 +1359,7 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         const bool zok = zreal_generic ? axis_plan_bluestein(p->prec, Nz, az) : axis_plan(p->prec, zlen, az, mixed);
         if (!zok || !yok || !axis_plan(p->prec, Nx, axx, mixed))
             return fail(ERR_UNSUPPORTED, yzx && !c2c && Ny > 1024 ? "unsupported axis length (Y_Then_ZX R2C: powers of two up to 2048, other Ny up to 1024)"
-                        : "unsupported axis length (powers of two up to 8192 -- 4096 on the real axis of an R2C plan --, the mixed-radix lengths of kernels_mixed.inc up to 2048, any other length up to 1024)");
+                        : "unsupported axis length (powers of two up to 8192 -- 4096 on the real axis of an R2C plan --, any other length up to 4096)");
         for (auto &a : p->ax) axis_free(a);
         p->ax[0] = az; p->ax[1] = ay; p->ax[2] = axx;
         p->zreal_native = zr_native;

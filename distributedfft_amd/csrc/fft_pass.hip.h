@@ -1325,9 +1325,18 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_bluestein_kernel(const PassA
     R *lds = reinterpret_cast<R *>(smem);
     const int tid = threadIdx.x;
     const int lw = tid % TW, t = tid / TW;
-    const int g = lw / TL, l = lw % TL;
-    static_assert(Cfg::kSUB == 1, "sub-tile workgroups: fft_pass_kernel only");
-    const uint32_t w = logical_block<>(A) * Cfg::kG + g;
+    // tile and line of this thread; sub-tile workgroups (inner transforms of 4096 / 8192 points): lines
+    // [sub*TLK, sub*TLK + TLK) of tile blk / SUB, as in fft_pass_kernel
+    uint32_t w;
+    int l;
+    if constexpr (Cfg::kSUB > 1) {
+        const uint32_t blk = logical_block<true>(A);
+        w = blk / Cfg::kSUB;
+        l = (int)(blk % Cfg::kSUB) * Cfg::TLK + lw;
+    } else {
+        w = logical_block<>(A) * Cfg::kG + lw / TL;
+        l = lw % TL;
+    }
     const bool tile_ok = w < A.ntiles;
     TileCtx<TL> tc;
     tc.a = !tile_ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);

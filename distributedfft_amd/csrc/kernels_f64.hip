@@ -147,6 +147,8 @@ int launch_bluestein_f64(int M, const PassArgs &A, hipStream_t stream)
 #define X(n, v, cfg) case n: return launch_bluestein_cfg<cfg>(A, stream);
         DFFT_F64_BASE(X)
         X(2048, 0, F64_2048)
+        X(4096, 0, F64_4096)      // lines of 1025..2048 / 2049..4096 points: inner transforms on sub-tile workgroups
+        X(8192, 0, F64_8192)
 #undef X
     }
     return -1;

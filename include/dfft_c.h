@@ -108,7 +108,7 @@ int dfft_plan_destroy(dfft_plan *plan);
  * src/pencil/mpicufft_pencil_opt1.cpp:46-326, src/slab/default/mpicufft_slab.cpp:97-281.
  * P1*P2 must equal the number of ranks.  Axis lengths: powers of two up to 8192 (4096 on the real axis of an R2C
  * plan) and the lengths 2^a 3^b 5^c 7^d <= 2048 listed in csrc/kernels_mixed.inc (native chain), or any other length
- * up to 1024 (Bluestein).  c2c = 0: R2C/C2R plan (Nz_out = Nz/2+1,
+ * up to 4096 (Bluestein).  c2c = 0: R2C/C2R plan (Nz_out = Nz/2+1,
  * include/params.hpp:30); c2c = 1: complex plan (Nz_out = Nz). */
 int dfft_init(dfft_plan *plan, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int c2c, int allocate);
 /* setWorkArea(void *device, void *host)   mpicufft_pencil_opt1.cpp:329-387.  NULL device =

@@ -51,9 +51,10 @@ def test_kernel_table():
             info = dfft.kernel_info(n, prec)
             assert info and info["threads"] <= 1024 and info["lds_bytes"] <= 160 * 1024
             assert info["threads"] * info["points_per_thread"] == n * info["lines_per_workgroup"], (n, info)
-        # every other length runs through Bluestein on the next power of two >= 2N-1 (N <= 1024)
+        # every other length runs through Bluestein on the next power of two >= 2N-1 (N <= 4096)
         assert dfft.kernel_info(3, prec)["points_per_thread"] == 8 and dfft.kernel_info(1023, prec)["threads"] > 0
-        assert dfft.kernel_info(16384, prec) is None and dfft.kernel_info(1025, prec) is None and dfft.kernel_info(4095, prec) is None
+        assert dfft.kernel_info(1025, prec)["threads"] > 0 and dfft.kernel_info(4095, prec)["threads"] > 0
+        assert dfft.kernel_info(16384, prec) is None and dfft.kernel_info(4097, prec) is None
 
 
 def test_in_register_butterflies_on_the_host(tmp_path):
@@ -176,7 +177,7 @@ def test_init_errors():
     with pytest.raises(dfft.DfftError, match="Invalid Input Partition"):
         pl.initFFT(dfft.GlobalSize(16, 16, 16), dfft.Slab_Partition(2), allocate=False)
     with pytest.raises(dfft.DfftError, match="unsupported"):
-        pl.initFFT(dfft.GlobalSize(16, 16, 3000), dfft.Slab_Partition(1), allocate=False, c2c=True)
+        pl.initFFT(dfft.GlobalSize(16, 16, 5000), dfft.Slab_Partition(1), allocate=False, c2c=True)
     world = dfft.Comm.local(4)
     ps = dfft.MPIcuFFT_Slab_Opt1(dfft.Configurations(), world, rank=0)
     with pytest.raises(dfft.DfftError, match="slab"):

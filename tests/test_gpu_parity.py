@@ -322,7 +322,8 @@ def test_partial_dimension_transforms(shape, P1, P2, d, c2c):
 # arbitrary lengths (the reference accepts any size through cuFFT): Bluestein passes
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("prec", ["double", "float"])
-@pytest.mark.parametrize("N", [3, 5, 6, 7, 9, 10, 12, 15, 17, 30, 100, 127, 243, 250, 384, 500, 1000, 1023])
+@pytest.mark.parametrize("N", [3, 5, 6, 7, 9, 10, 12, 15, 17, 30, 100, 127, 243, 250, 384, 500, 1000, 1023, 1025, 1500, 2047,
+                               2049, 3000, 4095])
 def test_fft1d_any_length_vs_oracle(N, prec):
     """variant -1 = the Bluestein kernel for every length (also those that have a native mixed-radix configuration)"""
     batch = 45
@@ -416,7 +417,8 @@ def test_mixed_radix_grids_vs_oracle_and_bluestein(shape, P1, P2, prec):
             assert np.max(np.abs(spec[r] - spec_b[r])) / np.max(np.abs(want)) < tol_f
 
 
-@pytest.mark.parametrize("shape", [(12, 10, 14), (9, 7, 10), (30, 16, 50), (100, 3, 24), (5, 384, 6)])
+@pytest.mark.parametrize("shape", [(12, 10, 14), (9, 7, 10), (30, 16, 50), (100, 3, 24), (5, 384, 6), (1031, 6, 9), (4, 2500, 10),
+                                   (3, 5, 4095)])
 def test_single_rank_any_size_vs_oracle_and_golden(shape):
     g, got, back = run_single(shape, "double", seed=20260921)
     want = orc.fft3d_c2c(g, -1)
@@ -427,7 +429,8 @@ def test_single_rank_any_size_vs_oracle_and_golden(shape):
         assert rel(got, d["c2c_12x10x14"]) < 2e-11
 
 
-@pytest.mark.parametrize("shape,P1,P2", [((12, 10, 14), 2, 4), ((9, 7, 10), 3, 2), ((10, 9, 12), 3, 1), ((30, 20, 18), 2, 3)])
+@pytest.mark.parametrize("shape,P1,P2", [((12, 10, 14), 2, 4), ((9, 7, 10), 3, 2), ((10, 9, 12), 3, 1), ((30, 20, 18), 2, 3),
+                                         ((6, 1100, 2310), 2, 2)])
 def test_distributed_any_size_c2c_and_r2c(shape, P1, P2):
     """the uneven, non-power-of-two grids the survey replayed, C2C and R2C
     (R2C with odd and even Nz: Hermitian half via the real Bluestein modes)"""
