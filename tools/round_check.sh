@@ -29,7 +29,9 @@ prof f64_multirank $K --size 1024 --prec f64 --iters 5 --opt mirror_inverse=1 --
 prof f64_r2c $K --size 1024 --prec f64 --mode r2c --iters 5
 prof f32_r2c $K --size 1024 --prec f32 --mode r2c --iters 5
 prof f32_c2c $K --size 1024 --prec f32 --iters 5
-prof f64_bluestein1000 $K --size 1000 --prec f64 --iters 3
+prof f64_bluestein1000 $K --size 1000 --prec f64 --iters 3 --opt native_mixed=0
+prof f64_mixed1000 $K --size 1000 --prec f64 --iters 3
+prof f64_mixed1000_r2c $K --size 1000 --prec f64 --mode r2c --iters 3
 {
   echo "== c2c fp64 1024";                 $K --size 1024 --prec f64 --iters 5 --check
   echo "== c2c fp64 1024 multi-rank path"; $K --size 1024 --prec f64 --iters 5 --check --opt mirror_inverse=1 --opt pipeline_chunks=8
@@ -45,11 +47,17 @@ prof f64_bluestein1000 $K --size 1000 --prec f64 --iters 3
     echo "== c2c fp64 $sz";                $K --size $sz --prec f64 --iters 3 --check
     echo "== c2c fp64 $sz multi-rank path"; $K --size $sz --prec f64 --iters 3 --opt mirror_inverse=1
   done
-  echo "== Bluestein 1000^3 fp64";         $K --size 1000 --prec f64 --iters 3 --check
+  echo "== Bluestein 1000^3 fp64";         $K --size 1000 --prec f64 --iters 3 --check --opt native_mixed=0
+  echo "== mixed radix 1000^3 fp64";       $K --size 1000 --prec f64 --iters 5 --check
+  echo "== mixed radix 1000^3 fp64 r2c";   $K --size 1000 --prec f64 --mode r2c --iters 5 --check
+  echo "== mixed radix 1000^3 fp32";       $K --size 1000 --prec f32 --iters 5 --check
+  echo "== mixed radix 1536^3 fp32";       $K --size 1536 --prec f32 --iters 3 --check
+  echo "== 4096-point lines fp64";         for sz in 256x256x4096 256x4096x256 4096x256x256; do $K --size $sz --prec f64 --iters 5 --check; done
+  echo "== Bluestein 1500-point lines";    $K --size 256x1500x256 --prec f64 --iters 5 --check
   for n in 128 256 512; do echo "== r2c fp64 $n^3 (wall = latency)"; $K --size $n --prec f64 --mode r2c --iters 20; done
   echo "== c2c fp64 256^3 (C2), 512^3";    $K --size 256 --prec f64 --iters 20 --check; $K --size 512 --prec f64 --iters 10 --check
 } > $OUT/${TAG}_phase_times.txt 2>&1
-grep -E "^==|^PLAN|FFT" $OUT/${TAG}_phase_times.txt | head -150
+grep -E "^==|^PLAN|FFT" $OUT/${TAG}_phase_times.txt | head -220
 # PMC: LDS conflicts / activity of the 2048-point fp32 passes and the fp64 R2C passes (separate passes, kernel-trace only)
 bash tools/pmc_quick.sh ${TAG}_f32_2048 -- $K --size 2048 --prec f32 --iters 1 > /dev/null 2>&1
 bash tools/pmc_quick.sh ${TAG}_f64_r2c -- $K --size 1024 --prec f64 --mode r2c --iters 1 > /dev/null 2>&1
