@@ -410,11 +410,13 @@ def main():
     # HBM bytes per launch: NOT measured by this run.  It is the figure of the committed PMC profile of this kernel
     # on this workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 read correction applied)
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-        if ngpus == 1 and N == 1024 and prec == "double":
+        # newest committed PMC run of the headline kernel (tools/pmc_traffic.sh + tools/pmc_traffic.py)
+        pmc = [f for f in ("r2_pmc_traffic.json", "r1_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+        pm = json.load(open(os.path.join(ROOT, "profiles", pmc)))
+        if ngpus == 1 and N == 1024 and prec == "double" and pm.get("hbm_bytes_per_launch"):
             roofline["traffic"] = pm["hbm_bytes_per_launch"]
             roofline["traffic_static"] = True
-            roofline["traffic_source"] = "profiles/r1_pmc_traffic.json (a committed rocprofv3 PMC run, not this run)"
+            roofline["traffic_source"] = f"profiles/{pmc} (a committed rocprofv3 PMC run, not this run)"
     except Exception:   # noqa: BLE001
         pass
 

@@ -63,3 +63,10 @@ bash tools/pmc_quick.sh ${TAG}_f32_2048 -- $K --size 2048 --prec f32 --iters 1 >
 bash tools/pmc_quick.sh ${TAG}_f64_r2c -- $K --size 1024 --prec f64 --mode r2c --iters 1 > /dev/null 2>&1
 python tools/pmc_summary.py $R/gpurun_out/pmcq_${TAG}_f32_2048 fft_ > $OUT/${TAG}_pmc_f32_2048.txt 2>&1
 python tools/pmc_summary.py $R/gpurun_out/pmcq_${TAG}_f64_r2c fft_ > $OUT/${TAG}_pmc_f64_r2c.txt 2>&1
+# HBM traffic per launch of the headline kernel (FETCH_SIZE / WRITE_SIZE, separate passes) -> the json bench.py quotes
+bash tools/pmc_traffic.sh ${TAG}_f64_1024 -- $K --size 1024 --prec f64 --iters 2 > /dev/null 2>&1
+python tools/pmc_traffic.py $R/gpurun_out/pmct_${TAG}_f64_1024 34359738368 "1024^3 fp64 complex, one axis pass per launch (tools/kbench --size 1024 --prec f64)" > $OUT/${TAG}_pmc_traffic.json 2>&1
+cat $OUT/${TAG}_pmc_traffic.json
+bash tools/pmc_traffic.sh ${TAG}_f64_1000 -- $K --size 1000 --prec f64 --iters 2 > /dev/null 2>&1
+python tools/pmc_traffic.py $R/gpurun_out/pmct_${TAG}_f64_1000 32000000000 "1000^3 fp64 complex (mixed radix), one axis pass per launch" > $OUT/${TAG}_pmc_traffic_mixed1000.json 2>&1
+cat $OUT/${TAG}_pmc_traffic_mixed1000.json
