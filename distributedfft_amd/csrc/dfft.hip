@@ -1350,7 +1350,7 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         const size_t zlen = zr_native ? Nz / 2 : Nz;
         // Y_Then_ZX, R2C: the y pass reads real lines in place, which only the Bluestein kernel does
         // Y_Then_ZX, R2C: the y pass reads real lines in place.  Power-of-two Ny: the packed Ny/2-point real kernel
-        // with its strided-line load; any other Ny: the Bluestein kernel's real mode (Ny <= 1024)
+        // with its strided-line load; any other Ny: the Bluestein kernel's real mode (Ny <= 4096)
         const bool yr_native = yzx && !c2c && is_pow2(Ny) && Ny >= 4 && Ny <= 2048;
         const bool yok = yr_native ? axis_plan(p->prec, Ny / 2, ay) : yzx && !c2c ? axis_plan_bluestein(p->prec, Ny, ay) : axis_plan(p->prec, Ny, ay, mixed);
         // a real z pass is either the packed Nz/2-point kernel or the Bluestein kernel's real modes: never
@@ -1358,7 +1358,7 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         const bool zreal_generic = !yzx && !c2c && !zr_native;
         const bool zok = zreal_generic ? axis_plan_bluestein(p->prec, Nz, az) : axis_plan(p->prec, zlen, az, mixed);
         if (!zok || !yok || !axis_plan(p->prec, Nx, axx, mixed))
-            return fail(ERR_UNSUPPORTED, yzx && !c2c && Ny > 1024 ? "unsupported axis length (Y_Then_ZX R2C: powers of two up to 2048, other Ny up to 1024)"
+            return fail(ERR_UNSUPPORTED, yzx && !c2c && Ny > 2048 ? "unsupported axis length (Y_Then_ZX R2C: Ny up to 4096)"
                         : "unsupported axis length (powers of two up to 8192 -- 4096 on the real axis of an R2C plan --, any other length up to 4096)");
         for (auto &a : p->ax) axis_free(a);
         p->ax[0] = az; p->ax[1] = ay; p->ax[2] = axx;

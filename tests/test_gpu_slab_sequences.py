@@ -225,8 +225,8 @@ def test_y_then_zx_pipeline_depths_tables_and_errors(chunks):
     with pytest.raises(dfft.DfftError, match="forward only"):
         plans[0].execC2R(1, 1)
     one = dfft.MPIcuFFT_Slab_Y_Then_ZX(dfft.Configurations())
-    with pytest.raises(dfft.DfftError, match="Ny up to 1024"):      # not a power of two and beyond the Bluestein kernel
-        one.initFFT(dfft.GlobalSize(16, 1536, 16), dfft.Slab_Partition(1), True)
+    with pytest.raises(dfft.DfftError, match="Ny up to 4096"):      # not a power of two and beyond the Bluestein kernel
+        one.initFFT(dfft.GlobalSize(16, 5000, 16), dfft.Slab_Partition(1), True)
 
 
 @pytest.mark.parametrize("prec", ["double", "float"])
@@ -241,6 +241,19 @@ def test_y_then_zx_long_power_of_two_real_lines(shape, P, prec):
         s, o = pl.getOutSize(), pl.getOutStart()
         err = np.max(np.abs(spec[r] - want[:, o[1]:o[1] + s[1], :])) / scale
         assert err < (1e-11 if prec == "double" else 1e-4), err
+
+
+@pytest.mark.parametrize("shape,P", [((16, 1536, 16), 2), ((8, 1100, 24), 1), ((6, 3001, 16), 3)])
+def test_y_then_zx_long_real_lines_through_bluestein(shape, P):
+    """Ny that is not a power of two: the Bluestein kernel's real mode on strided lines, inner transforms of up to 8192
+    points (sub-tile workgroups) for Ny up to 4096"""
+    plans, spec = run_yzx(shape, P, "double", False)
+    g = global_input(shape, False, "double", seed=33)
+    want = orc.fft3d_c2c(np.ascontiguousarray(g.astype(np.complex128)), -1)[:, :shape[1] // 2 + 1, :]
+    scale = np.max(np.abs(want))
+    for r, pl in enumerate(plans):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        assert np.max(np.abs(spec[r] - want[:, o[1]:o[1] + s[1], :])) / scale < 2e-11
 
 
 def test_y_then_zx_256_cube_four_ranks_every_point():

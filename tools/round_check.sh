@@ -18,7 +18,8 @@ prof() {  # name, command...: rocprofv3 kernel trace + stats of a command, stats
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o $name -- "$@" > $OUT/prof_$name.log 2>&1 )
   find $OUT/prof_$name -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_${name}_kernel_stats.csv \;
 }
-prof bench python $R/bench.py --no-cpu-baseline
+# every axis-pass launch of this command is one full pass (the multi-rank leg, whose launches are 1/8 passes, is profiled separately below)
+prof bench python $R/bench.py --no-cpu-baseline --no-multi-rank-path
 python bench.py --size 2048 --precision float --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_f32_2048.json 2> $OUT/bench_f32_2048.err; tail -c 300 $OUT/bench_f32_2048.json; echo
 prof f32_2048 $K --size 2048 --prec f32 --iters 3
 prof f32_2048_multirank $K --size 2048 --prec f32 --iters 3 --opt mirror_inverse=1 --opt pipeline_chunks=8
