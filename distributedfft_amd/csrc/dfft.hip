@@ -251,6 +251,10 @@ struct Options {
                              // -1 = by measurement: z, x, y where it won (fp32 with x and y lines of 2048 points or more)
     int single_layout = 1;   // L2 of the z, x, y order: 0 = [kx][kz/TL][y][l], 1 = tile-outer [kz/TL][kx][y][l]
     int single_pad = 128;    // bytes added to every L2 row (a row stride that is an odd multiple of 128 B; 0 = packed)
+    int graph = 0;           // 1: single-rank plans replay the launches of an exec as one hipGraph from the second call with the same
+                             // buffers on.  Off by default -- measured (profiles/r2_graph_latency.txt): a blocking 64^3 R2C takes 28 us
+                             // with three plain launches and 34 us as a graph, 128^3 54 vs 60 us; the launches are already hidden
+                             // behind the first kernel (128^3: 50 us of kernels in a 54 us call)
     int native_mixed = 1;    // lengths 2^a 3^b 5^c 7^d with a configuration run the native chain (0: Bluestein, for A/B runs and tests)
     int order[6] = {-1, -1, -1, -1, -1, -1};     // workgroup->tile order per pass: fz fy fx ix iy iz; a_fastest + 2*xcd_swizzle
     int variant[6] = {-1, -1, -1, -1, -1, -1};   // kernel configuration per pass, same order (-1 = the plan's choice)
@@ -291,6 +295,9 @@ struct dfft_plan {
     std::vector<TimedSpan> spans;
     size_t nspans = 0;
     int last_dir = -1;
+    // hipGraph replay of single-rank execs (launch-bound small grids): one instantiated graph per (operation, in, out)
+    struct GraphEntry { int kind; const void *in; void *out; int uses; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -900,7 +907,7 @@ static int enqueue_forward(dfft_plan *p, void *out, const void *in)
     hipStream_t Sm2 = (pl.comm_stream2 && p->comm && p->comm->concurrent_channels()) ? pl.comm_stream2 : Sm;
     p->nspans = 0; p->last_dir = DFFT_FORWARD;
     // event ids: [0,C) z done, [C,2C) ex1 done, [2C,3C) y done, [3C,4C) ex2 done, 4C = entry fence
-    if (p->comm) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); if (Sm2 != Sm) EV_WAIT(4 * C, Sm2); }   // comm streams start after prior work
+    if (p->comm && p->nranks > 1) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); if (Sm2 != Sm) EV_WAIT(4 * C, Sm2); }   // comm streams start after prior work
     auto zpass = [&](int c) -> int {
         TRY(span_begin(p, 0, Sc));
         if (p->c2c) TRY(launch(p, pl.fz[c], p->vfwd[0], 0, I, zdst));
@@ -982,7 +989,7 @@ static int enqueue_inverse(dfft_plan *p, void *out, void *in)
         TRY(span_end(p, Sc));
         return 0;
     }
-    if (p->comm) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); if (Sm2 != Sm) EV_WAIT(4 * C, Sm2); }
+    if (p->comm && p->nranks > 1) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); if (Sm2 != Sm) EV_WAIT(4 * C, Sm2); }
     for (int c = 0; c < C; c++) {
         TRY(span_begin(p, 0, Sc));
         TRY(launch(p, pl.ix[c], p->vinv[2], 2, I, xdst));
@@ -1149,7 +1156,7 @@ static int enqueue_partial_forward(dfft_plan *p, void *out, const void *in, int 
         return launch_real(p, pl.pz1, 1, I, O);
     }
     char *zdst = W, *ysrc = p->P2 > 1 ? W + p->domainsize : W;
-    if (p->comm) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); }
+    if (p->comm && p->nranks > 1) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); }
     for (int c = 0; c < C; c++) {
         if (p->c2c) TRY(launch(p, pl.fz[c], p->vfwd[0], 0, I, zdst));
         else TRY(launch_real(p, pl.fz[c], 1, I, zdst));
@@ -1178,7 +1185,7 @@ static int enqueue_partial_inverse(dfft_plan *p, void *out, void *in, int d)
         return launch_real(p, pl.qz1, 2, I, O);
     }
     char *ydst = W, *zsrc = p->P2 > 1 ? W + p->domainsize : W;
-    if (p->comm) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); }
+    if (p->comm && p->nranks > 1) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); }
     for (int c = 0; c < C; c++) {
         TRY(launch(p, pl.qy2[c], p->vinv[1], 1, I, ydst));
         if (p->P2 > 1) {
@@ -1193,6 +1200,53 @@ static int enqueue_partial_inverse(dfft_plan *p, void *out, void *in, int d)
         else TRY(launch_real(p, pl.iz[c], 2, zsrc, O));
     }
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// hipGraph replay (option "graph", off by default).  A single-rank exec is a handful of kernel launches on one stream.
+// The first exec with a given (operation, in, out) runs plainly (lazy per-kernel attribute setup stays outside any
+// capture), the second is captured into a graph, later ones replay it with one hipGraphLaunch.  Anything that changes the
+// launches (dfft_init, dfft_set_work_area, dfft_set_stream, options, phase timing) drops the cached graphs.
+// Measured on ROCm 7.2 / MI355X the replay is 6-8 us SLOWER per exec than the three plain launches it replaces
+// (profiles/r2_graph_latency.txt), so it is not the default; it stays for callers that submit from a congested host thread.
+// ------------------------------------------------------------------------------------------
+static void graphs_clear(dfft_plan *p)
+{
+    for (auto &g : p->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    p->graphs.clear();
+}
+template <typename F> static int run_graphed(dfft_plan *p, int kind, const void *in, void *out, F &&enqueue)
+{
+    if (!p->opt.graph || p->nranks != 1 || p->timing || !p->stream) return enqueue();
+    dfft_plan::GraphEntry *e = nullptr;
+    for (auto &g : p->graphs) if (g.kind == kind && g.in == in && g.out == out) { e = &g; break; }
+    if (e && e->exec) { HIP_TRY(hipGraphLaunch(e->exec, p->stream)); return 0; }
+    if (!e) {
+        if (p->graphs.size() >= 16) graphs_clear(p);
+        p->graphs.push_back({kind, in, out, 0, nullptr});
+        e = &p->graphs.back();
+    }
+    if (e->uses < 0 || ++e->uses < 2) return enqueue();
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        e->uses = -1;                      // this stream cannot be captured: plain launches from now on
+        return enqueue();
+    }
+    const int r = enqueue();
+    const hipError_t ce = hipStreamEndCapture(p->stream, &graph);
+    hipGraphExec_t exec = nullptr;
+    if (r == 0 && ce == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        e->exec = exec;
+        HIP_TRY(hipGraphLaunch(exec, p->stream));
+        return 0;
+    }
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    e->uses = -1;
+    if (r != 0) return r;                  // the enqueue itself failed: report that
+    return enqueue();                      // nothing ran during the failed capture
 }
 
 static int check_ready(dfft_plan *p)
@@ -1289,6 +1343,7 @@ static int *option_slot(Options &o, const std::string &k)
     if (k == "single_layout") return &o.single_layout;
     if (k == "single_pad") return &o.single_pad;
     if (k == "native_mixed") return &o.native_mixed;
+    if (k == "graph") return &o.graph;
     for (int i = 0; i < 6; i++) {
         if (k == std::string("variant_") + kPassNames[i]) return &o.variant[i];
         if (k == std::string("order_") + kPassNames[i]) return &o.order[i];
@@ -1301,6 +1356,7 @@ int dfft_set_option(dfft_plan *p, const char *key, long value)
     int *slot = option_slot(p->opt, key);
     if (!slot) return fail(ERR_ARG, std::string("unknown option ") + key);
     *slot = (int)value;      // takes effect at the next dfft_init (debug_skip / mirror_inverse / real_variant: next exec)
+    graphs_clear(p);         // captured launches carry the old options
     return 0;
 }
 long dfft_get_option(dfft_plan *p, const char *key)
@@ -1313,6 +1369,7 @@ long dfft_get_option(dfft_plan *p, const char *key)
 int dfft_plan_destroy(dfft_plan *p)
 {
     if (!p) return 0;
+    graphs_clear(p);
     if (p->work_owned && p->work_d) (void)hipFree(p->work_d);
     for (auto &a : p->ax) axis_free(a);
     for (void *t : {p->tw_zr, p->tables_d}) if (t) (void)hipFree(t);
@@ -1329,6 +1386,7 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
 {
     if (!p) return fail(ERR_ARG, "null plan");
     p->initialized = false;      // a failed (re-)initialisation must not leave a half-updated plan executable
+    graphs_clear(p);
     if (!Nx || !Ny || !Nz) return fail(ERR_ARG, "GlobalSize not initialized!");
     if (P1 < 1 || P2 < 1 || P1 * P2 != p->nranks) return fail(ERR_ARG, "Invalid Input Partition!");
     const bool zyx_kind = p->kind == DFFT_SLAB_Z_THEN_YX || p->kind == DFFT_SLAB_Z_THEN_YX_OPT1;
@@ -1564,6 +1622,7 @@ int dfft_set_work_area(dfft_plan *p, void *device, void *host)
     (void)host;   // no host staging: device buffers are handed to the transport directly
     if (!p) return fail(ERR_ARG, "null plan");
     if (!p->initialized) return fail(ERR_STATE, "cannot set work area: plan not initialised");
+    graphs_clear(p);
     if (p->work_owned && p->work_d) { (void)hipFree(p->work_d); p->work_d = nullptr; p->work_owned = false; }
     TRY(ensure_device_state(p));
     if (device) {
@@ -1587,6 +1646,7 @@ int dfft_get_pipeline_chunks(const dfft_plan *p) { return p ? p->pl.C : 0; }
 int dfft_set_stream(dfft_plan *p, void *hip_stream)
 {
     if (!p) return fail(ERR_ARG, "null plan");
+    graphs_clear(p);
     if (p->stream_owned && p->stream) (void)hipStreamDestroy(p->stream);
     p->stream = (hipStream_t)hip_stream;
     p->stream_owned = false;
@@ -1599,8 +1659,8 @@ int dfft_enqueue_c2c(dfft_plan *p, void *out, void *in, int direction)
     TRY(check_ready(p));
     if (!p->c2c) return fail(ERR_STATE, "plan was initialised for R2C/C2R");
     if (!out || !in) return fail(ERR_ARG, "null buffer");
-    if (direction == DFFT_FORWARD) return enqueue_forward(p, out, in);
-    if (direction == DFFT_INVERSE) return enqueue_inverse(p, out, in);
+    if (direction == DFFT_FORWARD) return run_graphed(p, 0, in, out, [&]() { return enqueue_forward(p, out, in); });
+    if (direction == DFFT_INVERSE) return run_graphed(p, 1, in, out, [&]() { return enqueue_inverse(p, out, in); });
     return fail(ERR_ARG, "direction must be DFFT_FORWARD or DFFT_INVERSE");
 }
 
@@ -1618,8 +1678,11 @@ int dfft_exec_dim(dfft_plan *p, void *out, void *in, int direction, int d)
     if (d < 1 || d > 3) return fail(ERR_ARG, "d must be 1, 2 or 3");
     if (direction != DFFT_FORWARD && direction != DFFT_INVERSE) return fail(ERR_ARG, "bad direction");
     if ((p->zyx || p->yzx) && d != 3) return fail(ERR_UNSUPPORTED, "partial transforms are not defined for the Z_Then_YX / Y_Then_ZX sequences");
-    if (d == 3) TRY(direction == DFFT_FORWARD ? enqueue_forward(p, out, in) : enqueue_inverse(p, out, in));
-    else TRY(direction == DFFT_FORWARD ? enqueue_partial_forward(p, out, in, d) : enqueue_partial_inverse(p, out, in, d));
+    const int kind = 2 * d + (direction == DFFT_INVERSE ? 1 : 0) + 8;
+    TRY(run_graphed(p, kind, in, out, [&]() {
+        if (d == 3) return direction == DFFT_FORWARD ? enqueue_forward(p, out, in) : enqueue_inverse(p, out, in);
+        return direction == DFFT_FORWARD ? enqueue_partial_forward(p, out, in, d) : enqueue_partial_inverse(p, out, in, d);
+    }));
     HIP_TRY(hipStreamSynchronize(p->stream));
     return 0;
 }
@@ -1646,7 +1709,7 @@ int dfft_exec_r2c(dfft_plan *p, void *out, const void *in)
     TRY(check_ready(p));
     if (p->c2c) return fail(ERR_STATE, "plan was initialised for C2C");
     if (!out || !in) return fail(ERR_ARG, "null buffer");
-    TRY(enqueue_forward(p, out, in));
+    TRY(run_graphed(p, 2, in, out, [&]() { return enqueue_forward(p, out, in); }));
     HIP_TRY(hipStreamSynchronize(p->stream));
     return 0;
 }
@@ -1655,7 +1718,7 @@ int dfft_exec_c2r(dfft_plan *p, void *out, void *in)
     TRY(check_ready(p));
     if (p->c2c) return fail(ERR_STATE, "plan was initialised for C2C");
     if (!out || !in) return fail(ERR_ARG, "null buffer");
-    TRY(enqueue_inverse(p, out, in));
+    TRY(run_graphed(p, 3, in, out, [&]() { return enqueue_inverse(p, out, in); }));
     HIP_TRY(hipStreamSynchronize(p->stream));
     return 0;
 }
@@ -1815,6 +1878,7 @@ int dfft_enable_phase_timing(dfft_plan *p, int enable)
 {
     if (!p) return fail(ERR_ARG, "null plan");
     p->timing = enable != 0;
+    graphs_clear(p);
     return 0;
 }
 int dfft_get_phase_times(dfft_plan *p, float *ms, int max_entries)

@@ -132,6 +132,9 @@ int dfft_get_pipeline_chunks(const dfft_plan *plan);
  *   "single_order"     one rank, complex plan: 1 = pass order z, x, y through a padded private layout, 0 = z, y, x, -1 (default)
  *                      = where it measured faster (env default DFFT_SINGLE_ORDER); "single_layout" (0 | 1) and "single_pad"
  *                      (bytes) shape that layout
+ *   "graph"            1: a single-rank plan replays the kernel launches of an exec as one hipGraph from the second call
+ *                      with the same (operation, in, out) on; 0 (default): plain launches -- measured 6-8 us faster per
+ *                      exec on ROCm 7.2 (profiles/r2_graph_latency.txt)
  *   "native_mixed"     1 (default): lengths that are not powers of two but have a mixed-radix configuration run the
  *                      native chain; 0: they run the Bluestein kernel like every other length (A/B runs, tests)
  *   "debug_skip"       measurement only: 1 = every pass skips its transform and becomes a copy with the same

@@ -453,6 +453,53 @@ def test_distributed_any_size_c2c_and_r2c(shape, P1, P2):
             assert rel(backs[r] / n3, ins[r]) < 1e-10
 
 
+@pytest.mark.parametrize("c2c", [True, False])
+def test_graph_replay_of_repeated_execs(c2c):
+    """with option "graph" a single-rank plan captures the launches of an exec into a hipGraph at the second call with the
+    same buffers and replays it afterwards: every call -- plain, captured, replayed -- must transform the CURRENT contents
+    of the buffers; changing an option or re-initialising drops the graphs"""
+    shape = (24, 32, 40)
+    plan = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations())
+    assert plan.getOption("graph") == 0       # off by default: plain launches measured faster (profiles/r2_graph_latency.txt)
+    plan.setOption("graph", 1)
+    plan.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(1, 1), True, c2c=c2c)
+    rng = np.random.default_rng(3)
+    if c2c:
+        d_in = torch.zeros(shape, dtype=torch.complex128, device="cuda")
+    else:
+        d_in = torch.zeros(shape, dtype=torch.float64, device="cuda")
+    d_out = torch.zeros(plan.getDomainSize() // 16, dtype=torch.complex128, device="cuda")
+    d_back = torch.zeros_like(d_in)
+    n3 = float(np.prod(shape))
+    for it in range(6):
+        if it == 4:
+            plan.setOption("graph", 0)          # plain launches again (and the cached graphs are gone)
+        x = rng.uniform(0, 255, shape) + (1j * rng.uniform(0, 255, shape) if c2c else 0)
+        d_in.copy_(torch.from_numpy(x if c2c else x.real.copy()).cuda())
+        torch.cuda.synchronize()
+        if c2c:
+            plan.execC2C(d_out, d_in, dfft.FORWARD)
+            want = orc.fft3d_c2c(x, -1)
+        else:
+            plan.execR2C(d_out, d_in)
+            want = orc.fft3d_r2c(x.real)
+        got = d_out[:want.size].cpu().numpy().reshape(want.shape)
+        assert rel(got, want) < 1e-11, it
+        if c2c:
+            plan.execC2C(d_back, d_out, dfft.INVERSE)
+        else:
+            plan.execC2R(d_back, d_out)
+        assert rel(d_back.cpu().numpy() / n3, x if c2c else x.real) < 1e-10, it
+    plan.setOption("graph", 1)
+    plan.initFFT(dfft.GlobalSize(16, 16, 16), dfft.Pencil_Partition(1, 1), True, c2c=True)     # re-plan: other kernels, other sizes
+    y = rng.uniform(0, 1, (16, 16, 16)) + 1j * rng.uniform(0, 1, (16, 16, 16))
+    d2 = torch.from_numpy(y).cuda()
+    o2 = torch.zeros(plan.getDomainSize() // 16, dtype=torch.complex128, device="cuda")
+    for _ in range(3):
+        plan.execC2C(o2, d2, dfft.FORWARD)
+        assert rel(o2[:y.size].cpu().numpy().reshape(y.shape), orc.fft3d_c2c(y, -1)) < 1e-11
+
+
 def test_plan_can_be_reinitialised():
     """initFFT twice on one object (the reference allows it: plans are rebuilt in initFFT)"""
     plan = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), precision="double")

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -111,6 +112,7 @@ struct Args {
     size_t Nx = 1024, Ny = 1024, Nz = 1024;
     std::string prec = "f64", mode = "c2c", label;
     int iters = 5, check = 0;
+    int latency = 0;      // --latency: no phase timing; host wall clock of the blocking exec calls (what a caller waits for)
     std::vector<std::pair<std::string, long>> opts;
     size_t line = 0, batch = 0;
     int variant = 0, debug = 0;
@@ -169,6 +171,7 @@ static Args parse(int argc, char **argv)
         else if (k == "--mode") a.mode = next();
         else if (k == "--iters") a.iters = atoi(next());
         else if (k == "--check") a.check = 1;
+        else if (k == "--latency") a.latency = 1;
         else if (k == "--label") a.label = next();
         else if (k == "--line") a.line = (size_t)atoll(next());
         else if (k == "--batch") a.batch = (size_t)atoll(next());
@@ -299,6 +302,26 @@ template <typename R> static int run_plan(const Args &a)
     if (a.check && !dbg) {
         check_random<R><<<nblk, 256>>>((const R *)back, nreal, 1.0 / (double)n, part);
         rt_err = reduce_partials(part, nblk) / 255.0;
+    }
+    if (a.latency) {
+        // blocking execs as a caller issues them; two more warm-up rounds so that the plan's launch graph (option
+        // "graph") is captured before the clock starts
+        fwd(); inv(); fwd(); inv();
+        double tf = 0, tb = 0;
+        for (int it = 0; it < a.iters; it++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            fwd();
+            const auto t1 = std::chrono::steady_clock::now();
+            inv();
+            const auto t2 = std::chrono::steady_clock::now();
+            tf += std::chrono::duration<double, std::micro>(t1 - t0).count();
+            tb += std::chrono::duration<double, std::micro>(t2 - t1).count();
+        }
+        std::string optstr;
+        for (auto &kv : a.opts) optstr += " " + kv.first + "=" + std::to_string(kv.second);
+        printf("LATENCY %s %zux%zux%zu %s %s%s | forward %.1f us  inverse %.1f us (host wall clock of the blocking exec, %d iterations)\n",
+               a.label.c_str(), a.Nx, a.Ny, a.Nz, a.prec.c_str(), a.mode.c_str(), optstr.c_str(), tf / a.iters, tb / a.iters, a.iters);
+        return 0;
     }
     DCHK(dfft_enable_phase_timing(plan, 1));
     double accf[8] = {0}, accb[8] = {0}, minf[8], minb[8];
