@@ -49,7 +49,7 @@ enum dfft_kind {
     DFFT_SLAB_Z_THEN_YX = 4,       /* MPIcuFFT_Slab_Z_Then_YX      include/mpicufft_slab_z_then_yx.hpp      */
     DFFT_SLAB_Z_THEN_YX_OPT1 = 5,  /* MPIcuFFT_Slab_Z_Then_YX_Opt1 include/mpicufft_slab_z_then_yx_opt1.hpp */
     /* forward only, like the reference: R2C along y, one all-to-all, 2-D (z,x) pass.  Output
-     * [Nx][(Ny/2+1)/P][Nz] (include/mpicufft_slab_y_then_zx.hpp:40-43).  R2C plans: Ny a power of two up to 2048, or any Ny <= 1024.  Unlike
+     * [Nx][(Ny/2+1)/P][Nz] (include/mpicufft_slab_y_then_zx.hpp:40-43).  R2C plans: Ny a power of two up to 2048, or any Ny <= 4096.  Unlike
      * the reference's single-rank branch (a z-Hermitian cufftPlan3d, mpicufft_slab_y_then_zx.cpp:111-121),
      * one rank produces the same y-Hermitian layout as several. */
     DFFT_SLAB_Y_THEN_ZX = 6        /* MPIcuFFT_Slab_Y_Then_ZX      include/mpicufft_slab_y_then_zx.hpp      */
