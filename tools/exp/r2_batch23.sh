@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: the option y_pad existed only for this measurement and was removed afterwards, profiles/r2_y_pad.txt)
 # round 2, GPU batch 23: padded rows in the y pass's private output (single-rank C2C, order z, y, x): row stride 16 MiB + pad
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/b23

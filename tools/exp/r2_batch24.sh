@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: the FLAT configurations existed only for this measurement and were removed afterwards, profiles/r2_flat_staging.txt)
 # round 2, GPU batch 24: FLAT natural-line staging for the mixed-radix z passes (roles 7 / 4 / 5) against the direct form
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/b24
