@@ -342,7 +342,7 @@ struct PassCfg {
     static_assert(THREADS <= 1024, "workgroup too large");
 };
 
-template <typename Cfg> __device__ __forceinline__ int lds_pad(int idx)
+template <typename Cfg> __host__ __device__ __forceinline__ int lds_pad(int idx)
 {
     return idx + ((idx >> Cfg::PS) << Cfg::PWS);
 }
@@ -363,7 +363,7 @@ template <typename C> __device__ __forceinline__ C pick(bool cond, C a, C b)
 // butterfly jA = t + NT*i as usual, block i + S/2 is its mirror N/RP - jA, so that points k and N - k -- which the
 // Hermitian split / merge of a packed real transform combines -- live in ONE thread and no extra trip through LDS is
 // needed.  Butterfly 0 is its own mirror; its slot in thread 0 takes the other self-mirrored butterfly N/(2 RP).
-template <typename Cfg, int RP, int I> __device__ __forceinline__ int pair_j(int t)
+template <typename Cfg, int RP, int I> __host__ __device__ __forceinline__ int pair_j(int t)
 {
     constexpr int S = Cfg::kE / RP, H = S / 2, NB = Cfg::kN / RP;
     static_assert(S % 2 == 0, "conjugate-pair assignment needs an even number of butterflies per thread");
@@ -373,7 +373,7 @@ template <typename Cfg, int RP, int I> __device__ __forceinline__ int pair_j(int
         return ja == 0 ? NB / 2 : NB - ja;
     }
 }
-template <typename Cfg, int RP, int I, int JM> __device__ __forceinline__ int butterfly_j(int t)
+template <typename Cfg, int RP, int I, int JM> __host__ __device__ __forceinline__ int butterfly_j(int t)
 {
     if constexpr (JM) return pair_j<Cfg, RP, I>(t);
     else return t + Cfg::NT * I;
@@ -382,7 +382,7 @@ template <typename Cfg, int RP, int I, int JM> __device__ __forceinline__ int bu
 // twiddle + butterflies of one Stockham pass: radix RP, previous sub-transform length NS; JM = 1: conjugate-pair
 // assignment of the butterflies (pair_j)
 template <typename Cfg, int RP, int NS, int JM = 0>
-__device__ __forceinline__ void pass_compute(typename Cfg::C *v, int t, const typename Cfg::C *__restrict__ W)
+__host__ __device__ __forceinline__ void pass_compute(typename Cfg::C *v, int t, const typename Cfg::C *__restrict__ W)
 {
     using C = typename Cfg::C;
     constexpr int S = Cfg::kE / RP;     // butterflies per thread == register stride
@@ -424,7 +424,7 @@ __device__ __forceinline__ void pass_compute(typename Cfg::C *v, int t, const ty
 
 
 // thread -> (line within workgroup, thread within line)
-template <typename Cfg, bool POINT_FASTEST> __device__ __forceinline__ void thread_map(int tid, int &lw, int &t)
+template <typename Cfg, bool POINT_FASTEST> __host__ __device__ __forceinline__ void thread_map(int tid, int &lw, int &t)
 {
     if constexpr (!POINT_FASTEST) {
         lw = tid % Cfg::TW;
@@ -436,7 +436,7 @@ template <typename Cfg, bool POINT_FASTEST> __device__ __forceinline__ void thre
     }
 }
 // LDS slot of point n of line lw
-template <typename Cfg> __device__ __forceinline__ int lds_slot(int lw, int n)
+template <typename Cfg> __host__ __device__ __forceinline__ int lds_slot(int lw, int n)
 {
     if constexpr (Cfg::kMAP == 0) return lds_pad<Cfg>(n * Cfg::TW + lw);
     else return lw * Cfg::PITCH + n + (n >> 5);
@@ -468,7 +468,7 @@ template <typename Cfg> constexpr bool gather_separable()
 
 // scatter the outputs of pass (RP, NS) to LDS plane, Stockham output index
 template <typename Cfg, int RP, int NS, int COMP, int JM = 0>
-__device__ __forceinline__ void lds_scatter(const typename Cfg::C *v, typename Cfg::real *plane, int t, int lw)
+__host__ __device__ __forceinline__ void lds_scatter(const typename Cfg::C *v, typename Cfg::real *plane, int t, int lw)
 {
     constexpr int S = Cfg::kE / RP;
     static_for<0, S>([&](auto ic) {
@@ -490,7 +490,7 @@ __device__ __forceinline__ void lds_scatter(const typename Cfg::C *v, typename C
 // gather for a consuming pass of radix RPN whose butterflies are assigned in conjugate pairs: register c = i + m*S holds
 // input leg m of butterfly pair_j(i), i.e. point pair_j(i) + m*(N/RPN)
 template <typename Cfg, int COMP, int RPN>
-__device__ __forceinline__ void lds_gather_paired(typename Cfg::C *v, const typename Cfg::real *plane, int t, int lw)
+__host__ __device__ __forceinline__ void lds_gather_paired(typename Cfg::C *v, const typename Cfg::real *plane, int t, int lw)
 {
     constexpr int S = Cfg::kE / RPN, LEG = Cfg::kN / RPN;
     constexpr bool SEP = Cfg::kMAP == 0 ? LEG % Cfg::r1 == 0 : LEG % 32 == 0;
@@ -508,7 +508,7 @@ __device__ __forceinline__ void lds_gather_paired(typename Cfg::C *v, const type
     });
 }
 template <typename Cfg, int COMP>
-__device__ __forceinline__ void lds_gather(typename Cfg::C *v, const typename Cfg::real *plane, int t, int lw)
+__host__ __device__ __forceinline__ void lds_gather(typename Cfg::C *v, const typename Cfg::real *plane, int t, int lw)
 {
     const int base = lds_slot<Cfg>(lw, t);
     static_for<0, Cfg::kE>([&](auto cc) {

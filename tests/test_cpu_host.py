@@ -72,6 +72,29 @@ def test_in_register_butterflies_on_the_host(tmp_path):
     assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout + out.stderr
 
 
+def test_whole_stockham_chain_emulated_on_the_host(tmp_path):
+    """tests/cpp/chain_check.hip: the kernel's own pass_compute / lds_scatter / lds_gather and output index map, compiled
+    for the host and driven for every thread of a workgroup (an array for LDS, loop boundaries for barriers), against a
+    long-double DFT -- every generated mixed-radix configuration of both precisions plus a few powers of two"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(os.path.dirname(__file__), "cpp", "chain_check.hip")
+    builds = []
+    for tag, flag in (("f64", []), ("f32", ["-DCHAIN_F32"])):
+        exe = str(tmp_path / ("chain_check_" + tag))
+        builds.append((exe, subprocess.Popen([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", *flag, src, "-o", exe])))
+    runs = []
+    for exe, proc in builds:
+        assert proc.wait() == 0
+        runs.append(subprocess.Popen([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for r in runs:
+        out = r.communicate()[0]
+        assert r.returncode == 0 and "ALL OK" in out, out[-2000:]
+
+
 CASES = [((12, 10, 14), 2, 4, False), ((9, 7, 10), 3, 2, True), ((1000, 100, 30), 4, 2, False), ((1024, 1024, 1024), 2, 4, False), ((1024, 1024, 1024), 2, 4, True), ((512, 512, 512), 2, 1, True),
          ((64, 32, 16), 4, 2, False), ((16, 16, 16), 3, 2, True), ((2048, 2048, 2048), 2, 4, True),
          ((256, 256, 256), 1, 1, True), ((64, 64, 64), 3, 5, False), ((128, 64, 32), 8, 1, True)]
