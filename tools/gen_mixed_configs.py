@@ -89,7 +89,12 @@ def choose(N, prec):
                 lds = lds_bytes(N, TLK * G, rr[0], planes, rsz, npass)
                 if lds > 160 * 1024:
                     continue
-                score = (sub, npass, abs(E - epref), -rr[0], rr)
+                # fp32: a configuration whose register estimate (2E for the points + 26 + 2E) exceeds the 256 VGPRs of a lane
+                # spills; it counts like one more pass.  Measured (profiles/r2_mixed_radix_vs_bluestein.txt): 1200^3 C2C
+                # 76.0 -> 60.9 ms with (30, 10, 2, 2) on 30 points per thread instead of (30, 10, 4) on 60; the same trade at
+                # 40 / 56 points per thread (no spills) LOSES: 1280^3 62.7 -> 67.4 ms, 896^3 18.3 -> 23.3 ms, 640^3 6.2 -> 6.8 ms
+                heavy = 1 if prec == "f32" and 4 * E + 26 > 256 else 0
+                score = (sub, npass + heavy, abs(E - epref), -rr[0], rr)
                 if best is None or score < best[0]:
                     best = (score, dict(N=N, E=E, TL=TL, G=G, rad=rr, planes=planes, threads=threads, lds=lds, sub=sub))
     return None if best is None else best[1]
