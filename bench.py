@@ -21,6 +21,15 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
   config.multi_rank_path (N = 1 only) -- the same grid through the code path every rank runs at N > 1: mirrored
                        inverse order (x, y, z) and segmented (8-chunk) address tables, so that a 1-GPU lease
                        predicts the per-GPU compute of the multi-GPU runs
+  config.per_gpu_kernels_8gpu (N = 1 only) -- rank 0's plan of the 8-GPU decompositions (pencil 2x4 = BASELINE C4, slab 8)
+                       executed on this GPU with the exchange stubbed out: the kernels one GPU of the 8-GPU run launches
+                       (its 1/8 of the volume, its segment tables and pipeline chunks), timed with HIP events
+  xgmi (N > 1)      -- bytes per link and the time the links need at the guide's 153 GB/s (predicted_ms) next to the
+                       measured exchange spans; overlap.hidden_frac = 1 - (step - sum kernels) / sum exchanges
+
+At N > 1 the headline decomposition is the one BASELINE.json names (8 GPUs: pencil 2x4, 4: pencil 2x2, 2: slab); the slab
+decomposition over all N ranks -- one exchange over N-1 private xGMI links instead of two over 3 + 1 -- is measured in the
+same run and reported as config.alt (--decomp slab makes it the headline).
 """
 import argparse
 import json
@@ -50,7 +59,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo lets several ranks share one GPU (functional test)")
     ap.add_argument("--decomp", default="auto", choices=["auto", "slab", "pencil"],
-                    help="auto = slab on one xGMI node (every GPU pair has its own link), pencil = BASELINE 2x4 / 2x2")
+                    help="auto = pencil = the BASELINE.json grids (2x4 at 8 GPUs, 2x2 at 4, slab at 2); slab = one exchange over all ranks")
+    ap.add_argument("--no-dup-channel", action="store_true",
+                    help="native RCCL transport: do not duplicate the communicator for the second exchange of a pencil plan")
     ap.add_argument("--no-alt", action="store_true", help="skip the alternative-decomposition measurement")
     ap.add_argument("--no-multi-rank-path", action="store_true", help="N = 1: skip the multi-rank code path measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -65,13 +76,27 @@ def pencil_partition(n):
 
 
 def choose_partition(n, decomp):
-    """On one xGMI node every GPU pair has a private link, so a P-way all-to-all drives P-1
-    links at once: slab (one exchange over all P ranks) moves (P-1)/P of the volume once over
-    P-1 links, pencil 2x4 moves 3/4 over 3 links and then 1/2 over a single link.
-    auto therefore picks slab; the BASELINE-named pencil grid is measured next to it."""
-    if decomp == "pencil":
-        return pencil_partition(n)
-    return (n, 1)
+    """The headline is the decomposition BASELINE.json names (pencil 2x4 at 8 GPUs, 2x2 at 4, slab at 2).  On one xGMI
+    node every GPU pair has a private link, so a P-way all-to-all drives P-1 links at once: slab (one exchange over all P
+    ranks) moves (P-1)/P of the volume once over P-1 links, pencil 2x4 moves 3/4 over 3 links and then 1/2 over a single
+    link -- slab is therefore measured next to it as config.alt."""
+    if decomp == "slab":
+        return (n, 1)
+    return pencil_partition(n)
+
+
+def xgmi_model(esz, N, ngpus, P1, P2):
+    """Per transform (one direction) and GPU: exchange 1 runs inside the row group (P2 ranks), exchange 2 inside the column
+    group (P1 ranks); every peer pair has its own xGMI link, so an exchange over P ranks sends V/P bytes down each of its
+    P - 1 links at the same time (V = bytes of the local volume).  predicted_ms = bytes per link / 153 GB/s."""
+    vol = esz * float(N) ** 3 / ngpus
+    out = {}
+    for name, P in (("exchange 1", P2), ("exchange 2", P1)):
+        if P > 1:
+            per_link = vol / P
+            out[name] = {"group_ranks": P, "links": P - 1, "bytes_per_link": per_link, "bytes_out": per_link * (P - 1),
+                         "predicted_ms": round(per_link / (XGMI_LINK_GBS * 1e9) * 1e3, 3)}
+    return out
 
 
 def flops_per_direction(n):
@@ -207,6 +232,14 @@ def main():
         if world > 1:
             from distributedfft_amd.torch_transport import make_comm
             comm, transport = make_comm(dist, rank, world, P1, P2, tmode_box[0])
+            if transport.startswith("rccl") and P1 > 1 and P2 > 1 and not args.no_dup_channel:
+                # row- and column-group exchanges use disjoint links: give the second one its own communicator (collective)
+                try:
+                    comm.setOption("dup_channel", 1)
+                    transport += ", duplicated communicator for exchange 2"
+                except Exception as e:   # noqa: BLE001
+                    if rank == 0:
+                        print(f"[bench] dup_channel unavailable: {e}", file=sys.stderr, flush=True)
         kind = dfft.MPIcuFFT_Slab_Opt1 if P2 == 1 and ngpus > 1 else dfft.MPIcuFFT_Pencil_Opt1
         plan = kind(dfft.Configurations(), comm, precision=prec, rank=rank)
         for k, v in (options or {}).items():
@@ -271,11 +304,21 @@ def main():
         torch.cuda.synchronize()
 
     def run_steps(pl, k, out_buf, back_buf, collect=False):
-        """k forward + inverse pairs; returns (seconds, {phase name: total ms}, launches of FFT passes)"""
+        """k forward + inverse pairs; returns (seconds, {phase name: total ms}, launches of FFT passes).
+        Normally ONE bracket (barrier + synchronize on both sides) around all k steps.  When the inverse writes back over
+        the input (`aliased`: 2048^3 fp32 on one GPU) every step multiplies the data by N^3, which overflows fp32 within
+        four steps: each step then gets its own bracket and the input is regenerated between the brackets, outside the
+        timed spans; the reported time is the sum of the k brackets."""
         acc, launches = {}, 0
+        refill = back_buf is d_in
+        dt = 0.0
         barrier()
         t0 = time.perf_counter()
-        for _ in range(k):
+        for i in range(k):
+            if refill and i:
+                fill(d_in)
+                barrier()
+                t0 = time.perf_counter()
             with torch.cuda.stream(side):
                 pl.execC2C(out_buf, d_in, dfft.FORWARD)       # blocking, like the reference's exec
                 ph_f = pl.getPhaseTimes(dfft.FORWARD) if collect else []
@@ -284,8 +327,12 @@ def main():
             for name, ms in ph_f + ph_b:
                 acc[name] = acc.get(name, 0.0) + ms
                 launches += "FFT" in name
-        barrier()
-        dt = time.perf_counter() - t0
+            if refill:
+                barrier()
+                dt += time.perf_counter() - t0
+        if not refill:
+            barrier()
+            dt = time.perf_counter() - t0
         if dist is not None:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -304,6 +351,7 @@ def main():
         return round_trip_error(back_buf)      # round-trip check on the warm-up result (reference testcase 3), worst rank
 
     rt_err = warm_and_check(plan, d_out, d_back)
+    assert rt_err is None or math.isfinite(rt_err), f"round trip is not finite ({rt_err})"
     tol = 1e-10 if prec == "double" else 5e-5
     if rt_err is not None and not rt_err < tol and world > 1 and transport.startswith("rccl") and args.transport == "auto":
         # the native RCCL exchange produced a wrong round trip at full size: measure with the torch
@@ -337,6 +385,53 @@ def main():
                 out[name]["TBps"] = round(vol_bytes / (m * 1e-3) / 1e12, 3)
         return out
 
+    def overlap_report(step_ms, fft_ms, exch_ms):
+        """hidden_frac = 1 - (step - sum of kernel spans) / (sum of exchange spans): 1 = every exchange span ran under a
+        kernel, 0 = none did (the spans are device times of the exchange calls on the communication streams)"""
+        exposed = max(step_ms - fft_ms, 0.0)
+        return {"step_ms": round(step_ms, 3), "kernels_ms": round(fft_ms, 3), "exchanges_ms": round(exch_ms, 3),
+                "exposed_ms": round(exposed, 3),
+                "hidden_frac": round(1.0 - exposed / exch_ms, 3) if exch_ms > 0 else None}
+
+    def per_gpu_kernels(P1v, P2v, steps):
+        """rank 0's plan of a P1v x P2v grid on THIS GPU with the exchange stubbed out (a callback transport that moves
+        nothing): the kernels run with that rank's descriptors -- 1/P of the volume, its peer segments, its pipeline chunks --
+        on whatever the buffers hold, so the times are the compute one GPU of the multi-GPU run does per step."""
+        nr = P1v * P2v
+        stub = dfft.Comm.callback(nr, 0, lambda *a: None)
+        kind = dfft.MPIcuFFT_Slab_Opt1 if P2v == 1 else dfft.MPIcuFFT_Pencil_Opt1
+        pl = kind(dfft.Configurations(), stub, precision=prec, rank=0)
+        pl.initFFT(dfft.GlobalSize(N, N, N), dfft.Partition(P1v, P2v), allocate=False, c2c=True)
+        pl.setStream(stream)
+        pl.setWorkArea(None)
+        isz_v = pl.getInSize()
+        nv = isz_v[0] * isz_v[1] * isz_v[2]
+        v_in = d_in[:nv]
+        v_out = d_out[:pl.getDomainSize() // esz]
+        pl.enablePhaseTiming(True)
+        acc = {}
+        for i in range(steps + 2):
+            with torch.cuda.stream(side):
+                pl.execC2C(v_out, v_in, dfft.FORWARD)
+                ph = pl.getPhaseTimes(dfft.FORWARD)
+                pl.execC2C(v_in, v_out, dfft.INVERSE)
+                ph = ph + pl.getPhaseTimes(dfft.INVERSE)
+            if i >= 2:
+                for name, ms in ph:
+                    if "FFT" in name:
+                        acc[name] = acc.get(name, 0.0) + ms
+        torch.cuda.synchronize()
+        vb = 2.0 * esz * float(N) ** 3 / nr
+        passes = {name: {"ms": round(ms / steps, 3), "TBps": round(vb / (ms / steps * 1e-3) / 1e12, 3)} for name, ms in acc.items()}
+        tot = sum(v["ms"] for v in passes.values())
+        res = {"decomposition": f"slab P={P1v}" if P2v == 1 else f"pencil {P1v}x{P2v}", "rank": 0,
+               "pipeline_chunks": pl.getPipelineChunks(), "kernels_ms_per_step": round(tot, 3), "per_pass": passes,
+               "alg_bytes_per_pass": vb, "avg_TBps": round(6 * vb / (tot * 1e-3) / 1e12, 3) if tot > 0 else None,
+               "xgmi_model_per_transform": xgmi_model(esz, N, nr, P1v, P2v)}
+        del pl
+        stub.destroy()
+        return res
+
     # N = 1: the code path of the N > 1 runs on the same grid (mirrored inverse order, 8-chunk segment tables)
     multi_rank_path = None
     chunks_main = plan.getPipelineChunks()
@@ -360,9 +455,16 @@ def main():
                            "per_pass": per_pass(phm, ksteps)}
         del plan_m
 
-    # the BASELINE-named pencil grid (2x2 / 2x4) measured next to the chosen decomposition
+    # N = 1: the kernels one GPU of the 8-GPU runs launches (BASELINE C4 / C5 grids: pencil 2x4; and slab 8), exchange stubbed
+    per_gpu_8 = None
+    if ngpus == 1 and not args.no_multi_rank_path and N % 8 == 0:
+        fill(d_in)
+        per_gpu_8 = [per_gpu_kernels(2, 4, 5), per_gpu_kernels(8, 1, 5)]
+        fill(d_in)
+
+    # the other decomposition (slab over all ranks next to the BASELINE pencil grid, or the reverse) in the same run
     alt = None
-    alt_part = pencil_partition(ngpus)
+    alt_part = (ngpus, 1) if P2 > 1 else pencil_partition(ngpus)
     if world > 1 and not args.no_alt and alt_part != (P1, P2) and not (args.p1 and args.p2):
         if not aliased:
             del d_back
@@ -383,13 +485,16 @@ def main():
         ex2 = sum(ms for name, ms in ph2.items() if "FFT" not in name)
         vol = esz * float(N) ** 3 / ngpus
         a1, a2 = alt_part
-        alt = {"decomposition": f"pencil {a1}x{a2} (BASELINE.json configs)", "transport": transport2,
+        alt = {"decomposition": f"slab P={a1}" if a2 == 1 else f"pencil {a1}x{a2} (BASELINE.json configs)", "transport": transport2,
                "ms_per_step": round(dt2 / args.steps * 1e3, 3), "round_trip_rel_linf": alt_rt,
                "value": round(2 * flops_per_direction(N) * args.steps / dt2 / 1e9, 1),
                "per_pass": per_pass(ph2, args.steps), "exchange_ms_per_step": round(ex2 / args.steps, 3),
                # bytes one GPU sends per step: exchange 1 inside the row group (a2 ranks), exchange 2 inside the column group
+               "fft_ms_per_step": round(sum(ms for name, ms in ph2.items() if "FFT" in name) / args.steps, 3),
                "xgmi_bytes_out_per_gpu_per_step": 2.0 * vol * ((a2 - 1) / a2 + (a1 - 1) / a1),
+               "xgmi_model_per_transform": xgmi_model(esz, N, ngpus, a1, a2),
                "links_in_use": {"exchange 1": a2 - 1, "exchange 2": a1 - 1}}
+        alt["overlap"] = overlap_report(alt["ms_per_step"], alt["fft_ms_per_step"], alt["exchange_ms_per_step"])
 
     flops_step = 2 * flops_per_direction(N)
     ms_per_step = dt / args.steps * 1e3
@@ -444,6 +549,11 @@ def main():
         }
         if multi_rank_path is not None:
             out["config"]["multi_rank_path"] = multi_rank_path
+        if per_gpu_8 is not None:
+            out["config"]["per_gpu_kernels_8gpu"] = {
+                "what": "rank 0's plan of the 8-GPU decompositions run on this GPU with the exchange stubbed out: per-pass "
+                        "device time of the kernels one GPU of the 8-GPU run launches per step (1/8 of the volume each)",
+                "plans": per_gpu_8}
         if alt is not None:
             out["config"]["alt"] = alt
         if ngpus > 1:
@@ -457,7 +567,17 @@ def main():
             if links:
                 xg["links_in_use"] = links
                 xg["achieved_GBps_per_link"] = round(xg["achieved_GBps_per_gpu"] / links, 1) if xg["achieved_GBps_per_gpu"] else None
+            # the model: per exchange and transform, bytes per link / 153 GB/s, next to the measured span of that exchange
+            # (sum over its pipeline chunks, forward and inverse halved)
+            model = xgmi_model(esz, N, ngpus, P1, P2)
+            for name, m in model.items():
+                meas = phases.get(name, 0.0) / args.steps / 2.0
+                m["measured_ms"] = round(meas, 3)
+                m["measured_GBps_per_link"] = round(m["bytes_per_link"] / (meas * 1e-3) / 1e9, 1) if meas > 0 else None
+            xg["per_exchange_per_transform"] = model
+            xg["predicted_exchange_ms_per_step"] = round(2.0 * sum(m["predicted_ms"] for m in model.values()), 3)
             out["xgmi"] = xg
+            out["overlap"] = overlap_report(ms_per_step, kern_ms / args.steps, exch_ms / args.steps)
         if not args.no_cpu_baseline and ngpus == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_n)
         print(json.dumps(out), flush=True)

@@ -149,6 +149,10 @@ class Comm:
         check(lib().dfft_comm_info(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def setOption(self, key, value):
+        """transport knobs (include/dfft_c.h: dfft_comm_set_option); 'dup_channel' = 1 is collective over all ranks"""
+        check(lib().dfft_comm_set_option(self._h, key.encode(), int(value)))
+
     def destroy(self):
         if self._h:
             lib().dfft_comm_destroy(self._h)

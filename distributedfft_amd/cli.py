@@ -298,7 +298,8 @@ def run(argv=None):
             full[rk.ist[0]:rk.ist[0] + rk.isz[0], rk.ist[1]:rk.ist[1] + rk.isz[1], :] = xs[rk.rank]
         if dist is not None:      # assemble the global input on every process (testcase 1 runs on small grids)
             buf = full.cpu() if args.backend == "gloo" else full
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            # gloo (and some RCCL builds) have no complex all_reduce: reduce the interleaved real view
+            dist.all_reduce(torch.view_as_real(buf) if buf.is_complex() else buf, op=dist.ReduceOp.SUM)
             full = buf.cuda()
         single = Rank(args, None, 0, 1, 1)
         torch.cuda.synchronize()

@@ -178,6 +178,24 @@ struct RcclComm : dfft_comm {
         if (!R || !R->CommCount || !comm || R->CommCount(comm, &n) != 0) return 0;
         return n;
     }
+    // "dup_channel" = 1: second communicator over the same ranks (ncclCommSplit, colour 0) for channel 1.  Collective: every
+    // rank calls it at the same point.  Without it both exchanges of a pencil plan share one communicator and RCCL
+    // serialises them.
+    int set_option(const char *key, long value) override
+    {
+        if (std::string(key ? key : "") != "dup_channel") return 1;
+        RcclApi *R = rccl();
+        if (!R || !comm) { set_error("librccl not available"); return 1; }
+        if (value == 0) {
+            if (comm2 && R->CommDestroy) R->CommDestroy(comm2);
+            comm2 = nullptr;
+            return 0;
+        }
+        if (comm2) return 0;
+        if (!R->CommSplit) { set_error("this librccl has no ncclCommSplit"); return 1; }
+        NCCL_TRY(R->CommSplit(comm, 0, rank, &comm2, nullptr));
+        return 0;
+    }
     int alltoallv(int myrank, const void *send, const size_t *scount, const size_t *sdispl, void *recv,
                   const size_t *rcount, const size_t *rdispl, const int *group, int ngroup, int me,
                   hipStream_t stream, int channel) override
@@ -237,12 +255,7 @@ dfft_comm *make_rccl_comm(const void *id128, int nranks, int rank)
         delete c;
         return nullptr;
     }
-    // second communicator over the same ranks for the second exchange of pencil plans (collective;
-    // every rank constructs its RcclComm at the same point).  Optional: without it both exchanges
-    // share one communicator and RCCL serialises them.
-    if (R->CommSplit && getenv("DFFT_RCCL_DUP") && std::string(getenv("DFFT_RCCL_DUP")) == "1") {
-        if (R->CommSplit(c->comm, 0, rank, &c->comm2, nullptr) != 0) c->comm2 = nullptr;
-    }
+    // (a second communicator for the second exchange of pencil plans is an explicit, collective option: set_option)
     return c;
 }
 

@@ -27,6 +27,10 @@ struct dfft_comm {
     virtual int transport_nranks() const { return 0; }
     // host-side rendezvous of all ranks (used around timing); no-op by default
     virtual void barrier(int /*myrank*/) {}
+    // transport knobs (dfft_comm_set_option): 0 = ok, 1 = unknown key / unsupported, else a transport error.
+    //   "dup_channel" = 1 (rccl): COLLECTIVE over all ranks of the communicator -- duplicates it (ncclCommSplit) so that
+    //   channel 1 (the second exchange of a pencil plan) may be on the wire together with channel 0
+    virtual int set_option(const char * /*key*/, long /*value*/) { return 1; }
 };
 
 namespace dfft {

@@ -244,6 +244,8 @@ struct Options {
     int chunks = 0;          // requested pipeline depth (0 = default)
     int mirror = 0;          // single-rank complex inverse in the mirrored (multi-rank) pass order x, y, z
     int tables = 1;          // per-point address tables: 0 never, 1 sides with more than one segment, 2 always
+    int uniform_tables = 1;  // sides whose segments all start at multiples of 16 points: table entries through wave-uniform
+                             // (scalar) loads, PassArgs::luni / suni (0: per-lane vector loads, for A/B runs)
     int shift = -1;          // row-aligned tile windows of odd-pitch point-major stores: -1 auto (fp64), 0 off, 2 always
     int debug = 0;           // PassArgs::debug of every launch (measurement only; results are wrong when set)
     int real_variant = 0;    // A/B configurations of the real z passes (DFFT_EXPERIMENTS builds)
@@ -1301,6 +1303,13 @@ int dfft_comm_info(const dfft_comm *comm, int *nranks, int *transport_nranks)
     if (transport_nranks) *transport_nranks = comm->transport_nranks();
     return 0;
 }
+int dfft_comm_set_option(dfft_comm *comm, const char *key, long value)
+{
+    if (!comm || !key) return fail(ERR_ARG, "null communicator or key");
+    const int r = comm->set_option(key, value);
+    if (r == 1 && g_error.empty()) set_error(std::string("this transport has no option ") + key);
+    return r;
+}
 int dfft_comm_destroy(dfft_comm *comm)
 {
     delete comm;
@@ -1336,6 +1345,7 @@ static int *option_slot(Options &o, const std::string &k)
     if (k == "pipeline_chunks") return &o.chunks;
     if (k == "mirror_inverse") return &o.mirror;
     if (k == "point_tables") return &o.tables;
+    if (k == "uniform_tables") return &o.uniform_tables;
     if (k == "shift") return &o.shift;
     if (k == "debug_skip") return &o.debug;
     if (k == "real_variant") return &o.real_variant;
@@ -1355,6 +1365,8 @@ int dfft_set_option(dfft_plan *p, const char *key, long value)
     if (!p || !key) return fail(ERR_ARG, "null plan or key");
     int *slot = option_slot(p->opt, key);
     if (!slot) return fail(ERR_ARG, std::string("unknown option ") + key);
+    // kernel configurations are keyed by (length, variant) with four bits for the variant (kernels.hip.inc)
+    if (std::string(key).rfind("variant_", 0) == 0 && (value < -1 || value > 15)) return fail(ERR_ARG, "variant_* must be -1 (the plan's choice) or 0..15");
     *slot = (int)value;      // takes effect at the next dfft_init (debug_skip / mirror_inverse / real_variant: next exec)
     graphs_clear(p);         // captured launches carry the old options
     return 0;
@@ -1590,6 +1602,11 @@ static int upload_tables(dfft_plan *p)
             if ((side == 0 && L->args.IA) || (side == 1 && L->args.SK)) continue;      // explicit strides: closed form only
             point_table(*L, side == 1, tab);
             (side == 0 ? L->lent : L->sent) = host.size();
+            // wave-uniform (scalar) table reads need the 4 / 8 / 16 consecutive points of a wave in one segment
+            const SegTable &T = side == 0 ? L->lseg : L->sseg;
+            bool aligned = p->opt.uniform_tables != 0;
+            for (int q = 0; q < T.nseg; q++) aligned = aligned && T.start[q] % 16 == 0;
+            (side == 0 ? L->args.luni : L->args.suni) = aligned ? 1 : 0;
             const size_t bytes = tab.size() * sizeof(SegEntry);
             host.resize(host.size() + bytes);
             memcpy(host.data() + host.size() - bytes, tab.data(), bytes);
@@ -1638,7 +1655,8 @@ int dfft_set_pipeline_chunks(dfft_plan *p, int chunks)
 {
     if (!p) return fail(ERR_ARG, "null plan");
     if (chunks < 0) return fail(ERR_ARG, "chunks must be >= 0");
-    p->opt.chunks = chunks;      // takes effect at the next dfft_init
+    p->opt.chunks = chunks;      // takes effect at the next dfft_init (the pipeline of an initialised plan is not rebuilt:
+                                 // dfft_get_pipeline_chunks keeps reporting the depth in use until then)
     return 0;
 }
 int dfft_get_pipeline_chunks(const dfft_plan *p) { return p ? p->pl.C : 0; }
@@ -1910,6 +1928,7 @@ int dfft_fft1d_batched_ex(int precision, size_t N, size_t batch, void *out, cons
     static thread_local int axP = -1;
     static thread_local bool axB = false;
     const bool force_bluestein = variant < 0;      // variant -1: the Bluestein kernel even where a native configuration exists
+    if (variant > 15) return fail(ERR_ARG, "variant must be -1 (Bluestein) or 0..15");
     if (force_bluestein) variant = 0;
     if (ax.N != N || axP != precision || axB != force_bluestein) {
         axis_free(ax);

@@ -100,6 +100,7 @@ struct PassArgs {
     const SegTable *lseg, *sseg;
     int32_t lnseg, snseg;
     const SegEntry *ltab, *stab;   // per-point tables (null: search the segment table per point)
+    int32_t luni, suni;            // the side's table may be read with wave-uniform (scalar) loads: every segment starts at a multiple of 16 points
 };
 
 // ------------------------------------------------------------------------------------------
@@ -312,13 +313,14 @@ template <int R, int OFF, int STRIDE, typename C> struct Dif {
 //      only TL/2 of them (half the on-chip footprint: two workgroups per CU at N = 2048) and its sibling
 //      (the next logical workgroup, kept on the same XCD so that L2 sees both halves of every 128-byte
 //      run) the rest.  Only fft_pass_kernel; needs G == 1.
-template <typename R, int N, int E, int TL, int G, int R1, int R2, int R3, int R4, int PLANES, int TWCHAIN = 0, int NTMEM = 0, int MAP = 0, int SUB = 1>
+template <typename R, int N, int E, int TL, int G, int R1, int R2, int R3, int R4, int PLANES, int TWCHAIN = 0, int NTMEM = 0, int MAP = 0, int SUB = 1, int PERSIST = 0>
 struct PassCfg {
     using real = R;
     using C = typename Vec2<R>::type;
     static constexpr int kN = N, kE = E, kTL = TL, kG = G;
     static constexpr int r1 = R1, r2 = R2, r3 = R3, r4 = R4, kPLANES = PLANES, kTWCHAIN = TWCHAIN, kNTMEM = NTMEM, kMAP = MAP;
     static constexpr int kSUB = SUB, TLK = TL / SUB;  // lines of a tile one workgroup transforms
+    static constexpr int kPERSIST = PERSIST;
     static constexpr int RLAST = R4 > 1 ? R4 : (R3 > 1 ? R3 : (R2 > 1 ? R2 : R1));
     static constexpr int NT = N / E;                 // threads per line
     static constexpr int TW = TLK * G;               // lines per workgroup
@@ -328,15 +330,29 @@ struct PassCfg {
     static constexpr int PS = ilog2(R1 * TW);        // pad once per first-pass scatter stride ...
     static constexpr int PWS = ilog2(TW) > 4 ? 4 : ilog2(TW);   // ... by min(TW,16) slots
     static constexpr int SLOTS = N * TW;
-    // MAP != 0: line-major LDS plane [line][n + n/32] with a pitch that keeps the 16-point groups
+    // MAP != 0: line-major LDS plane [line][n + n/PADB] with a pitch that keeps the 16-point groups
     // of the lines sharing a 32-lane LDS group on different banks
     static constexpr int PGRP = 16;
-    static constexpr int PITCH_BASE = N + N / 32;
+    // one pad slot per PADB points: 32, or 64 when the first pass is a radix-64 one -- its scatter writes points 64 t + m from
+    // lanes t = 0..15 of a line, i.e. with a stride of 64 + 64/PADB slots: 66 puts the two lines of a 32-lane group on the
+    // same (even) banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 20 %, profiles/r2_pmc_f32_2048.txt), 65 gives each line 16
+    // consecutive banks like the linear gathers have
+    static constexpr int PADB = R1 == 64 ? 64 : 32, PADSH = ilog2(PADB);
+    static constexpr int PITCH_BASE = N + N / PADB;
     static constexpr int PITCH_WANT = MAP == 2 ? 17 : 16;
     static constexpr int PITCH = PITCH_BASE + ((PITCH_WANT - PITCH_BASE % 32 + 32) % 32);
     static constexpr int PLANE_SLOTS = MAP == 0 ? SLOTS + ((SLOTS >> PS) << PWS) : TW * PITCH;
     static_assert(MAP == 0 || ((N / E) % 16 == 0 && G == 1), "point-fastest mapping needs >= 16 threads per line");
     static constexpr size_t LDS_BYTES = NPASS > 1 ? (size_t)PLANES * PLANE_SLOTS * sizeof(R) : 0;
+    // consecutive values of t one wave covers on the load side (first-pass mapping) and on the store side (mapping of the
+    // later passes): line fastest 64 / TW, point fastest 16.  Wave-uniform table reads (seg_entry_uniform) need them <= 16,
+    // the transposed-tile store <= the consumer's tile (TL): sub-tile workgroups with fewer than 4 lines do not qualify.
+    static constexpr int SPAN_LF = TW >= 64 ? 1 : 64 / TW;
+    static constexpr int SPAN_LOAD = MAP == 1 ? PGRP : SPAN_LF;
+    static constexpr int SPAN_STORE = (MAP != 0 && NPASS > 1) || MAP == 1 ? PGRP : SPAN_LF;
+    static constexpr bool UNI_LOAD = is_pow2(N) && SPAN_LOAD <= 16;
+    static constexpr bool UNI_STORE_SAME = is_pow2(N) && SPAN_STORE <= 16;
+    static constexpr bool UNI_STORE_TRANSPOSE = is_pow2(N) && SPAN_STORE <= TL;
     static_assert((R1 > 1 ? R1 : 1) * (R2 > 1 ? R2 : 1) * (R3 > 1 ? R3 : 1) * (R4 > 1 ? R4 : 1) == N, "radices must multiply to N");
     static_assert(E % R1 == 0 && (R2 <= 1 || E % R2 == 0) && (R3 <= 1 || E % R3 == 0) && (R4 <= 1 || E % R4 == 0), "radix must divide E");
     static_assert(THREADS <= 1024, "workgroup too large");
@@ -439,7 +455,7 @@ template <typename Cfg, bool POINT_FASTEST> __host__ __device__ __forceinline__ 
 template <typename Cfg> __host__ __device__ __forceinline__ int lds_slot(int lw, int n)
 {
     if constexpr (Cfg::kMAP == 0) return lds_pad<Cfg>(n * Cfg::TW + lw);
-    else return lw * Cfg::PITCH + n + (n >> 5);
+    else return lw * Cfg::PITCH + n + (n >> Cfg::PADSH);
 }
 
 // Slot of point n0 + dn when dn is a compile-time constant whose padding separates from n0's
@@ -448,7 +464,7 @@ template <typename Cfg> __host__ __device__ __forceinline__ int lds_slot(int lw,
 template <typename Cfg> constexpr int lds_slot_off(int dn)
 {
     if constexpr (Cfg::kMAP == 0) return dn * Cfg::TW + (((dn * Cfg::TW) >> Cfg::PS) << Cfg::PWS);
-    else return dn + (dn >> 5);
+    else return dn + (dn >> Cfg::PADSH);
 }
 // scatter of pass (RP, NS): point offsets are m*NS.  Line-fastest plane: separable because NS is 1 (then
 // RP == R1 and m*TW stays below the padded block) or a multiple of R1.  Line-major plane: 32-point pad blocks.
@@ -456,14 +472,14 @@ template <typename Cfg, int RP, int NS> constexpr bool scatter_separable()
 {
     if constexpr (!is_pow2(Cfg::kN)) return false;      // mixed radix: the pad blocks are not aligned to the radices
     else if constexpr (Cfg::kMAP == 0) return NS == 1 ? RP == Cfg::r1 : NS % Cfg::r1 == 0;
-    else return NS == 1 ? RP % 32 == 0 : NS % 32 == 0;
+    else return NS == 1 ? RP % Cfg::PADB == 0 : NS % Cfg::PADB == 0;
 }
 // gather: point offsets are NT*c
 template <typename Cfg> constexpr bool gather_separable()
 {
     if constexpr (!is_pow2(Cfg::kN)) return false;
     else if constexpr (Cfg::kMAP == 0) return Cfg::NT % Cfg::r1 == 0;
-    else return Cfg::NT % 32 == 0;
+    else return Cfg::NT % Cfg::PADB == 0 || Cfg::PADB % Cfg::NT == 0;      // t < NT: t + NT*c has the pad count of NT*c either way
 }
 
 // scatter the outputs of pass (RP, NS) to LDS plane, Stockham output index
@@ -493,7 +509,7 @@ template <typename Cfg, int COMP, int RPN>
 __host__ __device__ __forceinline__ void lds_gather_paired(typename Cfg::C *v, const typename Cfg::real *plane, int t, int lw)
 {
     constexpr int S = Cfg::kE / RPN, LEG = Cfg::kN / RPN;
-    constexpr bool SEP = Cfg::kMAP == 0 ? LEG % Cfg::r1 == 0 : LEG % 32 == 0;
+    constexpr bool SEP = Cfg::kMAP == 0 ? LEG % Cfg::r1 == 0 : LEG % Cfg::PADB == 0;
     static_for<0, S>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const int j = pair_j<Cfg, RPN, i>(t);
@@ -599,13 +615,17 @@ __device__ __forceinline__ SegEntry seg_entry(const SegEntry *p)
     return e;
 }
 
-// logical workgroup index: identity, or the XCD-aware remap of the guide (T1, bijective form)
+// logical workgroup index: identity, or the XCD-aware remap of the guide (T1, bijective form).  id / n = (virtual)
+// workgroup index and count: the hardware's for a plain launch, the walked ones of a persistent workgroup.
+template <bool ALWAYS = false> __device__ __forceinline__ uint32_t logical_block(const PassArgs &A, uint32_t id, uint32_t n)
+{
+    if (!ALWAYS && !A.xcd_swizzle) return id;
+    const uint32_t cpx = n >> 3;
+    return id < (cpx << 3) ? (id & 7) * cpx + (id >> 3) : id;
+}
 template <bool ALWAYS = false> __device__ __forceinline__ uint32_t logical_block(const PassArgs &A)
 {
-    const uint32_t id = blockIdx.x;
-    if (!ALWAYS && !A.xcd_swizzle) return id;
-    const uint32_t cpx = gridDim.x >> 3;
-    return id < (cpx << 3) ? (id & 7) * cpx + (id >> 3) : id;
+    return logical_block<ALWAYS>(A, blockIdx.x, gridDim.x);
 }
 
 template <typename Cfg, typename C> __device__ __forceinline__ C stream_load(const C *p)
@@ -628,79 +648,104 @@ template <typename Cfg, typename C> __device__ __forceinline__ void stream_store
     } else *p = v;
 }
 
-template <typename Cfg>
-__global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A)
+// tile and line of a lane.  e = index of the lane's line along the tiled axis.  With A.shift (point-major stores whose
+// row pitch is not a multiple of the tile) the window of a workgroup is moved back by the row's misalignment, so that
+// its TL stores per point fill exactly one aligned 128-byte line; (b, l, tw) then describe where that line lives in
+// the (unshifted) tiled input.
+template <int TL> struct TilePos {
+    uint32_t a, b, tw, e;
+    int l;
+    bool ok;
+};
+template <typename Cfg> __device__ __forceinline__ TilePos<Cfg::kTL> tile_pos(const PassArgs &A, uint32_t blk, int lwx)
+{
+    constexpr int TL = Cfg::kTL;
+    TilePos<TL> P;
+    uint32_t w;
+    if constexpr (Cfg::kSUB > 1) {          // sub-tile workgroup: lines [sub*TLK, sub*TLK + TLK) of tile blk / SUB
+        w = blk / Cfg::kSUB;
+        P.l = (int)(blk % Cfg::kSUB) * Cfg::TLK + lwx;
+    } else if constexpr (Cfg::kG == 1) {    // one tile per workgroup: (a, b, tw) are workgroup-uniform (scalar registers)
+        w = blk;
+        P.l = lwx;
+    } else {
+        w = blk * Cfg::kG + lwx / TL;
+        P.l = lwx % TL;
+    }
+    bool ok = w < A.ntiles;
+    P.a = !ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
+    P.b = !ok ? 0 : (A.a_fastest ? w / A.na : w % A.nb);
+    if (A.shift) {
+        const uint32_t s = (uint32_t)((uint64_t)P.a * A.AS_out) & (uint32_t)(TL - 1);
+        const int ei = (int)(P.b * TL + P.l) - (int)s;
+        ok = ok && ei >= 0 && (uint32_t)ei < A.LB;
+        P.e = ok ? (uint32_t)ei : 0;
+        P.b = P.e / TL;
+        P.l = (int)(P.e % TL);
+        const uint32_t rem = A.LB - P.b * TL;
+        P.tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;
+        P.ok = ok;
+        return P;
+    }
+    const uint32_t rem = A.LB - P.b * TL;
+    P.tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;     // valid lines of this tile
+    P.e = P.b * TL + P.l;
+    P.ok = ok && (uint32_t)P.l < P.tw;
+    return P;
+}
+
+// Wave-uniform table entries.  A wave covers SPAN consecutive values of t (line fastest: 64 / TW, point fastest: 16)
+// starting at a multiple of SPAN, and every compile-time point offset (NT*c, N/RL) is a multiple of SPAN when N is a
+// power of two.  If every segment of a side starts at a multiple of 16 points (the host checks: PassArgs::luni / suni),
+// the SPAN points a wave touches per register lie in ONE segment and their table entries differ only by the lane's
+// t - t0: the entry of lane 0's point is fetched with a SCALAR load (s_load_dwordx4 through the constant cache, no
+// vector-memory issue slot, no VGPRs) and the address becomes a scalar base plus one per-lane offset that does not
+// depend on the point -- the segmented side then costs what the single-segment closed form costs (the per-point vector
+// load of a 16-byte entry cost as much address-pipeline time as the 8- / 16-byte point it located: +47-73 % on the fp32
+// 2048-point passes, profiles/r2_f32_2048_multirank_kernel_stats.csv).
+__device__ __forceinline__ SegEntry seg_entry_uniform(const SegEntry *p)      // p must be wave-uniform
+{
+    const uint4 r = *reinterpret_cast<const uint4 *>(p);
+    SegEntry e;
+    e.base = (uint64_t)r.x | ((uint64_t)r.y << 32);
+    e.ln = r.z;
+    e.aux = r.w;
+    return e;
+}
+
+// loads registers [C0, C1) of the lane (register c holds point t + NT*c); v[c] must be valid for that range
+template <typename Cfg, int C0 = 0, int C1 = Cfg::kE>
+__device__ __forceinline__ void load_tile(const PassArgs &A, const typename Cfg::C *__restrict__ in, const TilePos<Cfg::kTL> &P,
+                                          int t, typename Cfg::C *v)
 {
     using C = typename Cfg::C;
-    using R = typename Cfg::real;
-    constexpr int N = Cfg::kN, E = Cfg::kE, TL = Cfg::kTL, NT = Cfg::NT;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    R *lds = reinterpret_cast<R *>(smem);
-
-    const int tid = threadIdx.x;
-    // coordinates for the load / first pass, and for the later passes / the store
-    constexpr bool PF_FIRST = Cfg::kMAP == 1, PF_REST = Cfg::kMAP != 0 && Cfg::NPASS > 1 ? true : Cfg::kMAP == 1;
-    int lw, t, lw2, t2;
-    thread_map<Cfg, PF_FIRST>(tid, lw, t);
-    thread_map<Cfg, PF_REST>(tid, lw2, t2);
-
-    // tile of a line (workgroup index, b fastest or a fastest, optionally XCD-remapped)
-    const uint32_t blk = logical_block<(Cfg::kSUB > 1)>(A);
-    // e = index of the lane's line along the tiled axis.  With A.shift (point-major stores whose
-    // row pitch is not a multiple of the tile) the window of a workgroup is moved back by the row's
-    // misalignment, so that its TL stores per point fill exactly one aligned 128-byte line; (b, l, tw)
-    // then describe where that line lives in the (unshifted) tiled input.
-    auto tile_of = [&](int lwx, uint32_t &a, uint32_t &b, uint32_t &tw, int &l, uint32_t &e) -> bool {
-        uint32_t w;
-        if constexpr (Cfg::kSUB > 1) {          // sub-tile workgroup: lines [sub*TLK, sub*TLK + TLK) of tile blk / SUB
-            w = blk / Cfg::kSUB;
-            l = (int)(blk % Cfg::kSUB) * Cfg::TLK + lwx;
-        } else {
-            w = blk * Cfg::kG + lwx / TL;
-            l = lwx % TL;
-        }
-        bool ok = w < A.ntiles;
-        a = !ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
-        b = !ok ? 0 : (A.a_fastest ? w / A.na : w % A.nb);
-        if (A.shift) {
-            const uint32_t s = (uint32_t)((uint64_t)a * A.AS_out) & (uint32_t)(TL - 1);
-            const int ei = (int)(b * TL + l) - (int)s;
-            ok = ok && ei >= 0 && (uint32_t)ei < A.LB;
-            e = ok ? (uint32_t)ei : 0;
-            b = e / TL;
-            l = (int)(e % TL);
-            const uint32_t rem = A.LB - b * TL;
-            tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;
-            return ok;
-        }
-        const uint32_t rem = A.LB - b * TL;
-        tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;     // valid lines of this tile
-        e = b * TL + l;
-        return ok && (uint32_t)l < tw;
-    };
-    uint32_t a, b, tw, e1;
-    int l;
-    const bool active = tile_of(lw, a, b, tw, l, e1);
-
-    const C *__restrict__ in = reinterpret_cast<const C *>(A.in);
-    C *__restrict__ out = reinterpret_cast<C *>(A.out);
-    const C *__restrict__ W = reinterpret_cast<const C *>(A.tw);
-
-    C v[E];
-    // ------------------------------------------------------------------ load
-    if (active) {
+    constexpr int N = Cfg::kN, TL = Cfg::kTL, NT = Cfg::NT;
+    const uint32_t a = P.a, b = P.b, tw = P.tw;
+    const int l = P.l;
+    if (P.ok) {
         if (A.load_kind == LOAD_LINES) {
             const uint64_t row = A.KS_in ? (uint64_t)a * A.AS_in + ((uint64_t)b * TL + l) * A.KS_in
                                          : ((uint64_t)a * A.LB + (uint64_t)b * TL + l) * N;
             const C *p = in + row + t;
-            static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = stream_load<Cfg>(p + NT * c); });
+            static_for<C0, C1>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = stream_load<Cfg>(p + NT * c); });
         } else if (A.load_kind == LOAD_KMAJOR) {
             const C *p = in + (uint64_t)a * A.AS_in + (uint64_t)b * TL + l + (uint64_t)t * A.KS_in;
-            static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = stream_load<Cfg>(p + (uint64_t)(NT * c) * A.KS_in); });
+            static_for<C0, C1>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = stream_load<Cfg>(p + (uint64_t)(NT * c) * A.KS_in); });
         } else {
-            if (A.ltab) {
+            if (Cfg::UNI_LOAD && A.ltab && A.luni) {
+                const int t0 = __builtin_amdgcn_readfirstlane(t);
                 const uint32_t Q = a * A.LB + b * TL;
-                static_for<0, E>([&](auto cc) {
+                const uint32_t lane = ((uint32_t)(t - t0) * tw + (uint32_t)l) * (uint32_t)sizeof(C);      // bytes, same for every point
+                const SegEntry *tab = A.ltab + t0;
+                static_for<C0, C1>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    const SegEntry e = seg_entry_uniform(tab + NT * c);
+                    const char *pu = reinterpret_cast<const char *>(in + (e.base + (uint64_t)e.ln * Q + (uint64_t)e.aux * tw));
+                    v[c] = stream_load<Cfg>(reinterpret_cast<const C *>(pu + lane));
+                });
+            } else if (A.ltab) {
+                const uint32_t Q = a * A.LB + b * TL;
+                static_for<C0, C1>([&](auto cc) {
                     constexpr int c = decltype(cc)::value;
                     const SegEntry e = seg_entry(A.ltab + (t + NT * c));
                     v[c] = stream_load<Cfg>(in + e.base + (uint64_t)e.ln * Q + (uint64_t)e.aux * tw + l);
@@ -709,9 +754,9 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
                 const uint64_t len = A.lseg->len[0];
                 const uint64_t ia = A.IA ? A.IA : len * A.LB, ib = A.IB ? A.IB : (uint64_t)TL * len;
                 const C *p = in + A.lseg->base[0] + (uint64_t)a * ia + (uint64_t)b * ib + l + (uint64_t)t * tw;
-                static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = stream_load<Cfg>(p + (uint64_t)(NT * c) * tw); });
+                static_for<C0, C1>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = stream_load<Cfg>(p + (uint64_t)(NT * c) * tw); });
             } else {
-                static_for<0, E>([&](auto cc) {
+                static_for<C0, C1>([&](auto cc) {
                     constexpr int c = decltype(cc)::value;
                     const uint32_t n = t + NT * c;
                     uint32_t s0 = A.lseg->start[0], ln = A.lseg->len[0];
@@ -723,49 +768,74 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
             }
         }
     } else {
-        static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].x = 0; v[c].y = 0; });
+        static_for<C0, C1>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].x = 0; v[c].y = 0; });
     }
-    // inverse transform = conj(forward(conj(x))): one multiplication by +-1 per point and side, no
-    // branch and no second copy of the data (a conditional re<->im swap costs both: the compiler keeps
-    // the swapped and the unswapped registers alive across the branch, +64 VGPRs at 32 points per thread)
-    const R sgn = A.swap ? (R)-1 : (R)1;
-    static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].y *= sgn; });
+}
 
-    // ------------------------------------------------------------------ passes
-    if (!(A.debug & 1)) transform<Cfg>(v, lds, W, t, lw, t2, lw2);
-
-    static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].y *= sgn; });
-
-    // ------------------------------------------------------------------ store (coordinates of the later passes)
-    uint32_t a2, b2, tws, e2;
-    int l2;
-    if (!tile_of(lw2, a2, b2, tws, l2, e2)) return;
+// register c = i + mr*S holds output k = t2 + NT*i + brev(mr)*(N/RL)   (RL = radix of the last pass, S = E / RL)
+// stores registers [C0, C1) of the lane
+template <typename Cfg, int C0 = 0, int C1 = Cfg::kE>
+__device__ __forceinline__ void store_tile(const PassArgs &A, typename Cfg::C *__restrict__ out, const TilePos<Cfg::kTL> &P,
+                                           int t2, const typename Cfg::C *v)
+{
+    using C = typename Cfg::C;
+    constexpr int N = Cfg::kN, E = Cfg::kE, TL = Cfg::kTL, NT = Cfg::NT;
     constexpr int RL = Cfg::RLAST;     // radix of the last pass
     constexpr int S = E / RL;
-    // register c = i + mr*S holds output k = t2 + NT*i + brev(mr)*(N/RL)
+    if (!P.ok) return;
+    const uint32_t a2 = P.a, b2 = P.b, tws = P.tw, e2 = P.e;
+    const int l2 = P.l;
     if (A.store_kind == STORE_LINES) {
         // natural lines, or (KS_out != 0) rows at a*AS_out + line*KS_out: the z pass of the Y_Then_ZX sequence
         const uint64_t row = A.KS_out ? (uint64_t)a2 * A.AS_out + ((uint64_t)b2 * TL + l2) * A.KS_out
                                       : ((uint64_t)a2 * A.LB + (uint64_t)b2 * TL + l2) * N;
         C *p = out + row + t2;
-        static_for<0, E>([&](auto cc) {
+        static_for<C0, C1>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
             stream_store<Cfg>(p + k0, v[c]);
         });
     } else if (A.store_kind == STORE_KMAJOR) {
         C *p = out + (uint64_t)a2 * A.AS_out + e2 + (uint64_t)t2 * A.KS_out;
-        static_for<0, E>([&](auto cc) {
+        static_for<C0, C1>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
             stream_store<Cfg>(p + (uint64_t)k0 * A.KS_out, v[c]);
         });
+    } else if ((A.store_kind == STORE_TILED_SAME ? Cfg::UNI_STORE_SAME : Cfg::UNI_STORE_TRANSPOSE) && A.stab && A.suni) {
+        // wave-uniform entries (see seg_entry_uniform): lane 0's entry per register, the lane's own t2 - t0 added in closed form
+        const int t0 = __builtin_amdgcn_readfirstlane(t2);
+        const uint32_t dt = (uint32_t)(t2 - t0);
+        const SegEntry *tab = A.stab + t0;
+        if (A.store_kind == STORE_TILED_SAME) {
+            // entry.base = block base + (k - start)*SK: the lane part dt*SK + (b*SB + a*tw + l) is the same for every point
+            const uint64_t sk = A.SK ? A.SK : (uint64_t)A.LB * A.LA;
+            C *pl = out + ((uint64_t)b2 * (A.SB ? A.SB : (uint64_t)TL * A.LA) + (uint64_t)a2 * tws + l2 + (uint64_t)dt * sk);
+            static_for<C0, C1>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
+                const SegEntry e = seg_entry_uniform(tab + k0);
+                stream_store<Cfg>(pl + e.base, v[c]);
+            });
+        } else {
+            // entry.base = block base + kt*T2*LB + kr, aux = width of the consumer tile: kr of the lane is kr + dt
+            const uint32_t line = b2 * TL + l2;
+            const uint32_t aLB = a2 * A.LB;
+            static_for<C0, C1>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
+                const SegEntry e = seg_entry_uniform(tab + k0);
+                char *pu = reinterpret_cast<char *>(out + (e.base + (uint64_t)e.ln * aLB));
+                const uint32_t lane = (line * e.aux + dt) * (uint32_t)sizeof(C);
+                stream_store<Cfg>(reinterpret_cast<C *>(pu + lane), v[c]);
+            });
+        }
     } else if (A.stab) {
         const bool same = A.store_kind == STORE_TILED_SAME;
         const uint32_t line = b2 * TL + l2;
         const uint64_t fixed = same ? (uint64_t)b2 * (A.SB ? A.SB : (uint64_t)TL * A.LA) + (uint64_t)a2 * tws + l2 : 0;
         const uint32_t aLB = a2 * A.LB;
-        static_for<0, E>([&](auto cc) {
+        static_for<C0, C1>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
             const SegEntry e = seg_entry(A.stab + (t2 + k0));
@@ -773,7 +843,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
             stream_store<Cfg>(out + off, v[c]);
         });
     } else {
-        static_for<0, E>([&](auto cc) {
+        static_for<C0, C1>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
             const uint32_t k = t2 + k0;
@@ -795,6 +865,97 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
             }
             stream_store<Cfg>(out + off, v[c]);
         });
+    }
+}
+
+template <typename Cfg>
+__global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A)
+{
+    using C = typename Cfg::C;
+    using R = typename Cfg::real;
+    constexpr int E = Cfg::kE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    R *lds = reinterpret_cast<R *>(smem);
+
+    const int tid = threadIdx.x;
+    // coordinates for the load / first pass, and for the later passes / the store
+    constexpr bool PF_FIRST = Cfg::kMAP == 1, PF_REST = Cfg::kMAP != 0 && Cfg::NPASS > 1 ? true : Cfg::kMAP == 1;
+    int lw, t, lw2, t2;
+    thread_map<Cfg, PF_FIRST>(tid, lw, t);
+    thread_map<Cfg, PF_REST>(tid, lw2, t2);
+
+    const C *__restrict__ in = reinterpret_cast<const C *>(A.in);
+    C *__restrict__ out = reinterpret_cast<C *>(A.out);
+    const C *__restrict__ W = reinterpret_cast<const C *>(A.tw);
+    // inverse transform = conj(forward(conj(x))): one multiplication by +-1 per point and side, no
+    // branch and no second copy of the data (a conditional re<->im swap costs both: the compiler keeps
+    // the swapped and the unswapped registers alive across the branch, +64 VGPRs at 32 points per thread)
+    const R sgn = A.swap ? (R)-1 : (R)1;
+
+    if constexpr (!Cfg::kPERSIST) {
+        // workgroup -> tile (b fastest or a fastest, optionally XCD-remapped)
+        const uint32_t blk = logical_block<(Cfg::kSUB > 1)>(A, blockIdx.x, gridDim.x);
+        C v[E];
+        load_tile<Cfg>(A, in, tile_pos<Cfg>(A, blk, lw), t, v);
+        static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].y *= sgn; });
+        if (!(A.debug & 1)) transform<Cfg>(v, lds, W, t, lw, t2, lw2);
+        static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].y *= sgn; });
+        store_tile<Cfg>(A, out, tile_pos<Cfg>(A, blk, lw2), t2, v);
+    } else if constexpr (Cfg::kPERSIST == 1) {
+        // Persistent, software-pipelined form for configurations that leave room for only ONE workgroup on a CU (a tile of
+        // 16 lines x 1024 fp64 points is the LDS plane of a CU): the grid is one workgroup per CU, each walks the tiles
+        // blockIdx.x, blockIdx.x + gridDim.x, ... and issues the global loads of its NEXT tile into a second register set
+        // before it transforms the current one, so that the memory system works during the butterflies, LDS exchanges and
+        // barriers (two tiles in flight per CU, like two resident workgroups, inside the 512 registers a lane has at two
+        // waves per SIMD).  The virtual workgroup index keeps the XCD of the hardware workgroup (gridDim.x % 8 == 0).
+        const uint32_t nwg = (A.ntiles + Cfg::kG - 1) / Cfg::kG * Cfg::kSUB;
+        uint32_t vid = blockIdx.x;
+        C vn[E];
+        load_tile<Cfg>(A, in, tile_pos<Cfg>(A, logical_block<(Cfg::kSUB > 1)>(A, vid, nwg), lw), t, vn);
+        for (;;) {
+            C v[E];
+            static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = vn[c]; v[c].y *= sgn; });
+            const uint32_t cur = logical_block<(Cfg::kSUB > 1)>(A, vid, nwg);
+            vid += gridDim.x;
+            const bool more = vid < nwg;
+            if (more) load_tile<Cfg>(A, in, tile_pos<Cfg>(A, logical_block<(Cfg::kSUB > 1)>(A, vid, nwg), lw), t, vn);
+            if (!(A.debug & 1)) transform<Cfg>(v, lds, W, t, lw, t2, lw2);
+            static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].y *= sgn; });
+            store_tile<Cfg>(A, out, tile_pos<Cfg>(A, cur, lw2), t2, v);
+            if (!more) break;
+            if constexpr (Cfg::NPASS > 1) __syncthreads();      // the next tile's first scatter reuses the LDS plane
+        }
+    } else {
+        // PERSIST == 2: the same walk with HALF of the next tile prefetched during the transform, for configurations whose
+        // points fill half of the registers of a lane (32 fp64 points at two waves per SIMD: 128 of 256 registers).  The
+        // other half is requested between the two halves of the current tile's stores, into the registers the first half
+        // of the stores has just freed, so that the memory system always has at least half a tile of reads outstanding.
+        constexpr int H = E / 2;
+        const uint32_t nwg = (A.ntiles + Cfg::kG - 1) / Cfg::kG * Cfg::kSUB;
+        uint32_t vid = blockIdx.x;
+        C va[H], vb[H];
+        {
+            const TilePos<Cfg::kTL> P0 = tile_pos<Cfg>(A, logical_block<(Cfg::kSUB > 1)>(A, vid, nwg), lw);
+            load_tile<Cfg, 0, H>(A, in, P0, t, va);
+            load_tile<Cfg, H, E>(A, in, P0, t, vb - H);
+        }
+        for (;;) {
+            C v[E];
+            static_for<0, H>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = va[c]; v[c].y *= sgn; v[c + H] = vb[c]; v[c + H].y *= sgn; });
+            const uint32_t cur = logical_block<(Cfg::kSUB > 1)>(A, vid, nwg);
+            vid += gridDim.x;
+            const bool more = vid < nwg;
+            const TilePos<Cfg::kTL> Pn = tile_pos<Cfg>(A, logical_block<(Cfg::kSUB > 1)>(A, more ? vid : cur, nwg), lw);
+            if (more) load_tile<Cfg, 0, H>(A, in, Pn, t, va);
+            if (!(A.debug & 1)) transform<Cfg>(v, lds, W, t, lw, t2, lw2);
+            static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].y *= sgn; });
+            const TilePos<Cfg::kTL> Ps = tile_pos<Cfg>(A, cur, lw2);
+            store_tile<Cfg, 0, H>(A, out, Ps, t2, v);
+            if (more) load_tile<Cfg, H, E>(A, in, Pn, t, vb - H);
+            store_tile<Cfg, H, E>(A, out, Ps, t2, v);
+            if (!more) break;
+            if constexpr (Cfg::NPASS > 1) __syncthreads();
+        }
     }
 }
 

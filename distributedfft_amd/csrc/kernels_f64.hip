@@ -17,8 +17,10 @@ using F64_1024 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1>;
 using F64_2048 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1>;
 // The variant number of a configuration is its ROLE in a plan (dfft_init picks by role, see PassRole):
 //   1 = strided read: passes that load the point-major API layout (multi-rank inverse x pass): 16 lines per workgroup
-//       (256-byte runs per row), 32 points per thread (twice the loads in flight), nontemporal loads and stores
-//       (7.9 -> 7.6 ms at 1024^3; 8.9 ms with the default configuration)
+//       (two tiles of 8: 128-byte runs from two neighbouring rows per point), 32 points per thread (twice the loads in
+//       flight), nontemporal loads and stores (7.9 -> 7.6 ms at 1024^3; 8.9 ms with the default configuration).  2048 points:
+//       the streaming configuration (18.8 -> 17.5 ms on 2048 x 1024 x 1024; 32 points per thread lose there, one or two
+//       workgroups per CU alike: profiles/r3_strided_read_variants.txt)
 //   3 = streaming: nontemporal loads and stores, for passes whose stores come in long runs (tiled 1 KiB chunks,
 //       natural lines): +2-3 %; it costs up to 10 % on 128-byte-run stores, so those keep 0
 //   7 = natural lines: a pass with natural lines on one side.  Only 2048 has its own: 8 lines x 2048 points are
@@ -43,10 +45,22 @@ using F64_8192 = PassCfg<double, 8192, 32, 8, 1, 32, 16, 16, 1, 1, 1, 0, 0, 8>;
 // whole-tile 64-point forms, 32-point fp64 2048, ...) were removed after they were measured: results in profiles/r2_*.txt and
 // DESIGN.md section 6, definitions in the git history (commit c38cf04).  New ones go here, under -DDFFT_EXPERIMENTS:
 
+// persistent, software-pipelined forms (PassCfg::PERSIST) under test
+using F64_1024_v8 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 3, 0, 1, 1>;
+using F64_1024_v9 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 0, 0, 1, 1>;
+using F64_2048_v8 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 0, 0, 1, 1>;
+using F64_2048_v9 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 0, 0, 1, 0>;
+using F64_2048_v10 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 3, 0, 1, 2>;
+using F64_1024_v10 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 3, 0, 1, 2>;
+using F64_1024_v11 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 0, 0, 1, 2>;
+// 32 points per thread on ONE tile of 8 lines: 256 threads, 68 KiB of LDS -> two independent workgroups per CU
+using F64_1024_v12 = PassCfg<double, 1024, 32, 8, 1, 32, 32, 1, 1, 1, 1, 3>;
+using F64_1024_v13 = PassCfg<double, 1024, 32, 8, 1, 32, 32, 1, 1, 1, 1, 0>;
+using F64_2048_v12 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 3, 0, 2>;
 #ifdef DFFT_EXPERIMENTS
 #define DFFT_F64_EXP_SMALL(X)
-#define DFFT_F64_EXP_1024(X)
-#define DFFT_F64_EXP_2048(X)
+#define DFFT_F64_EXP_1024(X) X(1024, 8, F64_1024_v8) X(1024, 9, F64_1024_v9) X(1024, 10, F64_1024_v10) X(1024, 11, F64_1024_v11) X(1024, 12, F64_1024_v12) X(1024, 13, F64_1024_v13)
+#define DFFT_F64_EXP_2048(X) X(2048, 8, F64_2048_v8) X(2048, 9, F64_2048_v9) X(2048, 10, F64_2048_v10) X(2048, 12, F64_2048_v12)
 #else
 #define DFFT_F64_EXP_SMALL(X)
 #define DFFT_F64_EXP_1024(X)
@@ -54,7 +68,7 @@ using F64_8192 = PassCfg<double, 8192, 32, 8, 1, 32, 16, 16, 1, 1, 1, 0, 0, 8>;
 #endif
 #define DFFT_F64_LIST_SMALL(X) X(512, 1, F64_512_v1) X(512, 3, F64_512_v3) X(2, 0, F64_2) X(4, 0, F64_4) X(8, 0, F64_8) X(16, 0, F64_16) X(32, 0, F64_32) X(64, 0, F64_64) X(128, 0, F64_128) X(256, 0, F64_256) X(512, 0, F64_512) DFFT_F64_EXP_SMALL(X)
 #define DFFT_F64_LIST_1024(X) X(1024, 1, F64_1024_v1) X(1024, 3, F64_1024_v3) X(1024, 0, F64_1024) DFFT_F64_EXP_1024(X)
-#define DFFT_F64_LIST_2048(X) X(2048, 3, F64_2048_v3) X(2048, 7, F64_2048_v7) X(2048, 0, F64_2048) X(4096, 0, F64_4096) X(8192, 0, F64_8192) DFFT_F64_EXP_2048(X)
+#define DFFT_F64_LIST_2048(X) X(2048, 1, F64_2048_v3) X(2048, 3, F64_2048_v3) X(2048, 7, F64_2048_v7) X(2048, 0, F64_2048) X(4096, 0, F64_4096) X(8192, 0, F64_8192) DFFT_F64_EXP_2048(X)
 
 // lengths that are not powers of two (mixed radix 2, 3, 5, 7): generated list, slices 5 (N < 512) and 6
 #define DFFT_MIXED_F64

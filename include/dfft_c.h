@@ -92,6 +92,12 @@ int dfft_comm_create_callback(int nranks, int rank, dfft_alltoallv_fn fn, void *
  * (ncclCommCount for the RCCL transport, 0 for the others), so that a caller can verify that RCCL really
  * spans the ranks it claims */
 int dfft_comm_info(const dfft_comm *comm, int *nranks, int *transport_nranks);
+/* transport knobs.  "dup_channel" = 1 (RCCL transport only; COLLECTIVE -- every rank of the communicator calls it at
+ * the same point): duplicate the communicator (ncclCommSplit) for the second exchange of pencil plans, so that the row-
+ * and the column-group exchange -- which use disjoint xGMI links -- may be on the wire at the same time; without it one
+ * ncclComm serialises them.  Replaces nothing in the reference (its two MPI sub-communicators are independent by
+ * construction, src/pencil/mpicufft_pencil_opt1.cpp:103-104).  Returns 0, or nonzero for an unknown key / a failure. */
+int dfft_comm_set_option(dfft_comm *comm, const char *key, long value);
 /* destroy the plans that use a communicator before the communicator itself */
 int dfft_comm_destroy(dfft_comm *comm);
 

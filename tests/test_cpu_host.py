@@ -395,3 +395,35 @@ def test_bench_dry_run_plans_c4_and_c5_for_all_ranks():
     assert d["C5"]["domain_GiB"] == 8.0 and d["C5"]["work_GiB"] == 24.0 and d["C5"]["fits_288_GB"]
     assert d["C5"]["per_gpu_total_GiB (in + out + back + work)"] == 48.0
     assert d["C3"]["partition"] == "2x1" and d["C4-slab"]["work_GiB"] == 4.0
+
+
+def test_bench_partitions_and_xgmi_model():
+    """bench.py helpers (no GPU): the headline decomposition at N > 1 is the one BASELINE.json names, and the xGMI model
+    charges every link of an exchange group with 1/P of the local volume at 153 GB/s"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.choose_partition(8, "auto") == (2, 4) and b.choose_partition(4, "auto") == (2, 2) and b.choose_partition(2, "auto") == (2, 1)
+    assert b.choose_partition(8, "slab") == (8, 1) and b.choose_partition(8, "pencil") == (2, 4)
+    m = b.xgmi_model(16, 1024, 8, 2, 4)
+    vol = 16 * 1024 ** 3 / 8
+    assert m["exchange 1"]["links"] == 3 and m["exchange 1"]["bytes_per_link"] == vol / 4
+    assert m["exchange 2"]["links"] == 1 and m["exchange 2"]["bytes_per_link"] == vol / 2
+    assert abs(m["exchange 2"]["predicted_ms"] - vol / 2 / 153e9 * 1e3) < 1e-3
+    s8 = b.xgmi_model(16, 1024, 8, 8, 1)
+    assert set(s8) == {"exchange 2"} and s8["exchange 2"]["links"] == 7
+
+
+def test_comm_options_and_variant_range():
+    """dfft_comm_set_option: transports without the option say so; variant_* outside 0..15 is rejected (the dispatch key has
+    four bits for the variant)"""
+    world = dfft.Comm.local(2)
+    with pytest.raises(dfft.DfftError):
+        world.setOption("dup_channel", 1)
+    plan = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), precision="double")
+    with pytest.raises(dfft.DfftError, match="variant"):
+        plan.setOption("variant_fy", 16)
+    plan.setOption("variant_fy", 15)
+    plan.setOption("uniform_tables", 0)
+    assert plan.getOption("uniform_tables") == 0

@@ -69,14 +69,15 @@ def test_slab_sequence_z_then_yx_testcases(tmp_path):
 
 @pytest.mark.parametrize("mode,extra,nproc", [("pencil", ["-p1", "2", "-p2", "2", "-o", "1", "-t", "3", "-i", "2", "-w", "1"], 4),
                                               ("slab", ["-p", "3", "-t", "4"], 3),
-                                              ("pencil", ["-p1", "3", "-p2", "2", "-t", "1"], 6)])
+                                              ("pencil", ["-p1", "3", "-p2", "2", "-t", "1"], 6),
+                                              ("pencil", ["-p1", "2", "-p2", "2", "-t", "1", "--complex"], 4)])
 def test_one_process_per_rank_under_torch_distributed_run(tmp_path, mode, extra, nproc):
     """the reference's `mpiexec -n P ./pencil ...` (tests/src/pencil/main.cpp:194-229): P processes, one rank each, here
     sharing the single GPU of the test box over gloo; error norms reduced over ranks, rank 0 writes the CSV"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 29600 + nproc
+    port = 29600 + nproc + (20 if "--complex" in extra else 0)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), "-m", "distributedfft_amd.cli", mode, "-nx", "48", "-ny", "32", "-nz", "40", "-d",
            "-b", str(tmp_path), "--backend", "gloo"] + extra

@@ -53,6 +53,13 @@ def test_bench_runs_on_all_gpus():
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == nproc and line["round_trip_rel_linf"] < 1e-10
     assert line["config"]["alt"]["round_trip_rel_linf"] < 1e-10 if "alt" in line["config"] else True
+    # the headline is the decomposition BASELINE.json names: pencil 2x2 / 2x4 at 4 / 8 GPUs (slab over all ranks is the alt)
+    if nproc >= 4:
+        assert line["config"]["decomposition"].startswith("pencil"), line["config"]["decomposition"]
+        assert line["config"]["alt"]["decomposition"].startswith("slab")
+    for name, m in line["xgmi"]["per_exchange_per_transform"].items():
+        assert m["predicted_ms"] > 0 and m["links"] == m["group_ranks"] - 1
+    assert "hidden_frac" in line["overlap"]
 
 
 @pytest.mark.parametrize("kind,transport", [("slab", "rccl"), ("pencil", "torch")])

@@ -1,0 +1,330 @@
+"""Round-3 parity additions (VERDICT r2 "next round" 3):
+
+* C4 (1024^3 fp64: pencil 2x4, slab 8, R2C 2x4) compared with the CPU oracle at EVERY point -- the oracle transforms
+  1024^3 in a few seconds on the GPU box's host, so the spot checks of test_gpu_fullsize.py are not the limit.
+* C5 at full size: 2048^3 fp32 on one GPU (in = back aliased, like bench.py): direct-DFT entries, Parseval, round trip.
+* the single-rank pass order z, x, y (build_pipeline_single) forced on small grids: both precisions, both L2 layouts,
+  padded and packed rows, ragged tiles, mixed-radix, Bluestein and one 4096-point axis.
+* the packed real z passes of EVERY generated mixed-radix length (DFFT_*_LIST_RMIXED* of csrc/kernels_mixed.inc).
+* wave-uniform (scalar) table reads against the per-lane table reads on segmented plans (option uniform_tables).
+"""
+import ctypes as C
+import math
+import os
+import re
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import distributedfft_amd as dfft  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+from test_gpu_fullsize import direct_dft_entry, make_world, owner_entry, run_all, spectrum_block  # noqa: E402
+from test_gpu_parity import (CDT, NPDT, NPR, TOL_FWD, TOL_RT, rel, run_distributed, run_distributed_real,  # noqa: E402
+                             run_single)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def host_free_gib():
+    try:
+        import psutil
+        return psutil.virtual_memory().available / 2 ** 30
+    except Exception:  # noqa: BLE001
+        return 0.0
+
+
+def gpu_free_gib():
+    free_b, _ = torch.cuda.mem_get_info()
+    return free_b / 2 ** 30
+
+
+# ------------------------------------------------------------------------------------------
+# C4 at every point
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("P1,P2,c2c", [(2, 4, True), (8, 1, True), (2, 4, False)])
+def test_c4_1024_fp64_every_point_vs_oracle(P1, P2, c2c):
+    """BASELINE C4: 1024^3 fp64 on the pencil 2x4 grid (and slab 8, and the reference's own R2C API on 2x4), every rank a
+    virtual rank of this GPU.  The global input is gathered on the host, transformed by the oracle (in place, OpenMP), and
+    every rank's spectrum block is compared with the oracle's at every point, on the device."""
+    need_host = 20 if c2c else 20
+    if host_free_gib() < need_host:
+        pytest.skip(f"needs {need_host} GiB of free host memory for the 1024^3 oracle transform, {host_free_gib():.0f} GiB free")
+    if gpu_free_gib() < 110:
+        pytest.skip(f"needs 110 GiB of free HBM (8 virtual ranks), {gpu_free_gib():.0f} GiB free")
+    shape = (1024, 1024, 1024)
+    n3 = float(np.prod(shape))
+    ranks = make_world(shape, P1, P2, "double", c2c=c2c)
+    g = np.empty(shape, dtype=np.complex128 if c2c else np.float64)
+    for rk in ranks:
+        s, o = rk["plan"].getInSize(), rk["plan"].getInStart()
+        g[o[0]:o[0] + s[0], o[1]:o[1] + s[1], :] = rk["x"].cpu().numpy()
+    if c2c:
+        run_all(ranks, lambda rk: rk["plan"].execC2C(rk["out"], rk["x"], dfft.FORWARD))
+        orc.lib().orc_fft3d_c2c(g.ctypes.data_as(C.c_void_p), *shape, -1)       # in place: g is the spectrum now
+        want = g
+    else:
+        run_all(ranks, lambda rk: rk["plan"].execR2C(rk["out"], rk["x"]))
+        want = orc.fft3d_r2c(g)
+        del g
+    scale = float(np.abs(want[0, 0, 0]))        # the DC term is the largest entry of a non-negative input
+    worst = 0.0
+    for rk in ranks:
+        s, o = rk["plan"].getOutSize(), rk["plan"].getOutStart()
+        ref = torch.from_numpy(np.ascontiguousarray(want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]])).cuda()
+        worst = max(worst, float((spectrum_block(rk) - ref).abs().max()) / scale)
+        del ref
+    assert worst < 1e-11, worst
+    del want
+    if c2c:
+        run_all(ranks, lambda rk: rk["plan"].execC2C(rk["back"], rk["out"], dfft.INVERSE))
+    else:
+        run_all(ranks, lambda rk: rk["plan"].execC2R(rk["back"], rk["out"]))
+    for rk in ranks:
+        assert float((rk["back"] / n3 - rk["x"]).abs().max()) / 255.0 < 1e-10
+
+
+# ------------------------------------------------------------------------------------------
+# C5 at full size on one GPU
+# ------------------------------------------------------------------------------------------
+def test_c5_2048_fp32_full_size_single_gpu():
+    """BASELINE C5's grid, 2048^3 fp32 complex (64 GiB per buffer), on one MI355X with the inverse written back over the
+    input like bench.py does: spectrum entries against a direct DFT accumulated in fp64 slab by slab, Parseval, and the
+    round trip against the regenerated input.  (The 8-GPU decomposition of this grid does not fit one GPU as virtual
+    ranks: 8 x (in + out + 3 work slices); its kernels and layouts run in test_c5_fp32_axis_2048_and_1024_cube.)"""
+    N = 2048
+    if gpu_free_gib() < 215:
+        pytest.skip(f"needs 215 GiB of free HBM (in 64 + out 64 + padded work area 64-72 GiB), {gpu_free_gib():.0f} GiB free")
+    n = N ** 3
+    plan = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), precision="float")
+    plan.initFFT(dfft.GlobalSize(N, N, N), dfft.Pencil_Partition(1, 1), True, c2c=True)
+    x = torch.empty(n, dtype=torch.complex64, device="cuda")
+    out = torch.empty(plan.getDomainSize() // 8, dtype=torch.complex64, device="cuda")
+    planes = 16                                  # x planes per slab: 16 * 2048^2 points = 512 MiB of complex64
+    slab = planes * N * N
+
+    def regenerate(visit):
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(2048)
+        for i in range(0, N, planes):
+            visit(i, torch.view_as_complex(torch.rand((slab, 2), dtype=torch.float32, device="cuda", generator=gen) * 255.0))
+
+    def fill(i, v):
+        x[i * N * N:(i + planes) * N * N] = v
+    regenerate(fill)
+    ks = [(0, 0, 0), (1, 2, 3), (N - 1, N // 2, N // 3), (777, 1500, 2047)]
+    idx = torch.arange(N, device="cuda", dtype=torch.float64)
+
+    def phase(k):
+        ang = -2.0 * math.pi * ((idx * k) % N) / N
+        return torch.complex(torch.cos(ang), torch.sin(ang))
+    want = [torch.zeros((), dtype=torch.complex128, device="cuda") for _ in ks]
+    energy = torch.zeros((), dtype=torch.float64, device="cuda")
+    for i in range(0, N, planes):
+        blk = x[i * N * N:(i + planes) * N * N].reshape(planes, N, N).to(torch.complex128)
+        energy += (blk.real ** 2 + blk.imag ** 2).sum()
+        for j, k in enumerate(ks):
+            want[j] += torch.einsum("xyz,z,y,x->", blk, phase(k[2]), phase(k[1]), phase(k[0])[i:i + planes])
+        del blk
+    torch.cuda.synchronize()
+    plan.execC2C(out, x, dfft.FORWARD)
+    spec = out[:n].reshape(N, N, N)
+    scale = abs(complex(want[0].item()))
+    for j, k in enumerate(ks):
+        got = complex(spec[k].item())
+        assert abs(got - complex(want[j].item())) / scale < 1e-4, (k, got, complex(want[j].item()))
+    eX = torch.zeros((), dtype=torch.float64, device="cuda")
+    for i in range(0, N, planes):
+        blk = spec[i:i + planes].to(torch.complex128)
+        eX += (blk.real ** 2 + blk.imag ** 2).sum()
+        del blk
+    assert abs(float(eX) / (float(n) * float(energy)) - 1.0) < 1e-5      # Parseval at fp32
+    torch.cuda.synchronize()
+    plan.execC2C(x, out, dfft.INVERSE)          # in = back aliased: the inverse destroys `out` and overwrites the input
+    worst = torch.zeros((), dtype=torch.float32, device="cuda")
+
+    def compare(i, v):
+        nonlocal worst
+        worst = torch.maximum(worst, (x[i * N * N:(i + planes) * N * N] / float(n) - v).abs().max())
+    regenerate(compare)
+    assert float(worst) / 255.0 < 5e-5
+
+
+# ------------------------------------------------------------------------------------------
+# single-rank pass order z, x, y, forced
+# ------------------------------------------------------------------------------------------
+def run_single_order(shape, prec, options, seed=5):
+    g = orc.fill_block(shape, (0, 0, 0), shape, 2, seed=seed).astype(NPDT[prec])
+    plan = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), precision=prec)
+    for k, v in options.items():
+        plan.setOption(k, v)
+    plan.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(1, 1), True, c2c=True)
+    esz = 16 if prec == "double" else 8
+    d_in = torch.from_numpy(g).cuda()
+    d_out = torch.zeros(plan.getDomainSize() // esz, dtype=CDT[prec], device="cuda")
+    torch.cuda.synchronize()
+    plan.execC2C(d_out, d_in, dfft.FORWARD)
+    got = d_out[:g.size].cpu().numpy().reshape(shape)
+    d_back = torch.zeros_like(d_in)
+    torch.cuda.synchronize()
+    plan.execC2C(d_back, d_out, dfft.INVERSE)
+    return g, got, d_back.cpu().numpy()
+
+
+SINGLE_ORDER_SHAPES = [
+    (16, 16, 16), (32, 64, 24), (64, 32, 20),          # Nz not a multiple of the tile (8 / 16 lines)
+    (128, 256, 40), (8, 8, 2048), (2048, 16, 16), (16, 2048, 24),
+    (12, 20, 24), (96, 100, 36), (1000, 6, 10),        # mixed-radix axes (native chain)
+    (17, 33, 9), (6, 1500, 10), (1025, 4, 4),          # Bluestein axes
+    (4096, 4, 16), (8, 4096, 8), (4, 8, 4096),         # sub-tile workgroups (kSUB > 1)
+]
+
+
+@pytest.mark.parametrize("prec", ["double", "float"])
+@pytest.mark.parametrize("layout,pad", [(1, 128), (0, 128), (1, 0), (0, 384), (1, 384)])
+@pytest.mark.parametrize("shape", SINGLE_ORDER_SHAPES)
+def test_single_order_zxy_forced_vs_oracle(shape, layout, pad, prec):
+    """option single_order = 1 (the z, x, y pass order that fp32 plans with 2048-point x and y lines pick by themselves):
+    strided natural-line z pass, padded private L2 rows, y pass storing into the API layout"""
+    g, got, back = run_single_order(shape, prec, {"single_order": 1, "single_layout": layout, "single_pad": pad})
+    want = orc.fft3d_c2c(g.astype(np.complex128), -1)
+    assert rel(got, want) < 2 * TOL_FWD[prec]
+    assert rel(back / g.size, g) < TOL_RT[prec]
+
+
+@pytest.mark.parametrize("prec", ["double", "float"])
+def test_single_order_matches_default_order(prec):
+    """the two single-rank pass orders give the same spectrum (different summation order: equal within tolerance)"""
+    shape = (64, 128, 48)
+    _, a, _ = run_single_order(shape, prec, {"single_order": 1})
+    _, b, _ = run_single_order(shape, prec, {"single_order": 0})
+    assert rel(a, b) < 2 * TOL_FWD[prec]
+
+
+# ------------------------------------------------------------------------------------------
+# every generated packed real z pass
+# ------------------------------------------------------------------------------------------
+def rmixed_lengths(tag):
+    txt = open(os.path.join(ROOT, "distributedfft_amd", "csrc", "kernels_mixed.inc")).read()
+    out = []
+    for m in re.finditer(r"#define DFFT_%s_LIST_RMIXED\d\(Y\)(.*)" % tag, txt):
+        out += [int(v) for v in re.findall(r"Y\((\d+),", m.group(1))]
+    return sorted(set(out))
+
+
+@pytest.mark.parametrize("prec", ["double", "float"])
+def test_every_mixed_real_z_pass_vs_oracle(prec):
+    """R2C / C2R with Nz = 2M for EVERY M that has a generated packed real configuration (each carries its own
+    ONEPLANE choice and LDS size); small Nx, Ny, ragged tiles; two virtual ranks split the Hermitian half unevenly"""
+    lengths = rmixed_lengths("F64" if prec == "double" else "F32")
+    assert len(lengths) >= 30, lengths
+    tol_f, tol_r = (2e-11, 1e-10) if prec == "double" else (2e-4, 5e-5)
+    for M in lengths:
+        shape = (6, 10, 2 * M)
+        plans, ins, spec, backs = run_distributed_real(shape, 1, 2, prec)
+        g = orc.fill_block(shape, (0, 0, 0), shape, 1, seed=13).astype(NPR[prec]).astype(np.float64)
+        want = orc.fft3d_r2c(g)
+        scale = np.max(np.abs(want))
+        for r, pl in enumerate(plans):
+            s, o = pl.getOutSize(), pl.getOutStart()
+            assert np.max(np.abs(spec[r] - want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]])) / scale < tol_f, M
+            assert rel(backs[r] / float(np.prod(shape)), ins[r]) < tol_r, M
+
+
+# ------------------------------------------------------------------------------------------
+# wave-uniform table reads
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["double", "float"])
+@pytest.mark.parametrize("shape,P1,P2,chunks", [((64, 64, 64), 2, 2, 2), ((128, 64, 32), 2, 4, 1), ((256, 128, 32), 4, 1, 4),
+                                                ((32, 2048, 16), 1, 2, 1), ((2048, 32, 16), 2, 1, 4), ((64, 4096, 8), 2, 2, 1),
+                                                ((16, 8192, 8), 1, 2, 1), ((512, 256, 32), 8, 1, 2), ((1024, 16, 48), 2, 3, 8)])
+def test_uniform_table_reads_match_per_lane_reads(shape, P1, P2, chunks, prec):
+    """segmented sides whose segments start at multiples of 16 points read their address tables with scalar loads
+    (PassArgs::luni / suni); the result must be bit-identical to the per-lane table reads (uniform_tables = 0) and match
+    the oracle.  Covers 8 / 16-line tiles, sub-tile workgroups (2048 ... 8192 points) and pipelined chunks."""
+    _, ins, spec_u, backs_u = run_distributed(shape, P1, P2, prec, chunks=chunks, options={"uniform_tables": 1})
+    plans, _, spec_v, backs_v = run_distributed(shape, P1, P2, prec, chunks=chunks, options={"uniform_tables": 0})
+    g = orc.fill_block(shape, (0, 0, 0), shape, 2, seed=7).astype(NPDT[prec]).astype(np.complex128)
+    want = orc.fft3d_c2c(g, -1)
+    scale = np.max(np.abs(want))
+    for r, pl in enumerate(plans):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        assert np.array_equal(spec_u[r], spec_v[r])
+        assert np.array_equal(backs_u[r], backs_v[r])
+        assert np.max(np.abs(spec_u[r] - want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]])) / scale < TOL_FWD[prec]
+        assert rel(backs_u[r] / float(np.prod(shape)), ins[r]) < TOL_RT[prec]
+
+
+def test_variant_options_outside_the_key_range_are_rejected():
+    """kernel configurations are keyed by (length, variant) with four bits for the variant: a variant of 16 or more would
+    alias another length's configuration"""
+    plan = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), precision="double")
+    for key in ("variant_fz", "variant_ix"):
+        with pytest.raises(dfft.DfftError, match="variant"):
+            plan.setOption(key, 32)
+        with pytest.raises(dfft.DfftError, match="variant"):
+            plan.setOption(key, -2)
+        plan.setOption(key, 15)
+        plan.setOption(key, -1)
+    x = torch.zeros((4, 6), dtype=torch.complex128, device="cuda")
+    with pytest.raises(dfft.DfftError, match="variant"):
+        dfft.fft1d_batched(torch.zeros_like(x), x, 6, 4, dfft.FORWARD, "double", variant=32)
+
+
+# ------------------------------------------------------------------------------------------
+# bench.py lines
+# ------------------------------------------------------------------------------------------
+def _bench(args, nproc=1, port=29671):
+    import json
+    import subprocess
+    import sys
+    if nproc > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("nproc,want,alt", [(8, "pencil 2x4", "slab P=8"), (4, "pencil 2x2", "slab P=4"), (2, "slab P=2", None)])
+def test_bench_multi_rank_line_is_self_documenting(nproc, want, alt):
+    """`bench.py --gpus N --backend gloo` with the N ranks sharing this GPU: the headline decomposition is the one
+    BASELINE.json names, slab over all ranks is config.alt, and the line carries the xGMI model (bytes per link / 153 GB/s
+    next to the measured exchange spans) and overlap.hidden_frac"""
+    line = _bench(["--gpus", str(nproc), "--backend", "gloo", "--size", "128", "--steps", "2", "--warmup", "1"], nproc=nproc,
+                  port=29671 + nproc)
+    assert line["n_gpus"] == nproc and line["round_trip_rel_linf"] < 1e-10
+    assert line["config"]["decomposition"] == want
+    if alt:
+        assert line["config"]["alt"]["decomposition"].startswith(alt)
+        assert line["config"]["alt"]["round_trip_rel_linf"] < 1e-10
+        assert "hidden_frac" in line["config"]["alt"]["overlap"]
+    else:
+        assert "alt" not in line["config"]
+    per = line["xgmi"]["per_exchange_per_transform"]
+    assert per and all(m["links"] == m["group_ranks"] - 1 and m["predicted_ms"] > 0 and m["measured_ms"] >= 0 for m in per.values())
+    vol = 16 * 128 ** 3 / nproc
+    for m in per.values():
+        assert abs(m["bytes_per_link"] - vol / m["group_ranks"]) < 1
+    assert "hidden_frac" in line["overlap"] and line["overlap"]["step_ms"] == line["ms_per_step"]
+
+
+def test_bench_single_gpu_line_carries_the_8gpu_kernels():
+    """N = 1: roofline object, the multi-rank code path and the per-GPU kernels of the 8-GPU plans (exchange stubbed)"""
+    line = _bench(["--size", "256", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    assert line["n_gpus"] == 1 and line["round_trip_rel_linf"] < 1e-10 and line["roofline"]["bound"] == "hbm"
+    plans = line["config"]["per_gpu_kernels_8gpu"]["plans"]
+    assert [p["decomposition"] for p in plans] == ["pencil 2x4", "slab P=8"]
+    for p in plans:
+        assert len(p["per_pass"]) == 6 and all(v["ms"] > 0 for v in p["per_pass"].values())
+        assert p["alg_bytes_per_pass"] == 2 * 16 * 256 ** 3 / 8
+    assert set(plans[0]["xgmi_model_per_transform"]) == {"exchange 1", "exchange 2"}
+    assert set(plans[1]["xgmi_model_per_transform"]) == {"exchange 2"}

@@ -125,7 +125,19 @@ struct Args {
     // --shuffle: the chunks are mapped in a pseudo-random order
     size_t vmm_mib = 0;
     int shuffle = 0;
+    // --ranks P1xP2 [--rank r]: the plan of rank r of a P1 x P2 grid with the exchange stubbed out (a callback transport that
+    // moves nothing): the kernels run with that rank's real descriptors (1/P of the volume, its segment tables, its
+    // pipeline chunks) on garbage, so their times are what one GPU of the multi-GPU run computes.  No --check.
+    int P1 = 1, P2 = 1, rank = 0;
+    // --sweep "k=v,k2=v2;k=v3": option sets measured one after the other IN ONE PROCESS ON THE SAME BUFFERS (the 128-byte-run
+    // passes depend on the physical placement of a buffer, profiles/r2_placement_probe.txt: A/B across processes is noise)
+    std::vector<std::vector<std::pair<std::string, long>>> sweep;
 };
+
+static int dry_exchange(void *, const void *, const size_t *, const size_t *, void *, const size_t *, const size_t *, const int *, int, int, void *)
+{
+    return 0;
+}
 
 static char *vmm_alloc(size_t bytes, size_t chunk, bool shuffle)
 {
@@ -182,6 +194,26 @@ static Args parse(int argc, char **argv)
         else if (k == "--perm") { a.slab = 1; a.perm = next(); }
         else if (k == "--vmm") a.vmm_mib = (size_t)atoll(next());
         else if (k == "--shuffle") a.shuffle = 1;
+        else if (k == "--ranks") { if (sscanf(next(), "%dx%d", &a.P1, &a.P2) != 2) { fprintf(stderr, "--ranks P1xP2\n"); exit(1); } }
+        else if (k == "--rank") a.rank = atoi(next());
+        else if (k == "--sweep") {
+            std::string all = next();
+            size_t pos = 0;
+            while (pos <= all.size()) {
+                const size_t semi = std::min(all.find(';', pos), all.size());
+                std::vector<std::pair<std::string, long>> set;
+                size_t q = pos;
+                while (q < semi) {
+                    const size_t comma = std::min(all.find(',', q), semi);
+                    const std::string kv = all.substr(q, comma - q);
+                    const size_t eq = kv.find('=');
+                    if (eq != std::string::npos) set.emplace_back(kv.substr(0, eq), atol(kv.c_str() + eq + 1));
+                    q = comma + 1;
+                }
+                a.sweep.push_back(set);
+                pos = semi + 1;
+            }
+        }
         else if (k == "--opt") {
             std::string kv = next();
             const size_t eq = kv.find('=');
@@ -249,15 +281,36 @@ template <typename R> static int run_plan(const Args &a)
     const bool c2c = a.mode == "c2c";
     const size_t esz = 2 * sizeof(R);
     dfft_plan *plan;
-    DCHK(dfft_plan_create(&plan, DFFT_PENCIL_OPT1, prec, nullptr, nullptr, 0, -1));
+    const int nranks = a.P1 * a.P2;
+    dfft_comm *comm = nullptr;
+    if (nranks > 1) DCHK(dfft_comm_create_callback(nranks, a.rank, dry_exchange, nullptr, &comm));
+    std::vector<std::vector<std::pair<std::string, long>>> sets = a.sweep;
+    if (sets.empty()) sets.emplace_back();
+    const bool sweeping = sets.size() > 1;
+    if (sweeping && (a.slab || a.vmm_mib)) { fprintf(stderr, "--sweep does not combine with --slab / --vmm\n"); exit(1); }
+    char *in = nullptr, *out = nullptr, *back = nullptr, *slab = nullptr, *work = nullptr;
+    size_t work_cap = 0;
+    bool alias_back = false;
+    double *part = nullptr;
+    const int nblk = 4096;
+  for (size_t si = 0; si < sets.size(); si++) {
+    DCHK(dfft_plan_create(&plan, a.P2 == 1 && nranks > 1 ? DFFT_SLAB_OPT1 : DFFT_PENCIL_OPT1, prec, nullptr, comm, a.rank, -1));
     for (auto &kv : a.opts) DCHK(dfft_set_option(plan, kv.first.c_str(), kv.second));
-    DCHK(dfft_init(plan, a.Nx, a.Ny, a.Nz, 1, 1, c2c ? 1 : 0, (a.slab || a.vmm_mib) ? 0 : 1));
-    const size_t n = a.Nx * a.Ny * a.Nz;
+    for (auto &kv : sets[si]) DCHK(dfft_set_option(plan, kv.first.c_str(), kv.second));
+    DCHK(dfft_init(plan, a.Nx, a.Ny, a.Nz, a.P1, a.P2, c2c ? 1 : 0, (a.slab || a.vmm_mib || sweeping) ? 0 : 1));
+    size_t isz[3];
+    DCHK(dfft_get_in_size(plan, isz));
+    const size_t n = nranks > 1 ? isz[0] * isz[1] * isz[2] : a.Nx * a.Ny * a.Nz;      // points of this rank's input block
     const size_t in_bytes = c2c ? n * esz : n * sizeof(R);
     const size_t dom = dfft_domain_size(plan);
-    char *in, *out, *back = nullptr, *slab = nullptr;
-    bool alias_back = false;
-    if (a.slab) {
+    if (sweeping) {      // one work area for every option set (grown if a set needs more)
+        const size_t ws = dfft_work_size_device(plan);
+        if (ws > work_cap) { if (work) HIPCHK(hipFree(work)); HIPCHK(hipMalloc(&work, ws)); work_cap = ws; }
+        DCHK(dfft_set_work_area(plan, work, nullptr));
+    }
+    if (si > 0) {
+        /* buffers of the first set are reused */
+    } else if (a.slab) {
         const size_t slot = ((std::max(dom, dfft_work_size_device(plan)) + 255) & ~(size_t)255) + a.delta;
         HIPCHK(hipMalloc(&slab, 4 * slot + 256));
         char *pos[256] = {nullptr};
@@ -280,14 +333,13 @@ template <typename R> static int run_plan(const Args &a)
         alias_back = free_b < in_bytes + (1ull << 30);       // 2048^3: the inverse writes over the input buffer
         if (!alias_back) HIPCHK(hipMalloc(&back, in_bytes)); else back = in;
     }
-    const int nblk = 4096;
-    double *part;
-    HIPCHK(hipMalloc(&part, nblk * sizeof(double)));
+    if (!part) HIPCHK(hipMalloc(&part, nblk * sizeof(double)));
     const size_t nreal = in_bytes / sizeof(R);
     double wave_err = -1, rt_err = -1;
     auto fwd = [&]() { if (c2c) DCHK(dfft_exec_c2c(plan, out, in, DFFT_FORWARD)); else DCHK(dfft_exec_r2c(plan, out, in)); };
     auto inv = [&]() { if (c2c) DCHK(dfft_exec_c2c(plan, back, out, DFFT_INVERSE)); else DCHK(dfft_exec_c2r(plan, back, out)); };
     const bool dbg = dfft_get_option(plan, "debug_skip") > 0;
+    if (nranks > 1 && a.check) { fprintf(stderr, "--check is meaningless with a stubbed exchange\n"); exit(1); }
     if (a.check && c2c && !dbg) {
         Waves w = {{1, (int)a.Nx / 2 + 3, (int)a.Nx - 1}, {0, 5 % (int)a.Ny, (int)a.Ny - 2}, {(int)a.Nz - 1, 7 % (int)a.Nz, (int)a.Nz / 2}};
         fill_waves<R><<<nblk, 256>>>((R *)in, a.Nx, a.Ny, a.Nz, w);
@@ -348,12 +400,15 @@ template <typename R> static int run_plan(const Args &a)
     }
     std::string optstr;
     for (auto &kv : a.opts) optstr += " " + kv.first + "=" + std::to_string(kv.second);
+    for (auto &kv : sets[si]) optstr += " " + kv.first + "=" + std::to_string(kv.second);
+    if (sweeping) optstr += " [set " + std::to_string(si) + ", shared buffers]";
     if (a.vmm_mib) optstr += " vmm=" + std::to_string(a.vmm_mib) + "MiB" + (a.shuffle ? " shuffled" : "");
     if (a.slab) optstr += " slab perm=" + a.perm + " delta=" + std::to_string(a.delta);
+    if (nranks > 1) optstr += " rank " + std::to_string(a.rank) + " of " + std::to_string(a.P1) + "x" + std::to_string(a.P2) + " (exchange stubbed), chunks=" + std::to_string(dfft_get_pipeline_chunks(plan));
     printf("PLAN %s %zux%zux%zu %s %s%s | wave_err %.2e roundtrip %.2e | wall %.3f ms/step\n", a.label.c_str(), a.Nx, a.Ny, a.Nz,
            a.prec.c_str(), a.mode.c_str(), optstr.c_str(), wave_err, rt_err, wall / a.iters);
     const size_t Nzc = c2c ? a.Nz : a.Nz / 2 + 1;
-    const double half = (double)a.Nx * a.Ny * Nzc * esz, real_b = (double)in_bytes;
+    const double half = (double)a.Nx * a.Ny * Nzc * esz / nranks, real_b = (double)in_bytes;
     double tot = 0;
     for (int dir = 0; dir < 2; dir++) {
         const int np = dir == 0 ? nf : nb;
@@ -369,6 +424,8 @@ template <typename R> static int run_plan(const Args &a)
     }
     printf("  total passes %.3f ms\n", tot);
     DCHK(dfft_plan_destroy(plan));
+  }
+    if (work) HIPCHK(hipFree(work));
     if (a.slab) HIPCHK(hipFree(slab));
     else if (a.vmm_mib) { /* process exit unmaps */ }
     else {
