@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--no-multi-rank-path", action="store_true", help="N = 1: skip the multi-rank code path measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=0, help="cube edge of the CPU-baseline sample (0 = 1024 if RAM allows, else 512)")
+    ap.add_argument("--tune-placement", type=int, default=-1,
+                    help="physical backings tried per buffer (work area, out, back) before the warm-up: dfft_tune_placement keeps the one "
+                         "the plan's own passes run fastest on.  -1 = 4 on one GPU, off otherwise; 0 / 1 = plain allocations")
     ap.add_argument("--dry-run", action="store_true", help="plan C4 / C5 for all 8 ranks without a GPU and print the memory budget")
     return ap.parse_args()
 
@@ -290,10 +293,25 @@ def main():
 
     d_in = torch.empty(n_in, dtype=cdt, device="cuda")
     fill(d_in)
-    d_out = torch.empty(domain // esz, dtype=cdt, device="cuda")
     free_b, _ = torch.cuda.mem_get_info()
-    aliased = free_b < n_in * esz + (2 << 30)     # 2048^3 fp32 on one GPU: the inverse writes back over the input
-    d_back = d_in if aliased else torch.empty(n_in, dtype=cdt, device="cuda")
+    aliased = free_b < domain + n_in * esz + (2 << 30)     # 2048^3 fp32 on one GPU: the inverse writes back over the input
+    # Placement: the passes that scatter 128-byte runs depend on the physical backing of the buffer they write
+    # to.  Before the warm-up the plan tries a few backings for its work area and for out / back (virtual-memory API, chunks
+    # of different sizes) and keeps the fastest; that needs room for two candidates of a buffer at a time.
+    tries = args.tune_placement if args.tune_placement >= 0 else (4 if world == 1 else 0)
+    placement = None
+    if tries > 1 and work is None and not aliased and free_b > 4 * domain + (4 << 30):
+        t_tune = time.perf_counter()
+        b_out, b_back, trial_ms = plan.tunePlacement(d_in, tries, want_back=True)
+        d_out = b_out.tensor(cdt)
+        d_back = b_back.tensor(cdt)[:n_in]
+        placement = {"tries_per_buffer": tries, "trial_fft_ms_fwd_plus_inv": [round(v, 3) for v in trial_ms],
+                     "what": "dfft_tune_placement before the warm-up: first entry = plain hipMalloc everywhere, then the work area, out and "
+                             "back one at a time on other physical backings; a candidate is kept when the plan's own passes run faster on it",
+                     "seconds": round(time.perf_counter() - t_tune, 2)}
+    else:
+        d_out = torch.empty(domain // esz, dtype=cdt, device="cuda")
+        d_back = d_in if aliased else torch.empty(n_in, dtype=cdt, device="cuda")
     if comm is not None and transport == "torch":
         comm.register(d_out)
     torch.cuda.synchronize()
@@ -543,7 +561,7 @@ def main():
                        "rccl_nranks": rccl_nranks, "world_size": world, "devices_visible": ndev,
                        "ranks_per_device": max(1, -(-world // ndev)),
                        "per_pass": per_pass(phases, args.steps),
-                       "input_aliased_with_inverse_output": bool(aliased)},
+                       "input_aliased_with_inverse_output": bool(aliased), "placement": placement},
             "round_trip_rel_linf": rt_err,
             "roofline": roofline,
         }

@@ -80,6 +80,9 @@ SYMBOLS = [
     ("dfft_last_error", C.c_char_p, []),
     ("dfft_version", C.c_char_p, []),
     ("dfft_kernel_info", _i, [_i, _sz, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    ("dfft_malloc", _i, [_sz, _sz, C.POINTER(_vp)]),
+    ("dfft_free", _i, [_vp]),
+    ("dfft_tune_placement", _i, [_vp, _vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_float), _i, C.POINTER(_i)]),
 ]
 
 _lib = None

@@ -96,6 +96,48 @@ def _ptr(x):
     raise TypeError(f"expected a device tensor or an integer address, got {type(x)}")
 
 
+class DeviceBuffer:
+    """Device memory from dfft_malloc / dfft_tune_placement (include/dfft_c.h): an address and a size.  Plans take it
+    wherever they take a tensor; `tensor(dtype)` is a zero-copy torch view (through __cuda_array_interface__) for the
+    callers that fill or check the data with torch ops.  Freed with dfft_free when the object dies."""
+
+    def __init__(self, address, nbytes, owned=True):
+        self.address, self.nbytes, self._owned = int(address), int(nbytes), owned
+
+    @classmethod
+    def alloc(cls, nbytes, chunk_mib=0):
+        h = C.c_void_p()
+        check(lib().dfft_malloc(int(nbytes), int(chunk_mib), C.byref(h)))
+        return cls(h.value, nbytes)
+
+    def data_ptr(self):
+        return self.address
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.address, False), "version": 2, "strides": None}
+
+    def tensor(self, dtype):
+        import torch
+        t = torch.as_tensor(self, device="cuda")
+        if t.data_ptr() != self.address:
+            raise DfftError("torch copied the buffer instead of viewing it")
+        t = t.view(dtype)
+        t._dfft_owner = self      # the view keeps the allocation alive
+        return t
+
+    def free(self):
+        if self._owned and self.address:
+            lib().dfft_free(C.c_void_p(self.address))
+        self.address = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:   # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
 class Comm:
     """Communicator handed to the plans in place of MPI_Comm (src/mpicufft.cpp:42-51)."""
 
@@ -199,6 +241,21 @@ class MPIcuFFT:
     def setWorkArea(self, device=None, host=None):
         self._work = device
         check(lib().dfft_set_work_area(self._h, _ptr(device), _ptr(host)))
+
+    def tunePlacement(self, in_, tries=4, want_back=True):
+        """dfft_tune_placement: tries several physical backings for the library-owned work area, a new `out` buffer and
+        (want_back) a new buffer for the inverse transform's output, and keeps for each the one this plan's own passes run
+        fastest on.  `in_` must hold a valid input block.  Returns (out, back or None, [ms of every trial])."""
+        o, b = C.c_void_p(), C.c_void_p()
+        rep = (C.c_float * (3 * max(1, int(tries)) + 1))()
+        n = C.c_int(0)
+        check(lib().dfft_tune_placement(self._h, _ptr(in_), int(tries), C.byref(o), C.byref(b) if want_back else None, rep, len(rep), C.byref(n)))
+        isz = self.getInSize()
+        esz = 16 if self.precision == 1 else 8
+        in_bytes = isz[0] * isz[1] * isz[2] * (esz if self.c2c else esz // 2)
+        out = DeviceBuffer(o.value, self.getDomainSize())
+        back = DeviceBuffer(b.value, in_bytes) if want_back else None
+        return out, back, [float(rep[i]) for i in range(n.value)]
 
     def setPipelineChunks(self, chunks):
         """pipeline depth of the exchanges (before initFFT); 1 = no overlap, 0 = default"""

@@ -18,6 +18,8 @@
 #include <string.h>
 #include <algorithm>
 #include <complex>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1251,6 +1253,86 @@ template <typename F> static int run_graphed(dfft_plan *p, int kind, const void 
     return enqueue();                      // nothing ran during the failed capture
 }
 
+// ------------------------------------------------------------------------------------------
+// Placement-aware device memory (dfft_malloc / dfft_free / dfft_tune_placement, no counterpart in the reference: its
+// buffers are plain cudaMalloc, src/pencil/mpicufft_pencil_opt1.cpp:344-365).  The passes that scatter 128-byte runs
+// (y and x) run 5-10 % faster or slower depending on the PHYSICAL backing of the buffer they write to, per buffer and
+// repeatably for the life of the allocation (profiles/r2_placement_probe.txt, profiles/r3_placement.txt); what the
+// driver hands out differs from allocation to allocation.  So buffers can be backed through the virtual-memory API in
+// physical chunks of a chosen size, and a plan can try several backings and keep the one its own passes run fastest on.
+struct DevAlloc { size_t bytes, chunk; };     // chunk == 0: plain hipMalloc
+static std::mutex g_alloc_mu;
+static std::map<void *, DevAlloc> g_allocs;
+
+static int dev_free(void *ptr)
+{
+    if (!ptr) return 0;
+    DevAlloc rec{0, 0};
+    {
+        std::lock_guard<std::mutex> lk(g_alloc_mu);
+        auto it = g_allocs.find(ptr);
+        if (it != g_allocs.end()) { rec = it->second; g_allocs.erase(it); }
+    }
+    if (!rec.chunk) { HIP_TRY(hipFree(ptr)); return 0; }
+    for (size_t off = 0; off < rec.bytes; off += rec.chunk) HIP_TRY(hipMemUnmap(static_cast<char *>(ptr) + off, rec.chunk));
+    HIP_TRY(hipMemAddressFree(ptr, rec.bytes));
+    return 0;
+}
+// chunk_mib == 0: hipMalloc.  Otherwise one virtual range backed by physical allocations of chunk_mib MiB each.
+static int dev_alloc(size_t bytes, size_t chunk_mib, void **out)
+{
+    *out = nullptr;
+    if (!bytes) return fail(ERR_ARG, "zero-sized allocation");
+    if (!chunk_mib) {
+        HIP_TRY(hipMalloc(out, bytes));
+        std::lock_guard<std::mutex> lk(g_alloc_mu);
+        g_allocs[*out] = DevAlloc{bytes, 0};
+        return 0;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    if (!gran) gran = 4096;
+    size_t chunk = chunk_mib << 20;
+    chunk = (chunk + gran - 1) / gran * gran;
+    const size_t total = (bytes + chunk - 1) / chunk * chunk;
+    void *va = nullptr;
+    HIP_TRY(hipMemAddressReserve(&va, total, chunk, nullptr, 0));
+    size_t mapped = 0;
+    hipError_t err = hipSuccess;
+    for (; mapped < total && err == hipSuccess; mapped += chunk) {
+        hipMemGenericAllocationHandle_t h;
+        err = hipMemCreate(&h, chunk, &prop, 0);
+        if (err != hipSuccess) break;
+        err = hipMemMap(static_cast<char *>(va) + mapped, chunk, 0, h, 0);
+        (void)hipMemRelease(h);      // the mapping keeps the physical memory alive
+        if (err != hipSuccess) break;
+    }
+    if (err == hipSuccess) {
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        err = hipMemSetAccess(va, total, &acc, 1);
+    }
+    if (err != hipSuccess) {
+        for (size_t off = 0; off < mapped; off += chunk) (void)hipMemUnmap(static_cast<char *>(va) + off, chunk);
+        (void)hipMemAddressFree(va, total);
+        set_error(std::string("virtual-memory allocation failed: ") + hipGetErrorString(err));
+        return (int)err;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_alloc_mu);
+        g_allocs[va] = DevAlloc{total, chunk};
+    }
+    *out = va;
+    return 0;
+}
+
 static int check_ready(dfft_plan *p)
 {
     if (!p) return fail(ERR_ARG, "null plan");
@@ -1382,7 +1464,7 @@ int dfft_plan_destroy(dfft_plan *p)
 {
     if (!p) return 0;
     graphs_clear(p);
-    if (p->work_owned && p->work_d) (void)hipFree(p->work_d);
+    if (p->work_owned && p->work_d) (void)dev_free(p->work_d);
     for (auto &a : p->ax) axis_free(a);
     for (void *t : {p->tw_zr, p->tables_d}) if (t) (void)hipFree(t);
     for (auto &t : p->spans) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
@@ -1640,12 +1722,12 @@ int dfft_set_work_area(dfft_plan *p, void *device, void *host)
     if (!p) return fail(ERR_ARG, "null plan");
     if (!p->initialized) return fail(ERR_STATE, "cannot set work area: plan not initialised");
     graphs_clear(p);
-    if (p->work_owned && p->work_d) { (void)hipFree(p->work_d); p->work_d = nullptr; p->work_owned = false; }
+    if (p->work_owned && p->work_d) { (void)dev_free(p->work_d); p->work_d = nullptr; p->work_owned = false; }
     TRY(ensure_device_state(p));
     if (device) {
         p->work_d = device;   // caller keeps ownership (:333-342)
     } else {
-        HIP_TRY(hipMalloc(&p->work_d, p->worksize_d));
+        TRY(dev_alloc(p->worksize_d, 0, &p->work_d));
         p->work_owned = true;
     }
     return 0;
@@ -1982,6 +2064,106 @@ int dfft_kernel_info(int precision, size_t N, int *threads, int *lds_bytes, int 
     if (lds_bytes) *lds_bytes = pi.lds_bytes;
     if (points_per_thread) *points_per_thread = pi.E;
     if (lines_per_workgroup) *lines_per_workgroup = pi.TL * pi.G / (pi.sub > 1 ? pi.sub : 1);      // sub-tile workgroups: part of a tile
+    return 0;
+}
+
+int dfft_malloc(size_t bytes, size_t chunk_mib, void **ptr)
+{
+    if (!ptr) return fail(ERR_ARG, "null pointer");
+    return dev_alloc(bytes, chunk_mib, ptr);
+}
+int dfft_free(void *ptr) { return dev_free(ptr); }
+
+// device time of the FFT passes (exchanges excluded) of one forward (+ inverse, if back != nullptr) execution on the given
+// buffers, best of `reps` after one untimed execution
+static int placement_measure(dfft_plan *p, const void *in, void *out, void *back, int reps, float *ms)
+{
+    auto once = [&](float *sum) -> int {
+        float ph[5];
+        if (p->c2c) TRY(dfft_exec_c2c(p, out, const_cast<void *>(in), DFFT_FORWARD)); else TRY(dfft_exec_r2c(p, out, in));
+        int n = dfft_get_phase_times(p, ph, 5);
+        float acc = 0;
+        for (int i = 0; i < n; i += 2) acc += ph[i];
+        if (back) {
+            if (p->c2c) TRY(dfft_exec_c2c(p, back, out, DFFT_INVERSE)); else TRY(dfft_exec_c2r(p, back, out));
+            n = dfft_get_phase_times(p, ph, 5);
+            for (int i = 0; i < n; i += 2) acc += ph[i];
+        }
+        *sum = acc;
+        return 0;
+    };
+    float best = 1e30f, cur = 0;
+    TRY(once(&cur));
+    for (int r = 0; r < reps; r++) { TRY(once(&cur)); best = std::min(best, cur); }
+    *ms = best;
+    return 0;
+}
+
+// physical chunk sizes (MiB) tried in turn; 0 = plain hipMalloc
+static const size_t kPlacementRecipes[] = {0, 64, 1024, 2, 256, 16, 512, 128};
+
+int dfft_tune_placement(dfft_plan *p, const void *in, int tries, void **out, void **back, float *report_ms, int max_report, int *n_report)
+{
+    TRY(check_ready(p));
+    if (!in || !out) return fail(ERR_ARG, "null buffer");
+    if (tries < 1) tries = 1;
+    size_t isz[3];
+    TRY(dfft_get_in_size(p, isz));
+    const size_t in_bytes = isz[0] * isz[1] * isz[2] * (p->c2c ? p->esz : p->esz / 2);
+    const size_t out_bytes = p->domainsize, work_bytes = p->worksize_d;
+    const bool own_work = p->work_owned;      // a caller-provided work area stays as it is
+    const bool was_timing = p->timing;
+    TRY(dfft_enable_phase_timing(p, 1));
+    int nrep = 0;
+    auto note = [&](float v) { if (report_ms && nrep < max_report) report_ms[nrep] = v; nrep++; };
+    auto room_for = [&](size_t bytes) {
+        size_t free_b = 0, total_b = 0;
+        return hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > bytes + ((size_t)1 << 30);
+    };
+    const size_t nrec = sizeof(kPlacementRecipes) / sizeof(kPlacementRecipes[0]);
+    void *o = nullptr, *b = nullptr;
+    int rc = dev_alloc(out_bytes, kPlacementRecipes[0], &o);
+    if (rc == 0 && back) rc = dev_alloc(in_bytes, kPlacementRecipes[0], &b);
+    float best = 0;
+    if (rc == 0) rc = placement_measure(p, in, o, b, 2, &best);
+    note(best);
+    // One buffer at a time (the passes' sensitivities to their buffers are independent): work area, out, back.  All candidates
+    // of a buffer are allocated BEFORE any is measured and the losers are freed afterwards: a freed candidate's physical pages
+    // would simply be handed out again to the next one, and it is the physical pages that differ.
+    for (int which = 0; which < 3 && rc == 0; which++) {
+        if (which == 0 && !own_work) continue;
+        if (which == 2 && !back) continue;
+        const size_t bytes = which == 0 ? work_bytes : which == 1 ? out_bytes : in_bytes;
+        std::vector<void *> cands;
+        for (int t = 1; t < tries; t++) {
+            void *cand = nullptr;
+            if (!room_for(bytes) || dev_alloc(bytes, kPlacementRecipes[(size_t)t % nrec], &cand) != 0) break;      // out of memory: fewer candidates
+            cands.push_back(cand);
+        }
+        void *keep = which == 0 ? p->work_d : which == 1 ? o : b;
+        for (void *cand : cands) {
+            if (rc != 0) { (void)dev_free(cand); continue; }
+            if (which == 0) p->work_d = cand;
+            float ms = 0;
+            rc = placement_measure(p, in, which == 1 ? cand : o, which == 2 ? cand : b, 2, &ms);
+            note(ms);
+            if (rc == 0 && ms < best) {
+                best = ms;
+                (void)dev_free(keep);
+                keep = cand;
+            } else {
+                (void)dev_free(cand);
+            }
+            if (which == 0) p->work_d = keep;
+        }
+        if (which == 1) o = keep; else if (which == 2) b = keep;
+    }
+    p->timing = was_timing;
+    graphs_clear(p);
+    if (rc != 0) { (void)dev_free(o); (void)dev_free(b); return rc; }
+    *out = o;
+    if (back) *back = b;
+    if (n_report) *n_report = nrep < max_report ? nrep : max_report;
     return 0;
 }
 

@@ -266,6 +266,23 @@ const char *dfft_version(void);
 int dfft_kernel_info(int precision, size_t N, int *threads, int *lds_bytes, int *points_per_thread,
                      int *lines_per_workgroup);
 
+/* ---- placement-aware device memory (no counterpart in the reference, whose buffers are plain cudaMalloc,
+ * src/pencil/mpicufft_pencil_opt1.cpp:344-365; the analogue of fftw_malloc + FFTW_MEASURE) ----------------
+ * The passes that write 128-byte runs (y, x) run 5-10 % faster or slower depending on the PHYSICAL backing of the
+ * buffer they scatter to -- per buffer, for the life of the allocation (profiles/r3_placement.txt).
+ * dfft_malloc: chunk_mib = 0 is hipMalloc; otherwise one virtual range backed by physical allocations of chunk_mib MiB
+ * each (HIP virtual-memory API).  Free with dfft_free (which also takes pointers it did not allocate: hipFree). */
+int dfft_malloc(size_t bytes, size_t chunk_mib, void **ptr);
+int dfft_free(void *ptr);
+/* Tries up to `tries` backings for the plan's own work area (only when the library owns it), for a new output buffer
+ * *out (dfft_domain_size bytes) and, if back != NULL, for a new buffer *back of the input block's size (the inverse
+ * transform's output), one buffer at a time, and keeps for each the backing on which the plan's own FFT passes
+ * (forward in -> out, inverse out -> back; exchanges not counted) run fastest.  `in` must hold a valid input block; it
+ * is only read.  *out / *back are freed with dfft_free.  On a multi-rank plan the call is collective (it executes the
+ * plan 3 * tries times).  report_ms (optional): the measured pass time of every trial in order, *n_report entries. */
+int dfft_tune_placement(dfft_plan *plan, const void *in, int tries, void **out, void **back, float *report_ms,
+                        int max_report, int *n_report);
+
 #ifdef __cplusplus
 }
 #endif

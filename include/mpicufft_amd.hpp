@@ -21,8 +21,10 @@
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
+#include <sys/stat.h>
 
 #include "dfft_c.h"
+#include "timer_amd.hpp"
 
 struct GlobalSize {
     GlobalSize(size_t Nx_, size_t Ny_, size_t Nz_) : Nx(Nx_), Ny(Ny_), Nz(Nz_), Nz_out(Nz_ / 2 + 1) {}
@@ -139,6 +141,7 @@ private:
 template <typename T> class MPIcuFFT {
 public:
     MPIcuFFT(Configurations config, MPI_Comm comm = MPI_COMM_WORLD, int max_world_size = -1, int kind = DFFT_PENCIL_OPT1)
+        : config(config), kind_(kind)
     {
         int size = 1;
         MPI_Comm_size(comm, &size);
@@ -154,6 +157,7 @@ public:
             MPI_Comm_split(comm, pidx < pcnt ? 0 : MPI_UNDEFINED, pidx, &sub_);
             world = sub_;
         }
+        world_ = world;
         if (pidx >= pcnt) return;                       // not part of the FFT world
         if (pcnt > 1) {
             if (config.cuda_aware) {                   // device path: RCCL over xGMI, one rank per GPU
@@ -175,24 +179,35 @@ public:
         dfft_plan_destroy(plan_);
         if (comm_) dfft_comm_destroy(comm_);
         delete staged_;
+        delete timer;
         if (sub_ != MPI_COMM_NULL) MPI_Comm_free(&sub_);
     }
     virtual void initFFT(GlobalSize *global_size, Partition *partition, bool allocate = true)
     {
         if (!plan_) return;
         if (!global_size || !partition) throw std::runtime_error("GlobalSize or Partition not initialized!");
+        startTimer(global_size, partition);
         check(dfft_init(plan_, global_size->Nx, global_size->Ny, global_size->Nz, (int)partition->P1,
                         (int)partition->P2, /*c2c=*/0, allocate));
+        check(dfft_enable_phase_timing(plan_, 1));
+        timer->stop_store("init");
     }
     // complex-to-complex plan (extension): same layouts with Nz_out = Nz
     void initFFT_C2C(GlobalSize *g, Partition *p, bool allocate = true)
     {
-        if (plan_) check(dfft_init(plan_, g->Nx, g->Ny, g->Nz, (int)p->P1, (int)p->P2, 1, allocate));
+        if (!plan_) return;
+        startTimer(g, p);
+        check(dfft_init(plan_, g->Nx, g->Ny, g->Nz, (int)p->P1, (int)p->P2, 1, allocate));
+        check(dfft_enable_phase_timing(plan_, 1));
+        timer->stop_store("init");
     }
     virtual void setWorkArea(void *device = nullptr, void *host = nullptr) { if (plan_) check(dfft_set_work_area(plan_, device, host)); }
-    virtual void execR2C(void *out, const void *in) { if (plan_) check(dfft_exec_r2c(plan_, out, in)); }
-    virtual void execC2R(void *out, const void *in) { if (plan_) check(dfft_exec_c2r(plan_, out, const_cast<void *>(in))); }
-    void execC2C(void *out, void *in, int direction) { if (plan_) check(dfft_exec_c2c(plan_, out, in, direction)); }
+    virtual void execR2C(void *out, const void *in) { if (plan_) timed(DFFT_FORWARD, [&] { return dfft_exec_r2c(plan_, out, in); }); }
+    virtual void execC2R(void *out, const void *in) { if (plan_) timed(DFFT_INVERSE, [&] { return dfft_exec_c2r(plan_, out, const_cast<void *>(in)); }); }
+    void execC2C(void *out, void *in, int direction) { if (plan_) timed(direction, [&] { return dfft_exec_c2c(plan_, out, in, direction); }); }
+    // the section timer of the reference's classes (include/mpicufft_pencil.hpp:263-287, include/mpicufft_slab.hpp:208-222):
+    // one block of the CSV per exec* once the warm-up rounds are used up
+    Timer *getTimer() const { return timer; }
     virtual inline void getInSize(size_t *isize) { if (plan_) check(dfft_get_in_size(plan_, isize)); }
     virtual inline void getInStart(size_t *istart) { if (plan_) check(dfft_get_in_start(plan_, istart)); }
     virtual inline void getOutSize(size_t *osize) { if (plan_) check(dfft_get_out_size(plan_, osize)); }
@@ -210,6 +225,95 @@ protected:
     {
         if (rc != 0) throw std::runtime_error(std::string("dfft: ") + dfft_last_error());
     }
+    // Timer sections and CSV name of the class, as the reference's initFFT builds them (src/pencil/mpicufft_pencil.cpp:67-73,
+    // src/pencil/mpicufft_pencil_opt1.cpp:50-56, src/slab/default/mpicufft_slab.cpp:99-105, mpicufft_slab_opt1.cpp:39-44,
+    // src/slab/z_then_yx/mpicufft_slab_z_then_yx.cpp:76-81, src/slab/y_then_zx/mpicufft_slab_y_then_zx.cpp:73-79)
+    void startTimer(GlobalSize *g, Partition *partition)
+    {
+        const bool pencil = kind_ == DFFT_PENCIL || kind_ == DFFT_PENCIL_OPT1;
+        const bool zyx = kind_ == DFFT_SLAB_Z_THEN_YX || kind_ == DFFT_SLAB_Z_THEN_YX_OPT1, yzx = kind_ == DFFT_SLAB_Y_THEN_ZX;
+        const int opt = (kind_ == DFFT_PENCIL_OPT1 || kind_ == DFFT_SLAB_OPT1 || kind_ == DFFT_SLAB_Z_THEN_YX_OPT1) ? 1 : 0;
+        const std::string sub = pencil ? "/pencil" : zyx ? "/slab_z_then_yx" : yzx ? "/slab_y_then_zx" : "/slab_default";
+        mkdir((config.benchmark_dir + sub).c_str(), 0777);
+        std::string f = config.benchmark_dir + sub + "/test_" + std::to_string(opt) + "_" + std::to_string((int)config.comm_method) + "_" +
+                        std::to_string((int)config.send_method);
+        if (pencil) f += "_" + std::to_string((int)config.comm_method2) + "_" + std::to_string((int)config.send_method2);
+        f += "_" + std::to_string(g->Nx) + "_" + std::to_string(g->Ny) + "_" + std::to_string(g->Nz) + "_" + std::to_string((int)config.cuda_aware);
+        f += pencil ? "_" + std::to_string(partition->P1) + "_" + std::to_string(partition->P2) : "_" + std::to_string(pcnt);
+        f += ".csv";
+        std::vector<std::string> d = {"init"};
+        const char *tr[] = {"(First Send)", "(Packing)", "(Start Local Transpose)", "(Start Receive)", "(First Receive)", "(Finished Receive)",
+                            "(Start All2All)", "(Finished All2All)", "(Unpacking)"};
+        auto transpose = [&](const std::string &prefix) { for (const char *t : tr) d.push_back(prefix + "Transpose " + t); };
+        if (pencil) {
+            d.push_back("1D FFT Z-Direction");
+            transpose("First ");
+            d.insert(d.end(), {"First Transpose (Send Complete)", "1D FFT Y-Direction"});
+            transpose("Second ");
+            d.push_back("1D FFT X-Direction");
+        } else if (zyx) {
+            d.push_back("1D FFT Z-Direction");
+            transpose("");
+            d.push_back("2D FFT Y-X-Direction");
+        } else if (yzx) {
+            d.insert(d.end(), {"1D FFT Y-Direction", "Transpose (First Send)", "Transpose (Packing)", "Transpose (Start Local Transpose)",
+                               "Transpose (Start Receive)", "Transpose (Finished Receive)", "2D FFT Z-X-Direction"});
+        } else {
+            d.insert(d.end(), {"2D FFT (Sync)", "2D FFT Y-Z-Direction"});
+            transpose("");
+            d.push_back("1D FFT X-Direction");
+        }
+        d.push_back("Run complete");
+        delete timer;
+        timer = new Timer(world_, 0, pcnt, pidx, d, f);
+        timer->start();
+    }
+    // runs one exec, then stores the sections it went through (cumulative milliseconds like the reference's stop points; the
+    // library's device events per phase instead of MPI_Wtime() after host-side synchronisations) and appends a block to the CSV
+    // when the warm-up rounds are used up (src/pencil/mpicufft_pencil_opt1.cpp:1515-1518)
+    template <typename F> void timed(int direction, F &&exec)
+    {
+        if (!timer) { check(exec()); return; }
+        timer->start();
+        check(exec());
+        timer->stop("Run complete");
+        float ph[5] = {0, 0, 0, 0, 0};
+        const int n = dfft_get_phase_times(plan_, ph, 5);
+        const bool pencil = kind_ == DFFT_PENCIL || kind_ == DFFT_PENCIL_OPT1;
+        const bool zyx = kind_ == DFFT_SLAB_Z_THEN_YX || kind_ == DFFT_SLAB_Z_THEN_YX_OPT1, yzx = kind_ == DFFT_SLAB_Y_THEN_ZX;
+        const char *done = config.comm_method == Peer2Peer ? "(Finished Receive)" : "(Finished All2All)";
+        const char *done2 = config.comm_method2 == Peer2Peer ? "(Finished Receive)" : "(Finished All2All)";
+        // section reached after phase i of this direction (phases in execution order: forward z, exchange 1, y, exchange 2, x;
+        // the inverse runs them backwards); empty = the phase closes no section of this class
+        std::string name[5];
+        if (pencil) {
+            const std::string f[5] = {"1D FFT Z-Direction", std::string("First Transpose ") + done, "1D FFT Y-Direction",
+                                      std::string("Second Transpose ") + done2, "1D FFT X-Direction"};
+            for (int i = 0; i < 5; i++) name[i] = direction == DFFT_FORWARD ? f[i] : f[4 - i];
+        } else if (zyx) {
+            const std::string f[5] = {"1D FFT Z-Direction", std::string("Transpose ") + done, "", "", "2D FFT Y-X-Direction"};
+            for (int i = 0; i < 5; i++) name[i] = f[i];
+            if (direction != DFFT_FORWARD) { name[0] = ""; name[2] = "2D FFT Y-X-Direction"; name[3] = std::string("Transpose ") + done; name[1] = ""; name[4] = "1D FFT Z-Direction"; }
+        } else if (yzx) {
+            name[0] = "1D FFT Y-Direction"; name[1] = "Transpose (Finished Receive)"; name[4] = "2D FFT Z-X-Direction";
+        } else {
+            if (direction == DFFT_FORWARD) { name[2] = "2D FFT Y-Z-Direction"; name[3] = std::string("Transpose ") + done; name[4] = "1D FFT X-Direction"; }
+            else { name[0] = "1D FFT X-Direction"; name[1] = std::string("Transpose ") + done; name[4] = "2D FFT Y-Z-Direction"; }
+        }
+        double cum = 0;
+        for (int i = 0; i < n && i < 5; i++) {
+            cum += ph[i];
+            if (!name[i].empty()) timer->store(name[i], cum);
+        }
+        timer->store("Run complete");
+        if (timer->duration("Run complete") < cum) timer->store("Run complete", cum);
+        if (config.warmup_rounds == 0) timer->gather();
+        else config.warmup_rounds--;
+    }
+    Configurations config;
+    int kind_ = DFFT_PENCIL_OPT1;
+    MPI_Comm world_ = MPI_COMM_WORLD;
+    Timer *timer = nullptr;
     // slab classes: initFFT(global_size, nullptr, allocate) is legal, the partition is the world size
     // (include/mpicufft_slab.hpp:103-106)
     void initSlab(GlobalSize *g, Partition *partition, bool allocate)
@@ -276,11 +380,11 @@ public:
     // partial transforms execR2C/execC2R(out, in, d), include/mpicufft_pencil.hpp:101-111
     virtual void execR2C(void *out, const void *in, int d)
     {
-        if (this->plan_) this->check(dfft_exec_dim(this->plan_, out, const_cast<void *>(in), DFFT_FORWARD, d));
+        if (this->plan_) this->timed(DFFT_FORWARD, [&] { return dfft_exec_dim(this->plan_, out, const_cast<void *>(in), DFFT_FORWARD, d); });
     }
     virtual void execC2R(void *out, const void *in, int d)
     {
-        if (this->plan_) this->check(dfft_exec_dim(this->plan_, out, const_cast<void *>(in), DFFT_INVERSE, d));
+        if (this->plan_) this->timed(DFFT_INVERSE, [&] { return dfft_exec_dim(this->plan_, out, const_cast<void *>(in), DFFT_INVERSE, d); });
     }
     // include/mpicufft_pencil.hpp:112-116; tables as built in src/pencil/mpicufft_pencil_opt1.cpp:70-93
     void getPartitionDimensions(Partition_Dimensions &input_dim_, Partition_Dimensions &transposed_dim_, Partition_Dimensions &output_dim_)

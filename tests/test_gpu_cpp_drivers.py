@@ -1,0 +1,150 @@
+"""The reference's test executables on the MI355X library: tools/drivers/pencil.cpp and slab.cpp (flags and testcases of
+tests/src/pencil/main.cpp:26-236 / tests/src/slab/main.cpp:26-214) built with g++ against MPICH and started with mpiexec,
+several ranks sharing the GPU through the shim's host-staged exchange.  Checks the printed error norms and the timer CSV
+(format of src/timer.cpp:58-101, file names of src/pencil/mpicufft_pencil_opt1.cpp:50-55 etc.)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MPIEXEC = "/opt/conda/bin/mpiexec"
+MPI_LIB = "/opt/conda/lib/libmpi.so.12"
+
+needs_mpich = pytest.mark.skipif(not (os.path.exists(MPI_LIB) and os.path.exists(MPIEXEC)), reason="MPICH from the image is not present")
+
+
+@pytest.fixture(scope="module")
+def drivers(tmp_path_factory):
+    d = tmp_path_factory.mktemp("drivers")
+    libdir = d / "mpilib"     # only MPICH's own libraries, not conda's old libstdc++
+    libdir.mkdir()
+    for lib in ("libmpi.so.12", "libgfortran.so.4", "libquadmath.so.0"):
+        src = os.path.join("/opt/conda/lib", lib)
+        if os.path.exists(src):
+            os.symlink(src, libdir / lib)
+    exes = {}
+    for name in ("pencil", "slab"):
+        exe = d / name
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-w", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/conda/include",
+                               "-I", "/opt/rocm/include", os.path.join(ROOT, "tools", "drivers", name + ".cpp"), "-o", str(exe),
+                               os.path.join(ROOT, "distributedfft_amd", "libdfft_amd.so"), MPI_LIB, "-L/opt/rocm/lib", "-lamdhip64",
+                               "-Wl,-rpath," + os.path.join(ROOT, "distributedfft_amd"), "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"])
+        exes[name] = str(exe)
+    return exes, dict(os.environ, LD_LIBRARY_PATH=f"/opt/rocm/lib:{libdir}")
+
+
+def run(drivers, name, nranks, args, bdir):
+    exes, env = drivers
+    out = subprocess.run([MPIEXEC, "-n", str(nranks), exes[name]] + args + ["-b", str(bdir)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    return out.stdout
+
+
+def results(stdout):
+    avg = [float(v) for v in re.findall(r"Result \(avg\): (\S+)", stdout)]
+    mx = [float(v) for v in re.findall(r"Result \(max\): (\S+)", stdout)]
+    return avg, mx
+
+
+def read_csv(path, nranks):
+    """blocks of the timer CSV: header row ',0,1,..,P-1,' then per gather an empty line and one row per section"""
+    lines = open(path).read().split("\n")
+    assert lines[0] == "," + "".join(f"{r}," for r in range(nranks))
+    blocks, cur = [], {}
+    for ln in lines[1:]:
+        if ln == "":
+            if cur:
+                blocks.append(cur)
+            cur = {}
+            continue
+        cells = ln.split(",")
+        assert len(cells) == nranks + 2 and cells[-1] == ""
+        cur[cells[0]] = [float(v) for v in cells[1:-1]]
+    if cur:
+        blocks.append(cur)
+    return blocks
+
+
+@needs_mpich
+@pytest.mark.parametrize("opt,P1,P2,prec", [(1, 2, 2, "-d"), (0, 2, 3, "-d"), (1, 3, 1, "")])
+def test_pencil_round_trip_and_timer_csv(drivers, tmp_path, opt, P1, P2, prec):
+    n, iters, warm = 48, 3, 1
+    args = ["-nx", str(n), "-ny", str(n), "-nz", str(n), "-p1", str(P1), "-p2", str(P2), "-o", str(opt), "-t", "3", "-i", str(iters), "-w", str(warm)]
+    out = run(drivers, "pencil", P1 * P2, args + ([prec] if prec else []), tmp_path)
+    avg, mx = results(out)
+    assert len(avg) == iters + warm and len(mx) == iters + warm
+    # printed like the reference: |inverse - N^3 * input|, input uniform in [0, 255)
+    tol = (1e-11 if prec else 1e-4) * 255 * n ** 3
+    assert max(mx) < tol and max(avg) < tol
+    name = f"test_{opt}_0_0_0_0_{n}_{n}_{n}_0_{P1}_{P2}.csv"      # Peer2Peer = 0, Sync = 0, cuda_aware = 0
+    blocks = read_csv(tmp_path / "pencil" / name, P1 * P2)
+    assert len(blocks) == 2 * iters                                 # one block per execR2C and per execC2R after the warm-up rounds
+    for b in blocks:
+        assert list(b)[0] == "init" and list(b)[-1] == "Run complete" and len(b) == 24      # include/mpicufft_pencil.hpp:263-287
+        assert all(v > 0 for v in b["Run complete"]) and all(v > 0 for v in b["init"])
+        z, y, x = b["1D FFT Z-Direction"], b["1D FFT Y-Direction"], b["1D FFT X-Direction"]
+        assert all(0 < v <= r * 1.001 for v, r in zip(z, b["Run complete"])) and all(v > 0 for v in y + x)
+    fwd, inv = blocks[0], blocks[1]      # cumulative stop points: z first in the forward transform, x first in the inverse
+    assert fwd["1D FFT Z-Direction"][0] < fwd["1D FFT Y-Direction"][0] < fwd["1D FFT X-Direction"][0]
+    assert inv["1D FFT X-Direction"][0] < inv["1D FFT Y-Direction"][0] < inv["1D FFT Z-Direction"][0]
+
+
+@needs_mpich
+@pytest.mark.parametrize("P1,P2,opt", [(2, 2, 1), (2, 1, 0)])
+def test_pencil_coordinator_testcase(drivers, tmp_path, P1, P2, opt):
+    """testcase 1: P1*P2 workers + one coordinator that transforms the whole grid on its own and compares"""
+    n = 32
+    out = run(drivers, "pencil", P1 * P2 + 1, ["-nx", str(n), "-ny", str(n), "-nz", str(n), "-p1", str(P1), "-p2", str(P2), "-o", str(opt), "-t", "1", "-i", "2", "-d"], tmp_path)
+    sums = [float(v) for v in re.findall(r"Results: (\S+)", out)]
+    assert len(sums) == 2 and all(s < 1e-9 * 255 * n ** 3 * n ** 3 / 2 for s in sums)      # sum over N^3/2 points of |diff|, |X| <= 255 N^3
+
+
+@needs_mpich
+def test_pencil_laplacian_and_partial_dimensions(drivers, tmp_path):
+    n = 32
+    out = run(drivers, "pencil", 4, ["-nx", str(n), "-ny", str(n), "-nz", str(n), "-p1", "2", "-p2", "2", "-o", "1", "-t", "4", "-d"], tmp_path)
+    avg, mx = results(out)
+    assert len(mx) == 1 and mx[0] < 1e-8 and avg[0] < 1e-9       # exact for a single Fourier mode up to rounding (-3 sqrt(N^3) sin sin sin)
+    for d in (1, 2):
+        out = run(drivers, "pencil", 4, ["-nx", str(n), "-ny", str(n), "-nz", str(n), "-p1", "2", "-p2", "2", "-o", "1", "-t", "3", "-f", str(d), "-d"], tmp_path)
+        avg, mx = results(out)
+        scale = {1: n, 2: n * n}[d]                                  # an unnormalised d-dimensional round trip
+        assert len(mx) == 1 and mx[0] < 1e-11 * 255 * scale, (d, mx)
+
+
+@needs_mpich
+@pytest.mark.parametrize("seq,opt,tc,sub", [("", 1, 3, "slab_default"), ("ZY_Then_X", 0, 4, "slab_default"), ("Z_Then_YX", 1, 3, "slab_z_then_yx"),
+                                            ("Z_Then_YX", 0, 1, "slab_z_then_yx"), ("Y_Then_ZX", 0, 0, "slab_y_then_zx"), ("Y_Then_ZX", 0, 1, "slab_y_then_zx")])
+def test_slab_sequences(drivers, tmp_path, seq, opt, tc, sub):
+    n, P = 40, 3
+    args = ["-nx", str(n), "-ny", str(n), "-nz", str(n), "-o", str(opt), "-t", str(tc), "-i", "2", "-d"] + (["-s", seq] if seq else [])
+    out = run(drivers, "slab", P + (1 if tc == 1 else 0), args, tmp_path)
+    if tc == 3:
+        avg, mx = results(out)
+        assert len(mx) == 2 and max(mx) < 1e-11 * 255 * n ** 3
+    elif tc == 4:
+        avg, mx = results(out)
+        assert len(mx) == 2 and max(mx) < 1e-8
+    elif tc == 1:
+        sums = [float(v) for v in re.findall(r"Results: (\S+)", out)]
+        assert len(sums) == 2 and all(s < 1e-9 * 255 * n ** 6 / 2 for s in sums)
+    path = tmp_path / sub / f"test_{opt}_0_0_{n}_{n}_{n}_0_{P}.csv"
+    blocks = read_csv(path, P)
+    assert len(blocks) == (4 if tc in (3, 4) else 2)
+    last = {"slab_default": "1D FFT X-Direction", "slab_z_then_yx": "2D FFT Y-X-Direction", "slab_y_then_zx": "2D FFT Z-X-Direction"}[sub]
+    assert all(v > 0 for v in blocks[0][last]) and all(v > 0 for v in blocks[0]["Run complete"])
+
+
+@needs_mpich
+def test_driver_rejects_bad_arguments(drivers, tmp_path):
+    exes, env = drivers
+    out = subprocess.run([exes["pencil"], "-nx", "8", "-ny", "8"], env=env, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1 and "Input parameter Nz is required." in out.stdout
+    out = subprocess.run([exes["slab"], "-nx", "8", "-ny", "8", "-nz", "8", "-s", "XYZ"], env=env, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1 and "Invalid sequence." in out.stdout
+    out = subprocess.run([exes["pencil"], "--help"], env=env, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "--partition1" in out.stdout

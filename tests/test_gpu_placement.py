@@ -1,0 +1,84 @@
+"""Placement-aware device memory (dfft_malloc / dfft_free / dfft_tune_placement, include/dfft_c.h): buffers backed through
+the HIP virtual-memory API hold transforms that equal the oracle's, the tuner returns usable buffers and leaves the plan
+with a work area, and the torch views are zero-copy."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import distributedfft_amd as dfft  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+from test_gpu_parity import CDT, TOL_FWD, TOL_RT, rel  # noqa: E402
+
+
+@pytest.mark.parametrize("chunk_mib", [0, 2, 16])
+def test_dfft_malloc_backings_hold_a_transform(chunk_mib):
+    shape = (64, 48, 40)
+    g = orc.fill_block(shape, (0, 0, 0), shape, 2, seed=11)
+    want = orc.fft3d_c2c(g, -1)
+    plan = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), precision="double")
+    plan.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(1, 1), True, c2c=True)
+    b_in = dfft.DeviceBuffer.alloc(g.nbytes, chunk_mib)
+    b_out = dfft.DeviceBuffer.alloc(plan.getDomainSize(), chunk_mib)
+    t_in = b_in.tensor(torch.complex128)
+    assert t_in.data_ptr() == b_in.address and t_in.numel() * 16 == b_in.nbytes
+    t_in.copy_(torch.from_numpy(g.reshape(-1)))
+    plan.execC2C(b_out, b_in, dfft.FORWARD)          # plans take the buffer objects directly
+    got = b_out.tensor(torch.complex128)[:g.size].cpu().numpy().reshape(shape)
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < TOL_FWD["double"]
+    plan.execC2C(b_in, b_out, dfft.INVERSE)
+    assert rel(t_in.cpu().numpy().reshape(shape) / g.size, g) < TOL_RT["double"]
+    del t_in, got
+    b_in.free(); b_out.free()
+    assert b_in.address == 0
+
+
+@pytest.mark.parametrize("prec,c2c", [("double", True), ("float", True), ("double", False)])
+def test_tune_placement_returns_working_buffers(prec, c2c):
+    shape = (96, 64, 128)
+    kind = 2 if c2c else 1
+    g = orc.fill_block(shape, (0, 0, 0), shape, kind, seed=5).astype(np.complex128 if c2c else np.float64)
+    want = orc.fft3d_c2c(g, -1) if c2c else orc.fft3d_r2c(g)
+    plan = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), precision=prec)
+    plan.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(1, 1), True, c2c=c2c)
+    rdt = torch.float64 if prec == "double" else torch.float32
+    d_in = torch.from_numpy(g).to("cuda").to(CDT[prec] if c2c else rdt).contiguous()
+    out, back, trials = plan.tunePlacement(d_in, tries=3, want_back=True)
+    # 1 baseline + 2 further candidates for each of work area, out, back
+    assert len(trials) == 7 and all(t > 0 for t in trials)
+    assert out.nbytes == plan.getDomainSize() and back.nbytes == d_in.numel() * d_in.element_size()
+    if c2c:
+        plan.execC2C(out, d_in, dfft.FORWARD)
+    else:
+        plan.execR2C(out, d_in)
+    osz = plan.getOutSize()
+    got = out.tensor(CDT[prec])[:osz[0] * osz[1] * osz[2]].cpu().numpy().reshape(osz)
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < TOL_FWD[prec]
+    if c2c:
+        plan.execC2C(back, out, dfft.INVERSE)
+        res = back.tensor(CDT[prec]).cpu().numpy().reshape(shape)
+    else:
+        plan.execC2R(back, out)
+        res = back.tensor(rdt).cpu().numpy().reshape(shape)
+    assert rel(res / float(np.prod(shape)), g) < TOL_RT[prec]
+    # the input was only read
+    assert np.array_equal(d_in.cpu().numpy().reshape(shape), g.astype(d_in.cpu().numpy().dtype))
+
+
+def test_tune_placement_keeps_a_callers_work_area():
+    shape = (32, 32, 32)
+    plan = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), precision="double")
+    plan.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(1, 1), False, c2c=True)
+    work = torch.empty(plan.getWorkSizeDevice(), dtype=torch.uint8, device="cuda")
+    plan.setWorkArea(work)
+    d_in = torch.randn(shape, dtype=torch.complex128, device="cuda")
+    out, back, trials = plan.tunePlacement(d_in, tries=2, want_back=False)
+    assert back is None and len(trials) == 2            # baseline + one more `out`; the caller's work area is not replaced
+    assert plan.getWorkAreaDevice() == work.data_ptr()
+    plan.execC2C(out, d_in, dfft.FORWARD)
+    want = torch.fft.fftn(d_in)
+    got = out.tensor(torch.complex128)[:d_in.numel()].reshape(shape)
+    assert float((got - want).abs().max() / want.abs().max()) < 1e-12
