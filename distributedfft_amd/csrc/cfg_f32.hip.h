@@ -1,0 +1,63 @@
+// cfg_f32.hip.h -- fp32 instantiations of the axis-pass kernel (TL = 16 lines per tile: 16 x 8 B = 128 B runs): the configurations shared by the translation units of this precision
+// (kernels_f32.hip: axis passes, real_f32.hip: packed real z passes, bluestein_f32.hip)
+#pragma once
+#include "kernels.hip.inc"
+
+namespace dfft {
+using F32_2    = PassCfg<float, 2,    2, 16, 16, 2, 1, 1, 1,   1>;
+using F32_4    = PassCfg<float, 4,    4, 16, 16, 4, 1, 1, 1,   1>;
+using F32_8    = PassCfg<float, 8,    8, 16, 16, 8, 1, 1, 1,   1>;
+using F32_16   = PassCfg<float, 16,  16, 16, 16, 16, 1, 1, 1,  1>;
+using F32_32   = PassCfg<float, 32,   8, 16, 4,  8, 4, 1, 1,   2>;
+using F32_64   = PassCfg<float, 64,   8, 16, 2,  8, 8, 1, 1,   2>;
+using F32_128  = PassCfg<float, 128, 16, 16, 2,  16, 8, 1, 1,  2>;
+using F32_256  = PassCfg<float, 256, 16, 16, 1,  16, 16, 1, 1, 2>;
+using F32_512  = PassCfg<float, 512, 16, 16, 1,  8, 8, 8, 1,   2>;
+// 32 points per thread: fp32 runs out of instruction issue, not bandwidth, at 16
+using F32_1024 = PassCfg<float, 1024, 32, 16, 1, 32, 8, 4, 1,  1, 1>;
+using F32_2048 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1,  1, 1>;
+// The variant number of a configuration is its ROLE in a plan (dfft_init picks by role, see PassRole):
+//   4 = natural-line load: point-fastest lane mapping in every pass (PassCfg::MAP = 1; forward z pass)
+//   5 = natural-line store: line-fastest first pass (tiled load), point-fastest afterwards (MAP = 2; inverse z pass)
+//   6 = tiled passes (y, x): two radix passes with a single LDS exchange
+using F32_1024_v4 = PassCfg<float, 1024, 32, 16, 1, 32, 8, 4, 1, 1, 1, 0, 1>;
+using F32_1024_v5 = PassCfg<float, 1024, 32, 16, 1, 32, 8, 4, 1, 1, 1, 0, 2>;
+using F32_1024_v6 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1>;
+using F32_512_v6 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1>;
+using F32_512_v4 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1, 0, 1>;
+using F32_512_v5 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1, 0, 2>;
+// 2048: 16 lines x 2048 points are 256 KiB -- one workgroup per CU.  The natural-line passes (4, 5) run 64 points
+// per thread (radix 64.32, a single LDS exchange) on sub-tile workgroups of 8 lines (PassCfg::SUB = 2: 256 threads,
+// 66 KiB LDS, two per CU): 36.2 -> 30.4 ms per pass at 2048^3.  The tiled passes (6) keep whole tiles (a sub-tile's
+// 64-byte runs cost more than its occupancy gives) with the same two-pass chain on 512 threads.
+using F32_2048_v4 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3, 1, 2>;
+using F32_2048_v5 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 2, 2>;
+using F32_2048_v6 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1>;
+// 4096 and 8192 points: sub-tile workgroups of 4 / 2 lines (see kernels_f64.hip), 512 threads, 64 KiB of LDS
+using F32_4096 = PassCfg<float, 4096, 32, 16, 1, 32, 16, 8, 1, 1, 1, 0, 0, 4>;
+using F32_8192 = PassCfg<float, 8192, 32, 16, 1, 32, 16, 16, 1, 1, 1, 0, 0, 8>;
+// A/B-only configurations of earlier measurements (sub-tile workgroups on tiled passes, nontemporal loads-only / stores-only,
+// whole-tile 64-point forms, 32-point fp64 2048, ...) were removed after they were measured: results in profiles/r2_*.txt and
+// DESIGN.md section 6, definitions in the git history (commit c38cf04).  New ones go here, under -DDFFT_EXPERIMENTS:
+
+// persistent, software-pipelined forms (PassCfg::PERSIST) under test
+using F32_2048_v8 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 0, 1, 1>;
+using F32_2048_v9 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3, 0, 1, 1>;
+#ifdef DFFT_EXPERIMENTS
+#define DFFT_F32_EXP_SMALL(X)
+#define DFFT_F32_EXP_1024(X)
+#define DFFT_F32_EXP_2048(X) X(2048, 8, F32_2048_v8) X(2048, 9, F32_2048_v9)
+#else
+#define DFFT_F32_EXP_SMALL(X)
+#define DFFT_F32_EXP_1024(X)
+#define DFFT_F32_EXP_2048(X)
+#endif
+#define DFFT_F32_LIST_SMALL(X) X(512, 6, F32_512_v6) X(512, 4, F32_512_v4) X(512, 5, F32_512_v5) X(2, 0, F32_2) X(4, 0, F32_4) X(8, 0, F32_8) X(16, 0, F32_16) X(32, 0, F32_32) X(64, 0, F32_64) X(128, 0, F32_128) X(256, 0, F32_256) X(512, 0, F32_512) DFFT_F32_EXP_SMALL(X)
+#define DFFT_F32_LIST_1024(X) X(1024, 4, F32_1024_v4) X(1024, 5, F32_1024_v5) X(1024, 6, F32_1024_v6) X(1024, 0, F32_1024) DFFT_F32_EXP_1024(X)
+#define DFFT_F32_LIST_2048(X) X(2048, 4, F32_2048_v4) X(2048, 5, F32_2048_v5) X(2048, 6, F32_2048_v6) X(2048, 0, F32_2048) X(4096, 0, F32_4096) X(8192, 0, F32_8192) DFFT_F32_EXP_2048(X)
+
+// lengths with a packed real z pass / a Bluestein inner transform of their own configuration
+// real-transform z passes (variant 0 configurations only); M = Nz/2
+#define DFFT_F32_BASE(X) X(2, 0, F32_2) X(4, 0, F32_4) X(8, 0, F32_8) X(16, 0, F32_16) X(32, 0, F32_32) X(64, 0, F32_64) \
+    X(128, 0, F32_128) X(256, 0, F32_256) X(512, 0, F32_512) X(1024, 0, F32_1024)
+}  // namespace dfft

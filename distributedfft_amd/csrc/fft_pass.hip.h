@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(Cfg::THREADS, ONEPLANE == 2 ? 4 : 1) void fft_r2c_k
         });
     } else if (!YLINES && active) {
         const C *p = in + ((uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + tc.l) * M + t;
-        static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = p[NT * c]; });
+        static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = stream_load<Cfg>(p + NT * c); });
     } else {
         static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].x = 0; v[c].y = 0; });
     }
@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(Cfg::THREADS, ONEPLANE == 2 ? 4 : 1) void fft_r2c_k
                 C x;
                 x.x = (R)0.5 * (Ar + wv.x * Bi + wv.y * Br);
                 x.y = (R)0.5 * (Ai - wv.x * Br + wv.y * Bi);
-                out[offset_of((uint32_t)k)] = x;
+                stream_store<Cfg>(out + offset_of((uint32_t)k), x);
                 if constexpr (c == 0) {
                     if (special) {          // k = M: X[M] = Re Z[0] - Im Z[0]
                         C xm; xm.x = z.x - z.y; xm.y = 0;
@@ -1277,7 +1277,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
                 constexpr int c = decltype(cc)::value;
                 constexpr int i = c % S1, m = c / S1;                  // input leg m of block i (natural leg order)
                 const int k = pair_j<Cfg, R1, i>(t) + m * LEG;
-                x[c] = in[offset_of((uint32_t)k)];
+                x[c] = stream_load<Cfg>(in + offset_of((uint32_t)k));
             });
             if (special) xM = in[offset_of((uint32_t)M)];
         };
@@ -1352,7 +1352,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
         constexpr int c = decltype(cc)::value;
         constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (M / RL);
         C r; r.x = v[c].y; r.y = v[c].x;     // swap back
-        p[k0] = r;
+        stream_store<Cfg>(p + k0, r);
     });
 }
 

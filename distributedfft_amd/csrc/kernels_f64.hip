@@ -1,172 +1,31 @@
-// fp64 instantiations of the axis-pass kernel (TL = 8 lines per tile: 8 x 16 B = 128 B runs)
-#include "kernels.hip.inc"
+// kernels_f64.hip -- the axis-pass kernels of the power-of-two lengths, f64.  Compiled in three parts (-DDFFT_PART = 0: up to 512
+// points and the entry points, 1: 1024, 2: 2048 and longer) so that a parallel make spreads the instantiations.
+#include "cfg_f64.hip.h"
 
 namespace dfft {
-//                 real    N     E  TL  G   radices      planes  chained twiddles
-using F64_2    = PassCfg<double, 2,    2, 8, 32, 2, 1, 1, 1,   1>;
-using F64_4    = PassCfg<double, 4,    4, 8, 32, 4, 1, 1, 1,   1>;
-using F64_8    = PassCfg<double, 8,    8, 8, 32, 8, 1, 1, 1,   1>;
-using F64_16   = PassCfg<double, 16,  16, 8, 32, 16, 1, 1, 1,  1>;
-using F64_32   = PassCfg<double, 32,   8, 8, 8,  8, 4, 1, 1,   2>;
-using F64_64   = PassCfg<double, 64,   8, 8, 4,  8, 8, 1, 1,   2>;
-using F64_128  = PassCfg<double, 128, 16, 8, 4,  16, 8, 1, 1,  2>;
-using F64_256  = PassCfg<double, 256, 16, 8, 2,  16, 16, 1, 1, 2>;
-using F64_512  = PassCfg<double, 512, 16, 8, 1,  8, 8, 8, 1,   1>;
-// 1024: 512 threads, <= 128 VGPRs, 68 KiB LDS -> two workgroups per CU (measured best)
-using F64_1024 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1>;
-using F64_2048 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1>;
-// The variant number of a configuration is its ROLE in a plan (dfft_init picks by role, see PassRole):
-//   1 = strided read: passes that load the point-major API layout (multi-rank inverse x pass): 16 lines per workgroup
-//       (two tiles of 8: 128-byte runs from two neighbouring rows per point), 32 points per thread (twice the loads in
-//       flight), nontemporal loads and stores (7.9 -> 7.6 ms at 1024^3; 8.9 ms with the default configuration).  2048 points:
-//       the streaming configuration (18.8 -> 17.5 ms on 2048 x 1024 x 1024; 32 points per thread lose there, one or two
-//       workgroups per CU alike: profiles/r3_strided_read_variants.txt)
-//   3 = streaming: nontemporal loads and stores, for passes whose stores come in long runs (tiled 1 KiB chunks,
-//       natural lines): +2-3 %; it costs up to 10 % on 128-byte-run stores, so those keep 0
-//   7 = natural lines: a pass with natural lines on one side.  Only 2048 has its own: 8 lines x 2048 points are
-//       256 KiB, one workgroup per CU whatever the configuration, so every tile is split between two sibling
-//       workgroups of 4 lines (PassCfg::SUB, 68 KiB LDS, two per CU) -- 16.5 -> 12-13 ms on a 1024 x 1024 x 2048 grid.
-//       With a tiled side the half-width (64-byte) runs of a sub-tile cost more than the occupancy gives, so the
-//       tiled 2048-point passes keep whole tiles.
-using F64_1024_v1 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 3>;
-using F64_1024_v3 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 3>;
-using F64_512_v1 = PassCfg<double, 512, 32, 8, 2, 32, 16, 1, 1, 1, 1>;
-using F64_512_v3 = PassCfg<double, 512, 16, 8, 1, 8, 8, 8, 1, 1, 0, 3>;
-using F64_2048_v3 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 3>;
-using F64_2048_v7 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 3, 0, 2>;
-// 4096 and 8192 points: a whole tile of 8 lines does not fit a CU, so a workgroup transforms 2 lines (4096) or 1 line
-// (8192) of a tile (PassCfg::SUB = 4 / 8; 64 KiB of LDS, two workgroups per CU) and its siblings -- consecutive logical
-// workgroups on one XCD -- the rest.  Natural lines are unaffected; a tiled side is accessed in 32- / 16-byte pieces that
-// L2 puts together: these lengths run for completeness (the reference takes any length, mpicufft_pencil_opt1.cpp:165-197),
-// not at the speed of the shorter ones.
-using F64_4096 = PassCfg<double, 4096, 16, 8, 1, 16, 16, 16, 1, 1, 1, 0, 0, 4>;
-using F64_8192 = PassCfg<double, 8192, 32, 8, 1, 32, 16, 16, 1, 1, 1, 0, 0, 8>;
-// A/B-only configurations of earlier measurements (sub-tile workgroups on tiled passes, nontemporal loads-only / stores-only,
-// whole-tile 64-point forms, 32-point fp64 2048, ...) were removed after they were measured: results in profiles/r2_*.txt and
-// DESIGN.md section 6, definitions in the git history (commit c38cf04).  New ones go here, under -DDFFT_EXPERIMENTS:
-
-// persistent, software-pipelined forms (PassCfg::PERSIST) under test
-using F64_1024_v8 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 3, 0, 1, 1>;
-using F64_1024_v9 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 0, 0, 1, 1>;
-using F64_2048_v8 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 0, 0, 1, 1>;
-using F64_2048_v9 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 0, 0, 1, 0>;
-using F64_2048_v10 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 3, 0, 1, 2>;
-using F64_1024_v10 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 3, 0, 1, 2>;
-using F64_1024_v11 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 0, 0, 1, 2>;
-// 32 points per thread on ONE tile of 8 lines: 256 threads, 68 KiB of LDS -> two independent workgroups per CU
-using F64_1024_v12 = PassCfg<double, 1024, 32, 8, 1, 32, 32, 1, 1, 1, 1, 3>;
-using F64_1024_v13 = PassCfg<double, 1024, 32, 8, 1, 32, 32, 1, 1, 1, 1, 0>;
-using F64_2048_v12 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 3, 0, 2>;
-#ifdef DFFT_EXPERIMENTS
-#define DFFT_F64_EXP_SMALL(X)
-#define DFFT_F64_EXP_1024(X) X(1024, 8, F64_1024_v8) X(1024, 9, F64_1024_v9) X(1024, 10, F64_1024_v10) X(1024, 11, F64_1024_v11) X(1024, 12, F64_1024_v12) X(1024, 13, F64_1024_v13)
-#define DFFT_F64_EXP_2048(X) X(2048, 8, F64_2048_v8) X(2048, 9, F64_2048_v9) X(2048, 10, F64_2048_v10) X(2048, 12, F64_2048_v12)
-#else
-#define DFFT_F64_EXP_SMALL(X)
-#define DFFT_F64_EXP_1024(X)
-#define DFFT_F64_EXP_2048(X)
-#endif
-#define DFFT_F64_LIST_SMALL(X) X(512, 1, F64_512_v1) X(512, 3, F64_512_v3) X(2, 0, F64_2) X(4, 0, F64_4) X(8, 0, F64_8) X(16, 0, F64_16) X(32, 0, F64_32) X(64, 0, F64_64) X(128, 0, F64_128) X(256, 0, F64_256) X(512, 0, F64_512) DFFT_F64_EXP_SMALL(X)
-#define DFFT_F64_LIST_1024(X) X(1024, 1, F64_1024_v1) X(1024, 3, F64_1024_v3) X(1024, 0, F64_1024) DFFT_F64_EXP_1024(X)
-#define DFFT_F64_LIST_2048(X) X(2048, 1, F64_2048_v3) X(2048, 3, F64_2048_v3) X(2048, 7, F64_2048_v7) X(2048, 0, F64_2048) X(4096, 0, F64_4096) X(8192, 0, F64_8192) DFFT_F64_EXP_2048(X)
-
-// lengths that are not powers of two (mixed radix 2, 3, 5, 7): generated list, slices 5 (N < 512) and 6
-#define DFFT_MIXED_F64
-#include "kernels_mixed.inc"
-
-DFFT_SLICE_DECLS(f64)
-#if DFFT_SLICE == 0
-DFFT_SLICE_FUNCS(f64, 0, DFFT_F64_LIST_SMALL)
+int launch_mixed_f64(int N, int variant, const PassArgs &A, hipStream_t stream);      // mixed_f64.hip
+bool mixed_info_f64(int N, int variant, PassInfo *pi);
+#define DFFT_DECL_PART(k) int launch_pass_f64_p##k(int, int, const PassArgs &, hipStream_t); bool pass_info_f64_p##k(int, int, PassInfo *);
+DFFT_DECL_PART(0) DFFT_DECL_PART(1) DFFT_DECL_PART(2)
+#undef DFFT_DECL_PART
+#if DFFT_PART == 0
+DFFT_PASS_FUNCS(launch_pass_f64_p0, pass_info_f64_p0, DFFT_F64_LIST_SMALL)
 int launch_pass_f64(int N, int variant, const PassArgs &A, hipStream_t stream)
 {
-    if (!is_pow2(N)) return N < 512 ? launch_pass_f64_s5(N, variant, A, stream) : launch_pass_f64_s6(N, variant, A, stream);
-    return N <= 512 ? launch_pass_f64_s0(N, variant, A, stream) : N == 1024 ? launch_pass_f64_s1(N, variant, A, stream)
-                                                                          : launch_pass_f64_s2(N, variant, A, stream);
+    if (!is_pow2(N)) return launch_mixed_f64(N, variant, A, stream);
+    return N <= 512 ? launch_pass_f64_p0(N, variant, A, stream) : N == 1024 ? launch_pass_f64_p1(N, variant, A, stream)
+                                                                          : launch_pass_f64_p2(N, variant, A, stream);
 }
 bool pass_info_f64(int N, int variant, PassInfo *pi)
 {
-    if (!is_pow2(N)) return N < 512 ? pass_info_f64_s5(N, variant, pi) : pass_info_f64_s6(N, variant, pi);
-    return N <= 512 ? pass_info_f64_s0(N, variant, pi) : N == 1024 ? pass_info_f64_s1(N, variant, pi) : pass_info_f64_s2(N, variant, pi);
+    if (!is_pow2(N)) return mixed_info_f64(N, variant, pi);
+    return N <= 512 ? pass_info_f64_p0(N, variant, pi) : N == 1024 ? pass_info_f64_p1(N, variant, pi) : pass_info_f64_p2(N, variant, pi);
 }
-#elif DFFT_SLICE == 1
-DFFT_SLICE_FUNCS(f64, 1, DFFT_F64_LIST_1024)
-#elif DFFT_SLICE == 2
-DFFT_SLICE_FUNCS(f64, 2, DFFT_F64_LIST_2048)
-#elif DFFT_SLICE == 5
-DFFT_SLICE_FUNCS(f64, 5, DFFT_F64_LIST_MIXED0)
-#elif DFFT_SLICE == 6
-DFFT_SLICE_FUNCS(f64, 6, DFFT_F64_LIST_MIXED1)
-#elif DFFT_SLICE == 7
-DFFT_REAL_MIXED_FUNCS(f64, 7, DFFT_F64_LIST_RMIXED0)
-#elif DFFT_SLICE == 8
-DFFT_REAL_MIXED_FUNCS(f64, 8, DFFT_F64_LIST_RMIXED1)
+#elif DFFT_PART == 1
+DFFT_PASS_FUNCS(launch_pass_f64_p1, pass_info_f64_p1, DFFT_F64_LIST_1024)
+#elif DFFT_PART == 2
+DFFT_PASS_FUNCS(launch_pass_f64_p2, pass_info_f64_p2, DFFT_F64_LIST_2048)
 #else
-// slices 3 (real z passes) and 4 (Bluestein) share the base list
-
-// real-transform z passes; M = Nz/2.  512 gets its own 8-points-per-thread configuration: the
-// split/merge step needs both LDS planes, and 512 threads x 64 KiB keeps 16 waves on a CU
-using F64_R512 = PassCfg<double, 512, 8, 8, 1, 8, 8, 8, 1, 1>;
-#define DFFT_F64_BASE(X) X(2, 0, F64_2) X(4, 0, F64_4) X(8, 0, F64_8) X(16, 0, F64_16) X(32, 0, F64_32) X(64, 0, F64_64) \
-    X(128, 0, F64_128) X(256, 0, F64_256) X(512, 0, F64_R512) X(1024, 0, F64_1024)
-#if DFFT_SLICE == 3
-// 512 and 1024 (Nz = 1024, 2048): the Hermitian split / merge runs in registers -- the pass next to it assigns its
-// butterflies in conjugate pairs (pair_j), which needs an even number of butterflies per thread in that pass: 16 points
-// per thread with radix 8 (512) or radix 4 (1024: last for R2C, first for C2R)
-using F64_R1024_c2r = PassCfg<double, 1024, 16, 8, 1, 4, 16, 16, 1, 1, 1>;
-// is there a packed real z pass for M = Nz/2 complex points?
-bool real_supported_f64(int M)
-{
-    if (!is_pow2(M)) return M < 320 ? real_mixed_info_f64_s7(M) : real_mixed_info_f64_s8(M);
-    switch (M) {
-#define X(n, v, cfg) case n: return true;
-        DFFT_F64_BASE(X)
-        X(2048, 0, F64_2048)
-#undef X
-    }
-    return false;
-}
-int launch_real_f64(int M, int mode, int variant, const PassArgs &A, hipStream_t stream)
-{
-    if (!is_pow2(M)) {      // mixed-radix lengths (kernels_mixed.inc); no strided-real-line (Y_Then_ZX) form
-        if (A.load_kind == LOAD_KMAJOR && mode == 1) return -1;
-        return M < 320 ? launch_real_mixed_f64_s7(M, mode, A, stream) : launch_real_mixed_f64_s8(M, mode, A, stream);
-    }
-    // Nz = 4096: 8 lines x 2048 points fill the LDS with one plane, so the split runs one plane after the other
-    if (M == 2048 && A.load_kind != LOAD_KMAJOR) return mode == 1 ? launch_real_cfg<F64_2048, 1, 1>(A, stream) : launch_real_cfg<F64_2048, 2>(A, stream);
-    if (variant == 0 && A.load_kind != LOAD_KMAJOR) {
-        if (M == 512) return mode == 1 ? launch_real_cfg<F64_512, 1, 2>(A, stream) : launch_real_cfg<F64_512, 2, 2>(A, stream);
-        if (M == 1024) return mode == 1 ? launch_real_cfg<F64_1024, 1, 2>(A, stream) : launch_real_cfg<F64_R1024_c2r, 2, 2>(A, stream);
-    }
-    if (mode == 1 && A.load_kind == LOAD_KMAJOR) {      // strided real lines (Y_Then_ZX)
-        switch (M) {
-#define X(n, v, cfg) case n: return launch_real_cfg<cfg, 3>(A, stream);
-            DFFT_F64_BASE(X)
-#undef X
-        }
-        return -1;
-    }
-    switch (M) {
-#define X(n, v, cfg) case n: return mode == 1 ? launch_real_cfg<cfg, 1>(A, stream) : launch_real_cfg<cfg, 2>(A, stream);
-        DFFT_F64_BASE(X)
-#undef X
-    }
-    return -1;
-}
-
-#else
-// Bluestein passes for arbitrary line lengths: M = power of two >= 2*NL - 1
-int launch_bluestein_f64(int M, const PassArgs &A, hipStream_t stream)
-{
-    switch (M) {
-#define X(n, v, cfg) case n: return launch_bluestein_cfg<cfg>(A, stream);
-        DFFT_F64_BASE(X)
-        X(2048, 0, F64_2048)
-        X(4096, 0, F64_4096)      // lines of 1025..2048 / 2049..4096 points: inner transforms on sub-tile workgroups
-        X(8192, 0, F64_8192)
-#undef X
-    }
-    return -1;
-}
-#endif  // DFFT_SLICE == 3
-#endif  // DFFT_SLICE
+#error "DFFT_PART must be 0, 1 or 2"
+#endif
 }  // namespace dfft

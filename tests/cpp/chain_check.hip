@@ -115,7 +115,7 @@ int main()
     using P1024 = PassCfg<float, 1024, 32, 16, 1, 32, 8, 4, 1, 1, 1>;
     check_cfg<P64>("pow2"); check_cfg<P1024>("pow2");
 #define X(n, v, cfg) check_cfg<cfg>(#cfg);
-    DFFT_F32_LIST_MIXED0(X) DFFT_F32_LIST_MIXED1(X)
+    DFFT_F32_LIST_MIXED_ALL(X)
 #undef X
 #else
     using P64 = PassCfg<double, 64, 8, 8, 4, 8, 8, 1, 1, 2>;
@@ -123,7 +123,7 @@ int main()
     using P1024 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1>;
     check_cfg<P64>("pow2"); check_cfg<P512>("pow2"); check_cfg<P1024>("pow2");
 #define X(n, v, cfg) check_cfg<cfg>(#cfg);
-    DFFT_F64_LIST_MIXED0(X) DFFT_F64_LIST_MIXED1(X)
+    DFFT_F64_LIST_MIXED_ALL(X)
 #undef X
 #endif
     printf("%d configurations checked, %d failed\n%s\n", checked, failures, failures ? "FAILED" : "ALL OK");

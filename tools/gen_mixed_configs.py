@@ -100,6 +100,10 @@ def choose(N, prec):
     return None if best is None else best[1]
 
 
+# compile parts per precision: (mixed_*.hip, rmixed_*.hip)
+PARTS = {"f64": (2, 3), "f32": (4, 6)}
+
+
 def main():
     out = []
     out.append("// kernels_mixed.inc -- GENERATED by tools/gen_mixed_configs.py; do not edit.")
@@ -120,14 +124,27 @@ def main():
             tail = ", 0, 0, 2" if c["sub"] == 2 else ""      # NTMEM, MAP, SUB
             out.append(f"using {tag}_M{c['N']} = PassCfg<{real}, {c['N']}, {c['E']}, {c['TL']}, {c['G']}, {r[0]}, {r[1]}, {r[2]}, {r[3]}, {c['planes']}, {chain}{tail}>;"
                        f"   // {c['threads']} threads, {c['lds']} B LDS")
-        # two compile slices per precision: lengths below / from 512
-        for k, sel in ((0, [c for c in cfgs if c["N"] < 512]), (1, [c for c in cfgs if c["N"] >= 512])):
+        # Compile parts (mixed_*.hip / rmixed_*.hip, -DDFFT_PART=k): the configurations are dealt to PARTS[...] lists of about
+        # equal compile cost (longest first onto the lightest list; cost ~ points per thread x (passes + 1), which is what
+        # the unrolled code size follows).  fp32 kernels take ~2.7x as long to compile as fp64 ones, hence more parts.
+        def deal(items, nparts):
+            bins = [[0.0, []] for _ in range(nparts)]
+            for c in sorted(items, key=lambda c: -(c["E"] * (len(c["rad"]) + 1))):
+                b = min(bins, key=lambda b: b[0])
+                b[0] += c["E"] * (len(c["rad"]) + 1)
+                b[1].append(c)
+            return [sorted(b[1], key=lambda c: c["N"]) for b in bins]
+
+        nm, nr = PARTS[prec]
+        for k, sel in enumerate(deal(cfgs, nm)):
             xs = " ".join(f"X({c['N']}, 0, {tag}_M{c['N']})" for c in sel)
             out.append(f"#define DFFT_{tag}_LIST_MIXED{k}(X) {xs}")
+        out.append(f"#define DFFT_{tag}_MIXED_FOREACH_PART(P) " + " ".join(f"P({k})" for k in range(nm)))
+        out.append(f"#define DFFT_{tag}_LIST_MIXED_ALL(X) " + " ".join(f"DFFT_{tag}_LIST_MIXED{k}(X)" for k in range(nm)))
         # packed real z passes (R2C / C2R of a real line of 2M points as an M-point complex transform + Hermitian split /
         # merge): every configuration with whole-tile workgroups; Y(M, cfg, ONEPLANE)
         real = [c for c in cfgs if c["sub"] == 1 and c["N"] <= 1024]
-        for k, sel in ((0, [c for c in real if c["N"] < 320]), (1, [c for c in real if c["N"] >= 320])):
+        for k, sel in enumerate(deal(real, nr)):
             ys = []
             for c in sel:
                 plane = lds_bytes(c["N"], c["TL"] * c["G"], c["rad"][0], 1, 8 if prec == "f64" else 4, 2)
@@ -135,10 +152,15 @@ def main():
                 # barriers, half the LDS: the mixed configurations have 256-512 threads, one workgroup per CU starves it)
                 ys.append(f"Y({c['N']}, {tag}_M{c['N']}, {0 if 2 * plane <= 80 * 1024 else 1})")
             out.append(f"#define DFFT_{tag}_LIST_RMIXED{k}(Y) {' '.join(ys)}")
+        out.append(f"#define DFFT_{tag}_RMIXED_FOREACH_PART(P) " + " ".join(f"P({k})" for k in range(nr)))
         out.append("#endif")
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "distributedfft_amd", "csrc", "kernels_mixed.inc")
-    with open(path, "w") as f:
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "distributedfft_amd", "csrc")
+    with open(os.path.join(csrc, "kernels_mixed.inc"), "w") as f:
         f.write("\n".join(out) + "\n")
+    with open(os.path.join(csrc, "kernels_mixed.mk"), "w") as f:      # part counts for the Makefile
+        f.write("# GENERATED by tools/gen_mixed_configs.py: compile parts of mixed_*.hip / rmixed_*.hip\n")
+        for prec in ("f64", "f32"):
+            f.write(f"NM_{prec} = {PARTS[prec][0]}\nNR_{prec} = {PARTS[prec][1]}\n")
     print("\n".join(out))
 
 

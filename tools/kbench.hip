@@ -132,6 +132,8 @@ struct Args {
     // --sweep "k=v,k2=v2;k=v3": option sets measured one after the other IN ONE PROCESS ON THE SAME BUFFERS (the 128-byte-run
     // passes depend on the physical placement of a buffer, profiles/r2_placement_probe.txt: A/B across processes is noise)
     std::vector<std::vector<std::pair<std::string, long>>> sweep;
+    // --tune K: out / back / the work area come from dfft_tune_placement with K physical backings per buffer
+    int tune = 0;
 };
 
 static int dry_exchange(void *, const void *, const size_t *, const size_t *, void *, const size_t *, const size_t *, const int *, int, int, void *)
@@ -196,6 +198,7 @@ static Args parse(int argc, char **argv)
         else if (k == "--shuffle") a.shuffle = 1;
         else if (k == "--ranks") { if (sscanf(next(), "%dx%d", &a.P1, &a.P2) != 2) { fprintf(stderr, "--ranks P1xP2\n"); exit(1); } }
         else if (k == "--rank") a.rank = atoi(next());
+        else if (k == "--tune") a.tune = atoi(next());
         else if (k == "--sweep") {
             std::string all = next();
             size_t pos = 0;
@@ -325,6 +328,16 @@ template <typename R> static int run_plan(const Args &a)
         in = vmm_alloc(in_bytes, chunk, a.shuffle);
         out = vmm_alloc(dom, chunk, a.shuffle);
         back = vmm_alloc(in_bytes, chunk, a.shuffle);
+    } else if (a.tune > 1) {
+        HIPCHK(hipMalloc(&in, in_bytes));
+        fill_random<R><<<nblk, 256>>>((R *)in, in_bytes / sizeof(R));
+        HIPCHK(hipDeviceSynchronize());
+        float rep[64];
+        int nrep = 0;
+        DCHK(dfft_tune_placement(plan, in, a.tune, (void **)&out, (void **)&back, rep, 64, &nrep));
+        printf("TUNE %d backings per buffer, FFT ms (fwd + inv) per trial:", a.tune);
+        for (int i = 0; i < nrep; i++) printf(" %.3f", rep[i]);
+        printf("\n");
     } else {
         HIPCHK(hipMalloc(&in, in_bytes));
         HIPCHK(hipMalloc(&out, dom));
@@ -403,6 +416,7 @@ template <typename R> static int run_plan(const Args &a)
     for (auto &kv : sets[si]) optstr += " " + kv.first + "=" + std::to_string(kv.second);
     if (sweeping) optstr += " [set " + std::to_string(si) + ", shared buffers]";
     if (a.vmm_mib) optstr += " vmm=" + std::to_string(a.vmm_mib) + "MiB" + (a.shuffle ? " shuffled" : "");
+    if (a.tune > 1) optstr += " tuned placement (" + std::to_string(a.tune) + ")";
     if (a.slab) optstr += " slab perm=" + a.perm + " delta=" + std::to_string(a.delta);
     if (nranks > 1) optstr += " rank " + std::to_string(a.rank) + " of " + std::to_string(a.P1) + "x" + std::to_string(a.P2) + " (exchange stubbed), chunks=" + std::to_string(dfft_get_pipeline_chunks(plan));
     printf("PLAN %s %zux%zux%zu %s %s%s | wave_err %.2e roundtrip %.2e | wall %.3f ms/step\n", a.label.c_str(), a.Nx, a.Ny, a.Nz,
@@ -428,6 +442,7 @@ template <typename R> static int run_plan(const Args &a)
     if (work) HIPCHK(hipFree(work));
     if (a.slab) HIPCHK(hipFree(slab));
     else if (a.vmm_mib) { /* process exit unmaps */ }
+    else if (a.tune > 1) { HIPCHK(hipFree(in)); DCHK(dfft_free(out)); DCHK(dfft_free(back)); }
     else {
         HIPCHK(hipFree(in)); HIPCHK(hipFree(out));
         if (!alias_back) HIPCHK(hipFree(back));
