@@ -534,7 +534,7 @@ def main():
     # on this workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 read correction applied)
     try:
         # newest committed PMC run of the headline kernel (tools/pmc_traffic.sh + tools/pmc_traffic.py)
-        pmc = [f for f in ("r2_pmc_traffic.json", "r1_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+        pmc = [f for f in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
         pm = json.load(open(os.path.join(ROOT, "profiles", pmc)))
         if ngpus == 1 and N == 1024 and prec == "double" and pm.get("hbm_bytes_per_launch"):
             roofline["traffic"] = pm["hbm_bytes_per_launch"]

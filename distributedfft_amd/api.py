@@ -247,7 +247,7 @@ class MPIcuFFT:
         (want_back) a new buffer for the inverse transform's output, and keeps for each the one this plan's own passes run
         fastest on.  `in_` must hold a valid input block.  Returns (out, back or None, [ms of every trial])."""
         o, b = C.c_void_p(), C.c_void_p()
-        rep = (C.c_float * (3 * max(1, int(tries)) + 1))()
+        rep = (C.c_float * (3 * max(1, int(tries)) + 8))()
         n = C.c_int(0)
         check(lib().dfft_tune_placement(self._h, _ptr(in_), int(tries), C.byref(o), C.byref(b) if want_back else None, rep, len(rep), C.byref(n)))
         isz = self.getInSize()

@@ -43,10 +43,15 @@ using F32_8192 = PassCfg<float, 8192, 32, 16, 1, 32, 16, 16, 1, 1, 1, 0, 0, 8>;
 // persistent, software-pipelined forms (PassCfg::PERSIST) under test
 using F32_2048_v8 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 0, 1, 1>;
 using F32_2048_v9 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3, 0, 1, 1>;
+// tiled 2048-point passes under test: radix 32 first (two butterflies per thread: the second one's loads are still in flight
+// while the first is computed; with radix 64 first a thread waits for all of its 64 loads), and the streaming form of 64.32
+using F32_2048_v10 = PassCfg<float, 2048, 64, 16, 1, 32, 64, 1, 1, 1, 1>;
+using F32_2048_v11 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3>;
+using F32_2048_v12 = PassCfg<float, 2048, 64, 16, 1, 32, 64, 1, 1, 1, 1, 3>;
 #ifdef DFFT_EXPERIMENTS
 #define DFFT_F32_EXP_SMALL(X)
 #define DFFT_F32_EXP_1024(X)
-#define DFFT_F32_EXP_2048(X) X(2048, 8, F32_2048_v8) X(2048, 9, F32_2048_v9)
+#define DFFT_F32_EXP_2048(X) X(2048, 8, F32_2048_v8) X(2048, 9, F32_2048_v9) X(2048, 10, F32_2048_v10) X(2048, 11, F32_2048_v11) X(2048, 12, F32_2048_v12)
 #else
 #define DFFT_F32_EXP_SMALL(X)
 #define DFFT_F32_EXP_1024(X)

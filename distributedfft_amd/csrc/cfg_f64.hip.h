@@ -32,6 +32,10 @@ using F64_2048 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1>;
 //       tiled 2048-point passes keep whole tiles.
 using F64_1024_v1 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 3>;
 using F64_1024_v3 = PassCfg<double, 1024, 16, 8, 1, 16, 16, 4, 1, 1, 1, 3>;
+//   2 = strided read of rows whose pitch is not a multiple of the tile (R2C plans: 513-wide rows): as 1, but only the STORES
+//       nontemporal -- the 256-byte runs of neighbouring workgroups share a cache line, which a streaming load hint evicts
+//       before the neighbour gets to it
+using F64_1024_v2 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 2>;
 using F64_512_v1 = PassCfg<double, 512, 32, 8, 2, 32, 16, 1, 1, 1, 1>;
 using F64_512_v3 = PassCfg<double, 512, 16, 8, 1, 8, 8, 8, 1, 1, 0, 3>;
 using F64_2048_v3 = PassCfg<double, 2048, 16, 8, 1, 16, 16, 8, 1, 1, 1, 3>;
@@ -69,7 +73,7 @@ using F64_2048_v12 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 3, 0, 2
 #define DFFT_F64_EXP_2048(X)
 #endif
 #define DFFT_F64_LIST_SMALL(X) X(512, 1, F64_512_v1) X(512, 3, F64_512_v3) X(2, 0, F64_2) X(4, 0, F64_4) X(8, 0, F64_8) X(16, 0, F64_16) X(32, 0, F64_32) X(64, 0, F64_64) X(128, 0, F64_128) X(256, 0, F64_256) X(512, 0, F64_512) DFFT_F64_EXP_SMALL(X)
-#define DFFT_F64_LIST_1024(X) X(1024, 1, F64_1024_v1) X(1024, 3, F64_1024_v3) X(1024, 0, F64_1024) DFFT_F64_EXP_1024(X)
+#define DFFT_F64_LIST_1024(X) X(1024, 1, F64_1024_v1) X(1024, 2, F64_1024_v2) X(1024, 3, F64_1024_v3) X(1024, 0, F64_1024) DFFT_F64_EXP_1024(X)
 #define DFFT_F64_LIST_2048(X) X(2048, 1, F64_2048_v3) X(2048, 3, F64_2048_v3) X(2048, 7, F64_2048_v7) X(2048, 0, F64_2048) X(4096, 0, F64_4096) X(8192, 0, F64_8192) DFFT_F64_EXP_2048(X)
 
 // lengths with a packed real z pass / a Bluestein inner transform of their own configuration

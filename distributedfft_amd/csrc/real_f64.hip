@@ -8,7 +8,6 @@ bool rmixed_info_f64(int M);
 // butterflies in conjugate pairs (pair_j), which needs an even number of butterflies per thread in that pass: 16 points
 // per thread with radix 8 (512) or radix 4 (1024: last for R2C, first for C2R)
 using F64_R1024_c2r = PassCfg<double, 1024, 16, 8, 1, 4, 16, 16, 1, 1, 1>;
-using F64_R1024_c2r_nt = PassCfg<double, 1024, 16, 8, 1, 4, 16, 16, 1, 1, 1, 3>;
 // 2048 (Nz = 4096): the same in-register split / merge -- radix 8 last (R2C: 16.16.8) or first (C2R: 8.16.16) leaves two
 // butterflies per thread in that pass.  The forms that went through LDS (one-plane split, unpaired merge) spilled 36 / 324
 // bytes per lane at the 128-VGPR budget of a 1024-thread workgroup; these need 98 / 124 VGPRs and no scratch.
@@ -33,11 +32,9 @@ int launch_real_f64(int M, int mode, int variant, const PassArgs &A, hipStream_t
     }
     // Nz = 4096: 8 lines x 2048 points fill the LDS with one plane; split / merge in registers
     if (M == 2048 && A.load_kind != LOAD_KMAJOR) return mode == 1 ? launch_real_cfg<F64_2048, 1, 2>(A, stream) : launch_real_cfg<F64_R2048_c2r, 2, 2>(A, stream);
-    if (variant == 5 && A.load_kind != LOAD_KMAJOR) {      // A/B: nontemporal loads and stores (the streaming configurations)
-        if (M == 512) return mode == 1 ? launch_real_cfg<F64_512_v3, 1, 2>(A, stream) : launch_real_cfg<F64_512_v3, 2, 2>(A, stream);
-        if (M == 1024) return mode == 1 ? launch_real_cfg<F64_1024_v3, 1, 2>(A, stream) : launch_real_cfg<F64_R1024_c2r_nt, 2, 2>(A, stream);
-    }
-    if ((variant == 0 || variant == 5) && A.load_kind != LOAD_KMAJOR) {
+    // (nontemporal loads / stores were measured on these passes and lose at fp64: the R2C pass goes 3.30 -> 4.16 ms at 1024^3 -- its
+    // mirrored butterflies store tiles in 112 + 16 byte pieces that need L2 to merge them --, C2R unchanged; profiles/r3_real_pass_nontemporal.txt)
+    if (variant == 0 && A.load_kind != LOAD_KMAJOR) {
         if (M == 512) return mode == 1 ? launch_real_cfg<F64_512, 1, 2>(A, stream) : launch_real_cfg<F64_512, 2, 2>(A, stream);
         if (M == 1024) return mode == 1 ? launch_real_cfg<F64_1024, 1, 2>(A, stream) : launch_real_cfg<F64_R1024_c2r, 2, 2>(A, stream);
     }

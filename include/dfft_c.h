@@ -278,8 +278,10 @@ int dfft_free(void *ptr);
  * *out (dfft_domain_size bytes) and, if back != NULL, for a new buffer *back of the input block's size (the inverse
  * transform's output), one buffer at a time, and keeps for each the backing on which the plan's own FFT passes
  * (forward in -> out, inverse out -> back; exchanges not counted) run fastest.  `in` must hold a valid input block; it
- * is only read.  *out / *back are freed with dfft_free.  On a multi-rank plan the call is collective (it executes the
- * plan 3 * tries times).  report_ms (optional): the measured pass time of every trial in order, *n_report entries. */
+ * is only read.  Afterwards the y / x passes try their streaming (nontemporal) kernel configuration on the chosen buffers and
+ * keep it where it measures faster.  *out / *back are freed with dfft_free.  On a multi-rank plan the call is collective (it
+ * executes the plan about 3 * tries + 4 times).  report_ms (optional): the measured pass time of every trial in order, *n_report
+ * entries. */
 int dfft_tune_placement(dfft_plan *plan, const void *in, int tries, void **out, void **back, float *report_ms,
                         int max_report, int *n_report);
 

@@ -205,6 +205,12 @@ public:
     virtual void execR2C(void *out, const void *in) { if (plan_) timed(DFFT_FORWARD, [&] { return dfft_exec_r2c(plan_, out, in); }); }
     virtual void execC2R(void *out, const void *in) { if (plan_) timed(DFFT_INVERSE, [&] { return dfft_exec_c2r(plan_, out, const_cast<void *>(in)); }); }
     void execC2C(void *out, void *in, int direction) { if (plan_) timed(direction, [&] { return dfft_exec_c2c(plan_, out, in, direction); }); }
+    // extension (no counterpart in the reference): buffers on the physical backing this plan's passes run fastest on, see
+    // dfft_tune_placement in dfft_c.h; free them with dfft_free.  Collective on a multi-rank plan.
+    void tunePlacement(const void *in, int tries, void **out, void **back = nullptr)
+    {
+        if (plan_) check(dfft_tune_placement(plan_, in, tries, out, back, nullptr, 0, nullptr));
+    }
     // the section timer of the reference's classes (include/mpicufft_pencil.hpp:263-287, include/mpicufft_slab.hpp:208-222):
     // one block of the CSV per exec* once the warm-up rounds are used up
     Timer *getTimer() const { return timer; }

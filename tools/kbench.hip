@@ -308,7 +308,8 @@ template <typename R> static int run_plan(const Args &a)
     const size_t dom = dfft_domain_size(plan);
     if (sweeping) {      // one work area for every option set (grown if a set needs more)
         const size_t ws = dfft_work_size_device(plan);
-        if (ws > work_cap) { if (work) HIPCHK(hipFree(work)); HIPCHK(hipMalloc(&work, ws)); work_cap = ws; }
+        // --tune: the shared work area comes from the virtual-memory API as well (64 MiB chunks: what the tuner picks most often)
+        if (ws > work_cap) { if (work) DCHK(dfft_free(work)); DCHK(dfft_malloc(ws, a.tune > 1 ? 64 : 0, (void **)&work)); work_cap = ws; }
         DCHK(dfft_set_work_area(plan, work, nullptr));
     }
     if (si > 0) {
@@ -439,7 +440,7 @@ template <typename R> static int run_plan(const Args &a)
     printf("  total passes %.3f ms\n", tot);
     DCHK(dfft_plan_destroy(plan));
   }
-    if (work) HIPCHK(hipFree(work));
+    if (work) DCHK(dfft_free(work));
     if (a.slab) HIPCHK(hipFree(slab));
     else if (a.vmm_mib) { /* process exit unmaps */ }
     else if (a.tune > 1) { HIPCHK(hipFree(in)); DCHK(dfft_free(out)); DCHK(dfft_free(back)); }

@@ -1,18 +1,34 @@
 #!/bin/bash
 # tools/round_check.sh [TAG] -- the standard measurement set of a round in ONE gpurun call:
-#   gpurun --timeout 1500 -- 'bash tools/round_check.sh r2'
+#   gpurun --timeout 1800 -- 'bash tools/round_check.sh r3'
 # GPU parity suite, the bench line (1024^3 fp64) and its rocprofv3 kernel stats, the 2048^3 fp32 bench line and
 # stats, per-pass times of every configuration DESIGN.md quotes (kbench, C ABI, no Python), PMC counters of the
 # headline kernels.  Everything lands in gpurun_out/round_check/; copy what DESIGN.md cites into profiles/.
-TAG=${1:-r2}
+TAG=${1:-r3}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/round_check
 mkdir -p $OUT
 cd $R
 K=$R/tools/kbench
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.txt 2>&1; tail -2 $OUT/pytest_gpu.txt
+timeout 1200 python -m pytest tests -x -q -m gpu --durations=10 > $OUT/pytest_gpu.txt 2>&1; tail -14 $OUT/pytest_gpu.txt
 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 300 $OUT/bench.json; echo
+# five more bench lines from fresh processes (placement tuner on, its default) and two with plain allocations
+for i in 1 2 3 4 5; do python bench.py --no-cpu-baseline --no-multi-rank-path > $OUT/bench_fresh_$i.json 2>> $OUT/bench.err; done
+for i in 1 2; do python bench.py --no-cpu-baseline --no-multi-rank-path --tune-placement 0 > $OUT/bench_plain_$i.json 2>> $OUT/bench.err; done
+python - <<P > $OUT/${TAG}_placement.txt
+import json
+print("bench.py from fresh processes, 1024^3 fp64 complex forward+inverse, 10 warm-up + 20 timed steps (ms per step, roofline.frac, per-pass ms)")
+for name in ["bench"] + [f"bench_fresh_{i}" for i in range(1, 6)] + ["bench_plain_1", "bench_plain_2"]:
+    try:
+        d = json.loads(open("$OUT/" + name + ".json").read().strip().splitlines()[-1])
+    except Exception as e:
+        print(name, "FAILED", e); continue
+    pl = d["config"].get("placement")
+    print(f"{name:14s} {'tuned placement' if pl else 'plain hipMalloc / torch buffers'}: {d['ms_per_step']:.3f} ms  frac {d['roofline']['frac']:.4f}  ",
+          {k: v["ms"] for k, v in d["config"]["per_pass"].items() if "FFT" in k}, "trials", (pl or {}).get("trial_fft_ms_fwd_plus_inv"))
+P
+cat $OUT/${TAG}_placement.txt
 prof() {  # name, command...: rocprofv3 kernel trace + stats of a command, stats csv copied next to the logs
   local name=$1; shift
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o $name -- "$@" > $OUT/prof_$name.log 2>&1 )
@@ -35,12 +51,17 @@ prof f64_mixed1000 $K --size 1000 --prec f64 --iters 3
 prof f64_mixed1000_r2c $K --size 1000 --prec f64 --mode r2c --iters 3
 {
   echo "== c2c fp64 1024";                 $K --size 1024 --prec f64 --iters 5 --check
+  echo "== c2c fp64 1024, tuned placement"; $K --size 1024 --prec f64 --iters 5 --check --tune 4
+  echo "== c2c fp64 1024 pattern roofs, tuned placement"; $K --size 1024 --prec f64 --iters 5 --opt debug_skip=1 --tune 4
   echo "== c2c fp64 1024 multi-rank path"; $K --size 1024 --prec f64 --iters 5 --check --opt mirror_inverse=1 --opt pipeline_chunks=8
   echo "== c2c fp64 1024 pattern roofs";   $K --size 1024 --prec f64 --iters 5 --opt debug_skip=1
   echo "== c2c fp32 1024";                 $K --size 1024 --prec f32 --iters 5 --check
   echo "== c2c fp32 1024 multi-rank path"; $K --size 1024 --prec f32 --iters 5 --check --opt mirror_inverse=1 --opt pipeline_chunks=8
   echo "== r2c fp64 1024";                 $K --size 1024 --prec f64 --mode r2c --iters 5 --check
+  echo "== r2c fp64 1024, tuned placement"; $K --size 1024 --prec f64 --mode r2c --iters 10 --check --tune 4
   echo "== r2c fp32 1024";                 $K --size 1024 --prec f32 --mode r2c --iters 5 --check
+  echo "== r2c fp32 1024, tuned placement"; $K --size 1024 --prec f32 --mode r2c --iters 10 --check --tune 4
+  echo "== c2c fp32 1024, tuned placement"; $K --size 1024 --prec f32 --iters 10 --check --tune 4
   echo "== c2c fp32 2048";                 $K --size 2048 --prec f32 --iters 3 --check
   echo "== c2c fp32 2048 pattern roofs";   $K --size 2048 --prec f32 --iters 3 --opt debug_skip=1
   echo "== c2c fp32 2048 multi-rank path"; $K --size 2048 --prec f32 --iters 3 --opt mirror_inverse=1 --opt pipeline_chunks=8
@@ -71,3 +92,4 @@ cat $OUT/${TAG}_pmc_traffic.json
 bash tools/pmc_traffic.sh ${TAG}_f64_1000 -- $K --size 1000 --prec f64 --iters 2 > /dev/null 2>&1
 python tools/pmc_traffic.py $R/gpurun_out/pmct_${TAG}_f64_1000 32000000000 "1000^3 fp64 complex (mixed radix), one axis pass per launch" > $OUT/${TAG}_pmc_traffic_mixed1000.json 2>&1
 cat $OUT/${TAG}_pmc_traffic_mixed1000.json
+rm -rf $R/gpurun_out/pmcq_* $R/gpurun_out/pmct_* 2>/dev/null; du -sh $R/gpurun_out 2>/dev/null
