@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--tune-placement", type=int, default=-1,
                     help="physical backings tried per buffer (work area, out, back) before the warm-up: dfft_tune_placement keeps the one "
                          "the plan's own passes run fastest on.  -1 = 4 on one GPU, off otherwise; 0 / 1 = plain allocations")
+    ap.add_argument("--no-tune-variants", action="store_true",
+                    help="skip dfft_tune_variants (the y / x passes try the streaming sibling of their kernel configuration on the run's own "
+                         "buffers before the warm-up; already part of the placement tuner where that runs)")
     ap.add_argument("--dry-run", action="store_true", help="plan C4 / C5 for all 8 ranks without a GPU and print the memory budget")
     return ap.parse_args()
 
@@ -315,6 +318,18 @@ def main():
     if comm is not None and transport == "torch":
         comm.register(d_out)
     torch.cuda.synchronize()
+    variants = None
+    if placement is None and not args.no_tune_variants:
+        # no placement tuner in this run (N > 1, or a grid that leaves no room for candidates): the kernel-configuration half of it
+        # on the buffers as they are.  Collective at N > 1 (it executes the plan); every rank decides for its own kernels.
+        try:
+            with torch.cuda.stream(side):
+                trial_ms = plan.tuneVariants(d_in, d_out, None if aliased else d_back)
+            variants = {"trial_fft_ms": [round(v, 3) for v in trial_ms],
+                        "what": "dfft_tune_variants before the warm-up: first entry = the plan's rule-based kernel configurations, then one entry per "
+                                "y / x pass that has a streaming (nontemporal) sibling; a sibling is kept when the pass time drops by more than 0.3 %"}
+        except Exception as e:   # noqa: BLE001
+            variants = {"error": str(e)}
 
     def barrier():
         if dist is not None:
@@ -561,7 +576,7 @@ def main():
                        "rccl_nranks": rccl_nranks, "world_size": world, "devices_visible": ndev,
                        "ranks_per_device": max(1, -(-world // ndev)),
                        "per_pass": per_pass(phases, args.steps),
-                       "input_aliased_with_inverse_output": bool(aliased), "placement": placement},
+                       "input_aliased_with_inverse_output": bool(aliased), "placement": placement, "variants": variants},
             "round_trip_rel_linf": rt_err,
             "roofline": roofline,
         }

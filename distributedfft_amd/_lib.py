@@ -82,6 +82,7 @@ SYMBOLS = [
     ("dfft_kernel_info", _i, [_i, _sz, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     ("dfft_malloc", _i, [_sz, _sz, C.POINTER(_vp)]),
     ("dfft_free", _i, [_vp]),
+    ("dfft_tune_variants", _i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     ("dfft_tune_placement", _i, [_vp, _vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_float), _i, C.POINTER(_i)]),
 ]
 

@@ -257,6 +257,14 @@ class MPIcuFFT:
         back = DeviceBuffer(b.value, in_bytes) if want_back else None
         return out, back, [float(rep[i]) for i in range(n.value)]
 
+    def tuneVariants(self, in_, out, back=None):
+        """dfft_tune_variants: the y / x passes try the streaming sibling of their kernel configuration on these buffers and
+        keep it where the plan's own passes get faster.  Returns the measured FFT ms (forward + inverse) of every trial."""
+        rep = (C.c_float * 8)()
+        n = C.c_int(0)
+        check(lib().dfft_tune_variants(self._h, _ptr(in_), _ptr(out), _ptr(back), rep, len(rep), C.byref(n)))
+        return [float(rep[i]) for i in range(n.value)]
+
     def setPipelineChunks(self, chunks):
         """pipeline depth of the exchanges (before initFFT); 1 = no overlap, 0 = default"""
         check(lib().dfft_set_pipeline_chunks(self._h, int(chunks)))

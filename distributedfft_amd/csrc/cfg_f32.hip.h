@@ -40,26 +40,29 @@ using F32_8192 = PassCfg<float, 8192, 32, 16, 1, 32, 16, 16, 1, 1, 1, 0, 0, 8>;
 // whole-tile 64-point forms, 32-point fp64 2048, ...) were removed after they were measured: results in profiles/r2_*.txt and
 // DESIGN.md section 6, definitions in the git history (commit c38cf04).  New ones go here, under -DDFFT_EXPERIMENTS:
 
-// persistent, software-pipelined forms (PassCfg::PERSIST) under test
-using F32_2048_v8 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 0, 1, 1>;
-using F32_2048_v9 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3, 0, 1, 1>;
-// tiled 2048-point passes under test: radix 32 first (two butterflies per thread: the second one's loads are still in flight
-// while the first is computed; with radix 64 first a thread waits for all of its 64 loads), and the streaming form of 64.32
+//   9 = tiled passes, streaming: variant 6 with nontemporal loads and stores.  Whether the hints pay depends on the pass, the
+//       layout and the buffers (2048 points, rank 0 of the 2 x 4 plan at 2048^3: y 4.86 -> 3.73 ms, x^-1 5.75 -> 4.68, but x
+//       3.92 -> 4.27 and y^-1 5.6 -> 9.2; one GPU: the middle pass 9.6 -> 8.5 ms, the last one 6.78 -> 6.85;
+//       profiles/r3_f32_2048_tiled_variants.txt), so no plan picks it by rule: dfft_tune_variants tries it per pass and keeps it
+//       where that plan's own pass runs faster.  (Radix 32 first instead of 64 first made no difference at 2048 points.)
+using F32_512_v9 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1, 3>;
+using F32_1024_v9 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 3>;
+using F32_2048_v9 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3>;
+// persistent, software-pipelined forms (PassCfg::PERSIST): measured and rejected (profiles/r3_strided_read_variants.txt), A/B builds only
+using F32_2048_v13 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 0, 1, 1>;
 using F32_2048_v10 = PassCfg<float, 2048, 64, 16, 1, 32, 64, 1, 1, 1, 1>;
-using F32_2048_v11 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3>;
-using F32_2048_v12 = PassCfg<float, 2048, 64, 16, 1, 32, 64, 1, 1, 1, 1, 3>;
 #ifdef DFFT_EXPERIMENTS
 #define DFFT_F32_EXP_SMALL(X)
 #define DFFT_F32_EXP_1024(X)
-#define DFFT_F32_EXP_2048(X) X(2048, 8, F32_2048_v8) X(2048, 9, F32_2048_v9) X(2048, 10, F32_2048_v10) X(2048, 11, F32_2048_v11) X(2048, 12, F32_2048_v12)
+#define DFFT_F32_EXP_2048(X) X(2048, 13, F32_2048_v13) X(2048, 10, F32_2048_v10)
 #else
 #define DFFT_F32_EXP_SMALL(X)
 #define DFFT_F32_EXP_1024(X)
 #define DFFT_F32_EXP_2048(X)
 #endif
-#define DFFT_F32_LIST_SMALL(X) X(512, 6, F32_512_v6) X(512, 4, F32_512_v4) X(512, 5, F32_512_v5) X(2, 0, F32_2) X(4, 0, F32_4) X(8, 0, F32_8) X(16, 0, F32_16) X(32, 0, F32_32) X(64, 0, F32_64) X(128, 0, F32_128) X(256, 0, F32_256) X(512, 0, F32_512) DFFT_F32_EXP_SMALL(X)
-#define DFFT_F32_LIST_1024(X) X(1024, 4, F32_1024_v4) X(1024, 5, F32_1024_v5) X(1024, 6, F32_1024_v6) X(1024, 0, F32_1024) DFFT_F32_EXP_1024(X)
-#define DFFT_F32_LIST_2048(X) X(2048, 4, F32_2048_v4) X(2048, 5, F32_2048_v5) X(2048, 6, F32_2048_v6) X(2048, 0, F32_2048) X(4096, 0, F32_4096) X(8192, 0, F32_8192) DFFT_F32_EXP_2048(X)
+#define DFFT_F32_LIST_SMALL(X) X(512, 6, F32_512_v6) X(512, 9, F32_512_v9) X(512, 4, F32_512_v4) X(512, 5, F32_512_v5) X(2, 0, F32_2) X(4, 0, F32_4) X(8, 0, F32_8) X(16, 0, F32_16) X(32, 0, F32_32) X(64, 0, F32_64) X(128, 0, F32_128) X(256, 0, F32_256) X(512, 0, F32_512) DFFT_F32_EXP_SMALL(X)
+#define DFFT_F32_LIST_1024(X) X(1024, 4, F32_1024_v4) X(1024, 5, F32_1024_v5) X(1024, 6, F32_1024_v6) X(1024, 9, F32_1024_v9) X(1024, 0, F32_1024) DFFT_F32_EXP_1024(X)
+#define DFFT_F32_LIST_2048(X) X(2048, 4, F32_2048_v4) X(2048, 5, F32_2048_v5) X(2048, 6, F32_2048_v6) X(2048, 9, F32_2048_v9) X(2048, 0, F32_2048) X(4096, 0, F32_4096) X(8192, 0, F32_8192) DFFT_F32_EXP_2048(X)
 
 // lengths with a packed real z pass / a Bluestein inner transform of their own configuration
 // real-transform z passes (variant 0 configurations only); M = Nz/2

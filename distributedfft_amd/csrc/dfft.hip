@@ -18,6 +18,7 @@
 #include <string.h>
 #include <algorithm>
 #include <complex>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -1589,8 +1590,12 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         auto has32 = [&](const Axis &a, int role) { return !a.bluestein && pass_info_f32((int)a.N, role, &vi); };
         for (int k = 0; k < 3; k++) p->vfwd[k] = p->vinv[k] = ROLE_DEFAULT;
         if (p->prec == DFFT_F64) {
-            // the multi-rank inverse x pass reads the point-major API layout
-            if (has64(p->ax[2], ROLE_STRIDED_READ)) p->vinv[2] = ROLE_STRIDED_READ;
+            // the multi-rank inverse x pass reads the point-major API layout: 16 lines x 32 points (256-byte runs) -- where the rows
+            // are whole tiles.  On the 513-wide rows of an R2C plan the 256-byte runs straddle three cache lines and the one
+            // workgroup per CU re-reads 17 % of them (profiles/r3_pmc_traffic_f64_r2c.json): the default configuration (8 lines,
+            // two workgroups per CU) is 15 % faster there, 3.66 vs 4.26 ms at 1024^3 (profiles/r3_strided_read_odd_pitch.txt)
+            const size_t zs_local = p->zs.empty() ? p->Nzc : p->zs[p->zyx ? (size_t)p->rank % p->zs.size() : (size_t)p->pj % p->zs.size()];
+            if (has64(p->ax[2], ROLE_STRIDED_READ) && zs_local % (size_t)p->TL == 0) p->vinv[2] = ROLE_STRIDED_READ;
             // complex z passes have natural lines on one side and long-run stores
             const int zrole = has64(p->ax[0], ROLE_LINES) ? ROLE_LINES : has64(p->ax[0], ROLE_STREAM) ? ROLE_STREAM : ROLE_DEFAULT;
             if (p->c2c) p->vfwd[0] = p->vinv[0] = zrole;
@@ -2099,8 +2104,52 @@ static int placement_measure(dfft_plan *p, const void *in, void *out, void *back
     return 0;
 }
 
+// The y / x passes of a plan on given buffers: the streaming (nontemporal) sibling of their kernel configuration where one
+// exists and measures faster HERE.  Whether the hints pay depends on the pass, the layout and the physical backing of the
+// buffers: on plain hipMalloc buffers they gained nothing repeatable on the 128-byte-run stores of 1024^3 fp64 (round 2), on
+// tuned backings the x pass goes 5.66 -> 5.44 ms (profiles/r3_yx_variants_on_tuned_buffers.txt); at fp32 2048 points they take
+// a quarter off two passes of the 8-GPU plan and double another (profiles/r3_f32_2048_tiled_variants.txt).
+static int stream_sibling(int role) { return role == ROLE_DEFAULT ? ROLE_STREAM : role == ROLE_TILED ? ROLE_TILED_STREAM : -1; }
+static int tune_variants(dfft_plan *p, const void *in, void *o, void *b, float &best, const std::function<void(float)> &note)
+{
+    for (int k = 0; k < 4; k++) {
+        const int axis = 1 + (k & 1);                    // y, x of the forward chain, then of the inverse chain
+        int *slot = k < 2 ? &p->vfwd[axis] : &p->vinv[axis];
+        if (k >= 2 && (!b || (p->nranks == 1 && !p->opt.mirror && p->c2c))) continue;      // a single rank's complex inverse runs the forward chain
+        const int sib = stream_sibling(*slot);
+        if (sib < 0 || p->opt.variant[k < 2 ? axis : 5 - axis] >= 0 || p->ax[axis].bluestein) continue;
+        PassInfo pi;
+        if (!(p->prec == DFFT_F64 ? pass_info_f64((int)p->ax[axis].N, sib, &pi) : pass_info_f32((int)p->ax[axis].N, sib, &pi))) continue;
+        const int old = *slot;
+        *slot = sib;
+        float ms = 0;
+        TRY(placement_measure(p, in, o, b, 2, &ms));
+        note(ms);
+        if (ms < 0.997f * best) best = ms; else *slot = old;
+    }
+    return 0;
+}
+
 // physical chunk sizes (MiB) tried in turn; 0 = plain hipMalloc
 static const size_t kPlacementRecipes[] = {0, 64, 1024, 2, 256, 16, 512, 128};
+
+int dfft_tune_variants(dfft_plan *p, const void *in, void *out, void *back, float *report_ms, int max_report, int *n_report)
+{
+    TRY(check_ready(p));
+    if (!in || !out) return fail(ERR_ARG, "null buffer");
+    const bool was_timing = p->timing;
+    TRY(dfft_enable_phase_timing(p, 1));
+    int nrep = 0;
+    auto note = [&](float v) { if (report_ms && nrep < max_report) report_ms[nrep] = v; nrep++; };
+    float best = 0;
+    int rc = placement_measure(p, in, out, back, 2, &best);
+    note(best);
+    if (rc == 0) rc = tune_variants(p, in, out, back, best, note);
+    p->timing = was_timing;
+    graphs_clear(p);
+    if (n_report) *n_report = nrep < max_report ? nrep : max_report;
+    return rc;
+}
 
 int dfft_tune_placement(dfft_plan *p, const void *in, int tries, void **out, void **back, float *report_ms, int max_report, int *n_report)
 {
@@ -2158,22 +2207,7 @@ int dfft_tune_placement(dfft_plan *p, const void *in, int tries, void **out, voi
         }
         if (which == 1) o = keep; else if (which == 2) b = keep;
     }
-    // The y / x passes on these buffers: the streaming (nontemporal) configuration where one exists and measures faster HERE.  On
-    // plain hipMalloc buffers the hints gained nothing repeatable on the 128-byte-run stores; on the backings
-    // chosen above the x pass of 1024^3 fp64 goes 5.66 -> 5.44 ms (profiles/r3_yx_variants_on_tuned_buffers.txt).
-    for (int k = 0; k < 4 && rc == 0; k++) {
-        const int axis = 1 + (k & 1);                    // y, x of the forward chain, then of the inverse chain
-        int *slot = k < 2 ? &p->vfwd[axis] : &p->vinv[axis];
-        if (k >= 2 && p->nranks == 1 && !p->opt.mirror && p->c2c) continue;      // a single rank's complex inverse runs the forward chain
-        if (p->opt.variant[k < 2 ? axis : 5 - axis] >= 0 || *slot != ROLE_DEFAULT || p->ax[axis].bluestein) continue;
-        PassInfo pi;
-        if (!(p->prec == DFFT_F64 ? pass_info_f64((int)p->ax[axis].N, ROLE_STREAM, &pi) : pass_info_f32((int)p->ax[axis].N, ROLE_STREAM, &pi))) continue;
-        *slot = ROLE_STREAM;
-        float ms = 0;
-        rc = placement_measure(p, in, o, b, 2, &ms);
-        note(ms);
-        if (rc == 0 && ms < 0.997f * best) best = ms; else *slot = ROLE_DEFAULT;
-    }
+    if (rc == 0) rc = tune_variants(p, in, o, b, best, note);
     p->timing = was_timing;
     graphs_clear(p);
     if (rc != 0) { (void)dev_free(o); (void)dev_free(b); return rc; }

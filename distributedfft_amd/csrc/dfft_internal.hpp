@@ -20,7 +20,8 @@ enum PassRole {
     ROLE_NATURAL_LOAD = 4,     // fp32: natural lines in (point-fastest mapping in every pass)
     ROLE_NATURAL_STORE = 5,    // fp32: natural lines out (point-fastest mapping after the first pass)
     ROLE_TILED = 6,            // fp32: tiled on both sides (two radix passes, one exchange)
-    ROLE_LINES = 7             // fp64: natural lines on one side where that differs from ROLE_STREAM (2048: sub-tiles)
+    ROLE_LINES = 7,            // fp64: natural lines on one side where that differs from ROLE_STREAM (2048: sub-tiles)
+    ROLE_TILED_STREAM = 9      // fp32: ROLE_TILED with nontemporal loads and stores (chosen by measurement only: dfft_tune_variants)
 };
 
 // tile size (lines interleaved in the intermediate layouts) per precision: 128 B per run

@@ -284,6 +284,12 @@ int dfft_free(void *ptr);
  * entries. */
 int dfft_tune_placement(dfft_plan *plan, const void *in, int tries, void **out, void **back, float *report_ms,
                         int max_report, int *n_report);
+/* The second half of dfft_tune_placement on the caller's own buffers (no allocation): every y / x pass whose kernel
+ * configuration has a streaming (nontemporal) sibling tries it -- forward in -> out and, if back != NULL, inverse
+ * out -> back, which destroys `out` like every inverse -- and keeps it where the plan's FFT passes get faster by more than
+ * 0.3 %.  Executes the plan 1 + (passes with a sibling) times; collective on a multi-rank plan, where every rank decides for
+ * its own kernels.  report_ms as above. */
+int dfft_tune_variants(dfft_plan *plan, const void *in, void *out, void *back, float *report_ms, int max_report, int *n_report);
 
 #ifdef __cplusplus
 }

@@ -82,3 +82,30 @@ def test_tune_placement_keeps_a_callers_work_area():
     want = torch.fft.fftn(d_in)
     got = out.tensor(torch.complex128)[:d_in.numel()].reshape(shape)
     assert float((got - want).abs().max() / want.abs().max()) < 1e-12
+
+
+@pytest.mark.parametrize("prec", ["double", "float"])
+def test_tune_variants_keeps_the_transform_exact(prec):
+    """dfft_tune_variants on the caller's buffers: the y / x passes (512 and 1024 points: both have a streaming sibling) try it, whatever
+    they keep the plan still computes the oracle's transform; forced siblings (variant 3 / 9) too"""
+    shape = (1024, 512, 16)
+    g = orc.fill_block(shape, (0, 0, 0), shape, 2, seed=3)
+    want = orc.fft3d_c2c(g, -1)
+    sib = 3 if prec == "double" else 9
+    for forced in (False, True):
+        plan = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), precision=prec)
+        if forced:
+            for key in ("variant_fy", "variant_fx"):
+                plan.setOption(key, sib)
+        plan.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(1, 1), True, c2c=True)
+        d_in = torch.from_numpy(g).to("cuda").to(CDT[prec]).contiguous()
+        d_out = torch.empty(plan.getDomainSize() // d_in.element_size(), dtype=CDT[prec], device="cuda")
+        d_back = torch.empty_like(d_in)
+        trials = plan.tuneVariants(d_in, d_out, d_back)
+        # baseline + one trial per pass with a sibling that the caller has not pinned (a single rank's inverse runs the forward chain)
+        assert len(trials) == (1 if forced else 3) and all(t > 0 for t in trials)
+        plan.execC2C(d_out, d_in, dfft.FORWARD)
+        got = d_out[:g.size].cpu().numpy().reshape(shape)
+        assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < TOL_FWD[prec]
+        plan.execC2C(d_back, d_out, dfft.INVERSE)
+        assert rel(d_back.cpu().numpy().reshape(shape) / g.size, g) < TOL_RT[prec]

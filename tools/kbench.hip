@@ -134,6 +134,8 @@ struct Args {
     std::vector<std::vector<std::pair<std::string, long>>> sweep;
     // --tune K: out / back / the work area come from dfft_tune_placement with K physical backings per buffer
     int tune = 0;
+    // --tune-variants: dfft_tune_variants on the run's buffers before the timed iterations
+    int tune_variants = 0;
 };
 
 static int dry_exchange(void *, const void *, const size_t *, const size_t *, void *, const size_t *, const size_t *, const int *, int, int, void *)
@@ -199,6 +201,7 @@ static Args parse(int argc, char **argv)
         else if (k == "--ranks") { if (sscanf(next(), "%dx%d", &a.P1, &a.P2) != 2) { fprintf(stderr, "--ranks P1xP2\n"); exit(1); } }
         else if (k == "--rank") a.rank = atoi(next());
         else if (k == "--tune") a.tune = atoi(next());
+        else if (k == "--tune-variants") a.tune_variants = 1;
         else if (k == "--sweep") {
             std::string all = next();
             size_t pos = 0;
@@ -364,6 +367,15 @@ template <typename R> static int run_plan(const Args &a)
     }
     fill_random<R><<<nblk, 256>>>((R *)in, nreal);
     HIPCHK(hipDeviceSynchronize());
+    if (a.tune_variants) {
+        float rep[8];
+        int nrep = 0;
+        DCHK(dfft_tune_variants(plan, in, out, alias_back ? nullptr : back, rep, 8, &nrep));
+        printf("TUNE-VARIANTS FFT ms per trial (first = rule-based configurations):");
+        for (int i = 0; i < nrep; i++) printf(" %.3f", rep[i]);
+        printf("\n");
+        if (alias_back) { fill_random<R><<<nblk, 256>>>((R *)in, nreal); HIPCHK(hipDeviceSynchronize()); }
+    }
     fwd(); inv();                                   // warm-up
     if (a.check && !dbg) {
         check_random<R><<<nblk, 256>>>((const R *)back, nreal, 1.0 / (double)n, part);
