@@ -48,12 +48,15 @@ using F32_8192 = PassCfg<float, 8192, 32, 16, 1, 32, 16, 16, 1, 1, 1, 0, 0, 8>;
 using F32_512_v9 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1, 3>;
 using F32_1024_v9 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 3>;
 using F32_2048_v9 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3>;
+// A/B only, measured and rejected (profiles/r3_f32_inverse_y_point_fastest_store.txt): tiled load + point-fastest store mapping for the
+// inverse y pass (transposed-tile stores in whole lines instead of 32-byte pieces): 4.42 vs 4.30 ms at 1024 points, 10.55 vs 10.35 at 2048
+using F32_1024_v10 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 2>;
+using F32_2048_v10 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 2>;
 // persistent, software-pipelined forms (PassCfg::PERSIST): measured and rejected (profiles/r3_strided_read_variants.txt), A/B builds only
 using F32_2048_v13 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 0, 1, 1>;
-using F32_2048_v10 = PassCfg<float, 2048, 64, 16, 1, 32, 64, 1, 1, 1, 1>;
 #ifdef DFFT_EXPERIMENTS
 #define DFFT_F32_EXP_SMALL(X)
-#define DFFT_F32_EXP_1024(X)
+#define DFFT_F32_EXP_1024(X) X(1024, 10, F32_1024_v10)
 #define DFFT_F32_EXP_2048(X) X(2048, 13, F32_2048_v13) X(2048, 10, F32_2048_v10)
 #else
 #define DFFT_F32_EXP_SMALL(X)

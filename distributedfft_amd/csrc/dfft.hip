@@ -1606,6 +1606,9 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
             if (p->c2c && has32(p->ax[0], ROLE_NATURAL_STORE)) p->vinv[0] = ROLE_NATURAL_STORE;
             for (int ax = 1; ax <= 2; ax++)
                 if (has32(p->ax[ax], ROLE_TILED)) p->vfwd[ax] = p->vinv[ax] = ROLE_TILED;
+            // (The inverse y pass stores transposed tiles, which a line-fastest fp32 wave -- 16 lines x 4 points -- writes in 32-byte
+            // pieces.  A point-fastest store mapping, PassCfg::MAP = 2, writes whole lines and was measured: 1024 points 4.42 vs 4.30 ms,
+            // 2048 points 10.55 vs 10.35, no better -- L2 merges the pieces; profiles/r3_f32_inverse_y_point_fastest_store.txt.)
         }
     }
     {   // per-pass overrides (dfft_set_option): fz fy fx ix iy iz
@@ -2112,20 +2115,26 @@ static int placement_measure(dfft_plan *p, const void *in, void *out, void *back
 static int stream_sibling(int role) { return role == ROLE_DEFAULT ? ROLE_STREAM : role == ROLE_TILED ? ROLE_TILED_STREAM : -1; }
 static int tune_variants(dfft_plan *p, const void *in, void *o, void *b, float &best, const std::function<void(float)> &note)
 {
+    auto exists = [&](int axis, int role) {
+        PassInfo pi;
+        return role >= 0 && (p->prec == DFFT_F64 ? pass_info_f64((int)p->ax[axis].N, role, &pi) : pass_info_f32((int)p->ax[axis].N, role, &pi));
+    };
     for (int k = 0; k < 4; k++) {
         const int axis = 1 + (k & 1);                    // y, x of the forward chain, then of the inverse chain
         int *slot = k < 2 ? &p->vfwd[axis] : &p->vinv[axis];
+        // Which trials run must not depend on the rank: every trial executes the plan, exchanges included.  A rank whose own role
+        // for the pass has no sibling (the strided-read role is chosen per rank: it depends on the local z extent) runs the trial
+        // with its configuration unchanged.
         if (k >= 2 && (!b || (p->nranks == 1 && !p->opt.mirror && p->c2c))) continue;      // a single rank's complex inverse runs the forward chain
-        const int sib = stream_sibling(*slot);
-        if (sib < 0 || p->opt.variant[k < 2 ? axis : 5 - axis] >= 0 || p->ax[axis].bluestein) continue;
-        PassInfo pi;
-        if (!(p->prec == DFFT_F64 ? pass_info_f64((int)p->ax[axis].N, sib, &pi) : pass_info_f32((int)p->ax[axis].N, sib, &pi))) continue;
-        const int old = *slot;
-        *slot = sib;
+        if (p->opt.variant[k < 2 ? axis : 5 - axis] >= 0 || p->ax[axis].bluestein) continue;
+        if (!exists(axis, ROLE_STREAM) && !exists(axis, ROLE_TILED_STREAM)) continue;
+        const int old = *slot, sib = stream_sibling(old);
+        const bool mine = exists(axis, sib);
+        if (mine) *slot = sib;
         float ms = 0;
         TRY(placement_measure(p, in, o, b, 2, &ms));
         note(ms);
-        if (ms < 0.997f * best) best = ms; else *slot = old;
+        if (mine && ms < 0.997f * best) best = ms; else *slot = old;
     }
     return 0;
 }

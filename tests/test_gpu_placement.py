@@ -109,3 +109,39 @@ def test_tune_variants_keeps_the_transform_exact(prec):
         assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < TOL_FWD[prec]
         plan.execC2C(d_back, d_out, dfft.INVERSE)
         assert rel(d_back.cpu().numpy().reshape(shape) / g.size, g) < TOL_RT[prec]
+
+
+def test_tune_variants_is_collective_with_rank_dependent_roles():
+    """R2C grid on 2 x 2 virtual ranks: the 513 kz planes split 257 + 256, so the strided-read role of the inverse x pass differs from rank
+    to rank; every rank must still run the same number of trials (each trial executes the plan, exchanges included) and the transform must
+    stay the oracle's"""
+    from concurrent.futures import ThreadPoolExecutor
+    shape, P1, P2 = (1024, 512, 1024), 2, 2
+    g = orc.fill_block(shape, (0, 0, 0), shape, 1, seed=9)
+    want = orc.fft3d_r2c(g)
+    world = dfft.Comm.local(P1 * P2)
+    plans, ins, outs, backs = [], [], [], []
+    for r in range(P1 * P2):
+        pl = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), world, precision="double", rank=r)
+        pl.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(P1, P2), True, c2c=False)
+        size, start = pl.getInSize(), pl.getInStart()
+        blk = g[start[0]:start[0] + size[0], start[1]:start[1] + size[1], :].copy()
+        plans.append(pl)
+        ins.append(torch.from_numpy(blk).cuda())
+        outs.append(torch.zeros(pl.getDomainSize() // 16, dtype=torch.complex128, device="cuda"))
+        backs.append(torch.zeros_like(ins[-1]))
+    torch.cuda.synchronize()
+    with ThreadPoolExecutor(P1 * P2) as ex:
+        trials = list(ex.map(lambda r: plans[r].tuneVariants(ins[r], outs[r], backs[r]), range(P1 * P2)))
+    assert len({len(t) for t in trials}) == 1 and len(trials[0]) == 5      # baseline + y, x forward + y, x inverse on every rank
+    with ThreadPoolExecutor(P1 * P2) as ex:
+        list(ex.map(lambda r: plans[r].execR2C(outs[r], ins[r]), range(P1 * P2)))
+    scale = np.max(np.abs(want))
+    for r, pl in enumerate(plans):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        got = outs[r][:s[0] * s[1] * s[2]].cpu().numpy().reshape(s)
+        assert np.max(np.abs(got - want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]])) / scale < TOL_FWD["double"]
+    with ThreadPoolExecutor(P1 * P2) as ex:
+        list(ex.map(lambda r: plans[r].execC2R(backs[r], outs[r]), range(P1 * P2)))
+    for r in range(P1 * P2):
+        assert rel(backs[r].cpu().numpy() / float(np.prod(shape)), ins[r].cpu().numpy()) < TOL_RT["double"]
