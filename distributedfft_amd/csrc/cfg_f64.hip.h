@@ -63,9 +63,12 @@ using F64_1024_v11 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 0, 0, 1
 using F64_1024_v12 = PassCfg<double, 1024, 32, 8, 1, 32, 32, 1, 1, 1, 1, 3>;
 using F64_1024_v13 = PassCfg<double, 1024, 32, 8, 1, 32, 32, 1, 1, 1, 1, 0>;
 using F64_2048_v12 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 3, 0, 2>;
+// strided read with 16 lines on 1024 threads (16 points per thread, four waves per SIMD instead of two)
+using F64_1024_v14 = PassCfg<double, 1024, 16, 8, 2, 16, 16, 4, 1, 1, 1, 3>;
+using F64_1024_v15 = PassCfg<double, 1024, 16, 8, 2, 16, 16, 4, 1, 1, 1, 0>;
 #ifdef DFFT_EXPERIMENTS
 #define DFFT_F64_EXP_SMALL(X)
-#define DFFT_F64_EXP_1024(X) X(1024, 8, F64_1024_v8) X(1024, 9, F64_1024_v9) X(1024, 10, F64_1024_v10) X(1024, 11, F64_1024_v11) X(1024, 12, F64_1024_v12) X(1024, 13, F64_1024_v13)
+#define DFFT_F64_EXP_1024(X) X(1024, 8, F64_1024_v8) X(1024, 9, F64_1024_v9) X(1024, 10, F64_1024_v10) X(1024, 11, F64_1024_v11) X(1024, 12, F64_1024_v12) X(1024, 13, F64_1024_v13) X(1024, 14, F64_1024_v14) X(1024, 15, F64_1024_v15)
 #define DFFT_F64_EXP_2048(X) X(2048, 8, F64_2048_v8) X(2048, 9, F64_2048_v9) X(2048, 10, F64_2048_v10) X(2048, 12, F64_2048_v12)
 #else
 #define DFFT_F64_EXP_SMALL(X)

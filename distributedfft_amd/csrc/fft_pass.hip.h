@@ -1327,6 +1327,10 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
                 // swapped on the fly (inverse via re<->im swap): v = (Im Z', Re Z')
                 v[c].y = Ar - wv.x * Bi + wv.y * Br;
                 v[c].x = Ai + wv.x * Br + wv.y * Bi;
+                // every point needs two loads (X[k], X[M-k]): left alone the scheduler hoists all 2E of them above the arithmetic, which
+                // at 24-30 fp64 points per thread is more registers than a lane has (212-516 bytes per lane of scratch in the
+                // mixed-radix C2R kernels); a fence every few points keeps a bounded number in flight
+                if constexpr (E > 16 && c % 6 == 5) __builtin_amdgcn_sched_barrier(0);
             });
         };
         if (A.load_kind == LOAD_LINES) {
