@@ -155,6 +155,14 @@ constexpr int brev(int m, int R)
     return r;
 }
 
+// slot that holds output index k after Dif<R> (the inverse of brev: the digit reversal is its own inverse only for prime powers)
+constexpr int brev_inv(int k, int R)
+{
+    for (int m = 0; m < R; m++)
+        if (brev(m, R) == k) return m;
+    return 0;
+}
+
 // cos(2*pi*j/64), j = 0..16 (one octant + 1); everything else by symmetry
 constexpr double kCos64[17] = {1.0,
                                           0.99518472667219688624,
@@ -509,7 +517,7 @@ template <typename Cfg, int COMP, int RPN>
 __host__ __device__ __forceinline__ void lds_gather_paired(typename Cfg::C *v, const typename Cfg::real *plane, int t, int lw)
 {
     constexpr int S = Cfg::kE / RPN, LEG = Cfg::kN / RPN;
-    constexpr bool SEP = Cfg::kMAP == 0 ? LEG % Cfg::r1 == 0 : LEG % Cfg::PADB == 0;
+    constexpr bool SEP = is_pow2(Cfg::kN) && (Cfg::kMAP == 0 ? LEG % Cfg::r1 == 0 : LEG % Cfg::PADB == 0);      // mixed radix: pad blocks are not aligned to the legs
     static_for<0, S>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const int j = pair_j<Cfg, RPN, i>(t);
@@ -1073,7 +1081,7 @@ template <typename Cfg> __device__ __forceinline__ bool real_tile(const PassArgs
 // separate instantiation so that its address forms do not cost the z pass registers (fp32: 194 instead of 166 VGPRs,
 // i.e. 2 instead of 3 waves per SIMD, when both lived in one kernel).
 template <typename Cfg, int ONEPLANE = 0, int YLINES = 0>
-__global__ __launch_bounds__(Cfg::THREADS, ONEPLANE == 2 ? 4 : 1) void fft_r2c_kernel(const PassArgs A)
+__global__ __launch_bounds__(Cfg::THREADS, ONEPLANE == 2 && is_pow2(Cfg::kN) ? 4 : 1) void fft_r2c_kernel(const PassArgs A)
 {
     using C = typename Cfg::C;
     using R = typename Cfg::real;
@@ -1135,8 +1143,8 @@ __global__ __launch_bounds__(Cfg::THREADS, ONEPLANE == 2 ? 4 : 1) void fft_r2c_k
                 constexpr int c = decltype(cc)::value;
                 constexpr int i = c % S, mr = c / S, m = brev(mr, RL);
                 const int k = pair_j<Cfg, RL, i>(t2) + m * LEG;
-                constexpr int pn = (i < H ? i + H : i - H) + brev(RL - 1 - m, RL) * S;      // the mirror block's leg RL-1-m
-                constexpr int ps = i < H ? i + brev((RL - m) % RL, RL) * S : i + brev(RL - 1 - m, RL) * S;   // self-mirrored butterflies
+                constexpr int pn = (i < H ? i + H : i - H) + brev_inv(RL - 1 - m, RL) * S;      // the mirror block's leg RL-1-m
+                constexpr int ps = i < H ? i + brev_inv((RL - m) % RL, RL) * S : i + brev_inv(RL - 1 - m, RL) * S;   // self-mirrored butterflies
                 C zm = v[pn];
                 if constexpr (i % H == 0) zm = pick(special, v[ps], v[pn]);
                 const C z = v[c];

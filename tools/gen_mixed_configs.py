@@ -100,6 +100,56 @@ def choose(N, prec):
     return None if best is None else best[1]
 
 
+def choose_real(N, prec, base):
+    """Configuration pair for the packed real z passes (R2C / C2R) of M = N complex points with the Hermitian split / merge IN
+    REGISTERS (fft_r2c_kernel ONEPLANE = 2, fft_c2r_kernel PAIRED): the pass next to the split / merge -- the last one of the R2C
+    chain, the first one of the C2R chain -- assigns its butterflies in conjugate pairs, which needs an even number of butterflies
+    per thread in that pass, E / radix even.  Same constraints as choose(); prefers the complex configuration's own points per
+    thread and radices (only their order changes).  None: the length keeps the split through LDS."""
+    TL, rsz, epref, emax = (8, 8, 16, 32) if prec == "f64" else (16, 4, 24, 64)
+    overhead = (lambda E: 46) if prec == "f64" else (lambda E: 26 + 2 * E - 24)
+    best = None
+    for rad in factorizations(N, 4):
+        if len(rad) < 2:
+            continue
+        lcm = 1
+        for r in rad:
+            lcm = lcm * r // math.gcd(lcm, r)
+        for mult in (1, 2, 3, 4):
+            E = lcm * mult
+            if E > emax or N % E:
+                continue
+            NT = N // E
+            if NT * TL > 1024:
+                continue
+            G = 1
+            while NT * TL * G < 256 and NT * TL * G * 2 <= 1024 and G < 32:
+                G *= 2
+            threads = NT * TL * G
+            if E * (rsz // 2) + overhead(E) > vgpr_cap(threads):
+                continue
+            if prec == "f32" and 4 * E + 26 > 256:      # would spill (see choose()): such a length keeps the LDS form
+                continue
+            heavy = 0
+            for last in sorted(set(rad), reverse=True):
+                if (E // last) % 2:
+                    continue
+                rest = list(rad)
+                rest.remove(last)
+                rest.sort(reverse=True)
+                r2c, c2r = tuple(rest) + (last,), (last,) + tuple(rest)
+                lds = max(lds_bytes(N, TL * G, r2c[0], 1, rsz, len(rad)), lds_bytes(N, TL * G, c2r[0], 1, rsz, len(rad)))
+                if lds > 160 * 1024:
+                    continue
+                same = 0 if (E == base["E"] and sorted(rad) == sorted(base["rad"])) else 1
+                score = (len(rad) + heavy, same, abs(E - epref), -r2c[0], r2c)
+                if best is None or score < best[0]:
+                    best = (score, dict(N=N, E=E, TL=TL, G=G, r2c=r2c, c2r=c2r, threads=threads, lds=lds, npass=len(rad) + heavy))
+    if best is None or best[1]["npass"] > len(base["rad"]):       # one more pass than the LDS form costs more than the split saves
+        return None
+    return best[1]
+
+
 # compile parts per precision: (mixed_*.hip, rmixed_*.hip)
 PARTS = {"f64": (2, 3), "f32": (4, 6)}
 
@@ -109,7 +159,7 @@ def main():
     out.append("// kernels_mixed.inc -- GENERATED by tools/gen_mixed_configs.py; do not edit.")
     out.append("// Axis-pass configurations of the natively supported lengths that are not powers of two (mixed radix 2, 3, 5, 7).")
     out.append("//                      real   N     E  TL  G  radices      planes chain")
-    for prec, real, tag in (("f64", "double", "F64"), ("f32", "float", "F32")):
+    for prec, real_t, tag in (("f64", "double", "F64"), ("f32", "float", "F32")):
         cfgs = []
         for N in SIZES:
             c = choose(N, prec)
@@ -122,7 +172,7 @@ def main():
             r = list(c["rad"]) + [1] * (4 - len(c["rad"]))
             chain = 1 if max(c["rad"]) >= 16 and len(c["rad"]) > 1 else 0
             tail = ", 0, 0, 2" if c["sub"] == 2 else ""      # NTMEM, MAP, SUB
-            out.append(f"using {tag}_M{c['N']} = PassCfg<{real}, {c['N']}, {c['E']}, {c['TL']}, {c['G']}, {r[0]}, {r[1]}, {r[2]}, {r[3]}, {c['planes']}, {chain}{tail}>;"
+            out.append(f"using {tag}_M{c['N']} = PassCfg<{real_t}, {c['N']}, {c['E']}, {c['TL']}, {c['G']}, {r[0]}, {r[1]}, {r[2]}, {r[3]}, {c['planes']}, {chain}{tail}>;"
                        f"   // {c['threads']} threads, {c['lds']} B LDS")
         # Compile parts (mixed_*.hip / rmixed_*.hip, -DDFFT_PART=k): the configurations are dealt to PARTS[...] lists of about
         # equal compile cost (longest first onto the lightest list; cost ~ points per thread x (passes + 1), which is what
@@ -144,13 +194,26 @@ def main():
         # packed real z passes (R2C / C2R of a real line of 2M points as an M-point complex transform + Hermitian split /
         # merge): every configuration with whole-tile workgroups; Y(M, cfg, ONEPLANE)
         real = [c for c in cfgs if c["sub"] == 1 and c["N"] <= 1024]
+        paired = {c["N"]: choose_real(c["N"], prec, c) for c in real}
+        for c in real:
+            pr = paired[c["N"]]
+            if pr is None:
+                continue
+            chain = 1 if max(pr["r2c"]) >= 16 else 0
+            for kind, rad in (("R", pr["r2c"]), ("C", pr["c2r"])):
+                r = list(rad) + [1] * (4 - len(rad))
+                out.append(f"using {tag}_{kind}{c['N']} = PassCfg<{real_t}, {c['N']}, {pr['E']}, {pr['TL']}, {pr['G']}, {r[0]}, {r[1]}, {r[2]}, {r[3]}, 1, {chain}>;"
+                           f"   // {pr['threads']} threads, {'R2C: pairs in the last pass' if kind == 'R' else 'C2R: pairs in the first pass'}")
         for k, sel in enumerate(deal(real, nr)):
             ys = []
             for c in sel:
+                if paired[c["N"]] is not None:
+                    ys.append(f"Y({c['N']}, {tag}_R{c['N']}, 2, {tag}_C{c['N']}, 2)")
+                    continue
                 plane = lds_bytes(c["N"], c["TL"] * c["G"], c["rad"][0], 1, 8 if prec == "f64" else 4, 2)
                 # two planes when two workgroups with two planes each still fit a CU, else one plane after the other (two more
                 # barriers, half the LDS: the mixed configurations have 256-512 threads, one workgroup per CU starves it)
-                ys.append(f"Y({c['N']}, {tag}_M{c['N']}, {0 if 2 * plane <= 80 * 1024 else 1})")
+                ys.append(f"Y({c['N']}, {tag}_M{c['N']}, {0 if 2 * plane <= 80 * 1024 else 1}, {tag}_M{c['N']}, 0)")
             out.append(f"#define DFFT_{tag}_LIST_RMIXED{k}(Y) {' '.join(ys)}")
         out.append(f"#define DFFT_{tag}_RMIXED_FOREACH_PART(P) " + " ".join(f"P({k})" for k in range(nr)))
         out.append("#endif")
