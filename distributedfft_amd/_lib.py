@@ -80,6 +80,7 @@ SYMBOLS = [
     ("dfft_last_error", C.c_char_p, []),
     ("dfft_version", C.c_char_p, []),
     ("dfft_kernel_info", _i, [_i, _sz, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    ("dfft_axis_plan_info", _i, [_i, _sz, _i, C.POINTER(_sz)]),
     ("dfft_malloc", _i, [_sz, _sz, C.POINTER(_vp)]),
     ("dfft_free", _i, [_vp]),
     ("dfft_tune_variants", _i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_float), _i, C.POINTER(_i)]),

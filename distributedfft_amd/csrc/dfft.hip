@@ -100,14 +100,19 @@ static int make_twiddles(int prec, size_t N, void **dev)
 static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 static size_t next_pow2(size_t n) { size_t m = 1; while (m < n) m <<= 1; return m; }
 
-// One axis of the 3-D transform: native power-of-two Stockham chain or Bluestein on top of it
+// One axis of the 3-D transform: native Stockham chain, Bluestein on top of it, or two levels of either (N = N1*N2)
 struct Axis {
     size_t N = 0;          // line length
-    bool bluestein = false;
+    bool bluestein = false;    // the generic kernel (fft_bluestein_kernel) runs the pass: Bluestein, or the levels of a two-level line
     size_t M = 0;          // inner power-of-two length (== N when native)
     void *tw = nullptr;    // exp(-2 pi i j / M), M entries
     void *chirp = nullptr; // Bluestein: exp(-i pi n^2 / N), N entries
     void *bhat = nullptr;  // Bluestein: FFT_M(conj chirp, wrapped) / M
+    // two-level line (fft_pass.hip.h, "Two-level lines"): lv[0] transforms N1 = lv[0].N points, lv[1] N2 = lv[1].N; a level is
+    // the plain power-of-two chain (bluestein == false, M == N) or Bluestein on an arbitrary factor
+    bool two = false;
+    std::vector<Axis> lv;
+    void *twN = nullptr;   // exp(-2 pi i j / N), N entries: twiddles between the levels
 };
 
 static void host_fft_pow2(std::vector<std::complex<long double>> &a)
@@ -152,29 +157,75 @@ static int upload_complex(int prec, const std::vector<std::complex<long double>>
 
 static void axis_free(Axis &a)
 {
-    for (void **t : {&a.tw, &a.chirp, &a.bhat}) if (*t) { (void)hipFree(*t); *t = nullptr; }
+    for (void **t : {&a.tw, &a.chirp, &a.bhat, &a.twN}) if (*t) { (void)hipFree(*t); *t = nullptr; }
+    for (auto &l : a.lv) axis_free(l);
 }
 
-// decide how an axis of length N is transformed; returns false if unsupported
-static bool axis_plan(int prec, size_t N, Axis &a, bool mixed = true)
+// Two-level plan of an axis: N = N1*N2 with both factors within reach of the generic kernel -- a power of two up to 8192 (plain
+// chain) or any length F with a Bluestein inner transform of next_pow2(2F-1) <= 8192 points.  The cheapest split by a model of
+// the launches' cost in passes over the data: plain 1 (2 on the sub-tile workgroups of 4096 / 8192 points), Bluestein 1.5 plus
+// the padding ratio M/F.  Largest N: 2^24 (32-bit point indices in the kernel).
+static bool axis_plan_two_level(int prec, size_t N, Axis &a)
+{
+    a.N = N;
+    if (N < 4 || N > ((size_t)1 << 24)) return false;
+    PassInfo pi;
+    auto level_cost = [&](size_t F, bool &blue, size_t &M) -> double {
+        if (is_pow2(F) && F <= 8192 && pass_info(prec, (int)F, &pi)) { blue = false; M = F; return F > 2048 ? 2.0 : 1.0; }
+        M = next_pow2(2 * F - 1);
+        if (F < 2 || M > 8192 || !pass_info(prec, (int)M, &pi)) return -1.0;
+        blue = true;
+        return 1.5 + (double)M / (double)F + (M > 2048 ? 2.0 : 0.0);
+    };
+    double best = -1.0;
+    size_t b1 = 0;
+    for (size_t n1 = 2; n1 * n1 <= N; n1++) {
+        if (N % n1) continue;
+        for (size_t f : {n1, N / n1}) {
+            bool bl1, bl2; size_t m1, m2;
+            const double c1 = level_cost(f, bl1, m1), c2 = level_cost(N / f, bl2, m2);
+            if (c1 < 0 || c2 < 0) continue;
+            // ties: the smaller largest inner transform, then the longer second level (its scratch reads are contiguous)
+            const double c = c1 + c2 + 1e-6 * (double)std::max(m1, m2) + (f > N / f ? 1e-9 : 0.0);
+            if (best < 0 || c < best) { best = c; b1 = f; }
+        }
+    }
+    if (best < 0) return false;
+    a.two = true; a.bluestein = true; a.M = 0;
+    a.lv.assign(2, Axis());
+    const size_t f[2] = {b1, N / b1};
+    for (int k = 0; k < 2; k++) {
+        bool bl; size_t M;
+        level_cost(f[k], bl, M);
+        a.lv[k].N = f[k]; a.lv[k].bluestein = bl; a.lv[k].M = M;
+    }
+    return true;
+}
+
+// decide how an axis of length N is transformed; returns false if unsupported.  two_level: 0 = only lengths with no other
+// plan, 1 = wherever a split exists (tests, A/B runs)
+static bool axis_plan(int prec, size_t N, Axis &a, bool mixed = true, int two_level = 0)
 {
     PassInfo pi;
     a.N = N;
+    if (two_level == 1 && axis_plan_two_level(prec, N, a)) return true;
     // native chain: powers of two 2..8192 and the mixed-radix lengths of kernels_mixed.inc (2^a 3^b 5^c 7^d <= 2048)
     if ((is_pow2(N) || mixed) && N <= 8192 && pass_info(prec, (int)N, &pi)) { a.bluestein = false; a.M = N; return true; }
     const size_t M = next_pow2(2 * N - 1);
-    if (N < 2 || M > 8192 || !pass_info(prec, (int)M, &pi)) return false;
+    if (N < 2 || M > 8192 || !pass_info(prec, (int)M, &pi)) return axis_plan_two_level(prec, N, a);
     a.bluestein = true; a.M = M;
     return true;
 }
 
-// Bluestein even for a power of two: its kernel is the one with a strided real-line load (Y_Then_ZX)
-static bool axis_plan_bluestein(int prec, size_t N, Axis &a)
+// Bluestein even for a power of two: its kernel is the one with a strided real-line load (Y_Then_ZX) and the real modes;
+// lengths beyond its reach in two levels (the generic kernel again, real modes included)
+static bool axis_plan_bluestein(int prec, size_t N, Axis &a, int two_level = 0)
 {
     PassInfo pi;
     a.N = N;
+    if (two_level == 1 && axis_plan_two_level(prec, N, a)) return true;
     const size_t M = next_pow2(2 * N - 1);
-    if (N < 2 || M > 8192 || !pass_info(prec, (int)M, &pi)) return false;
+    if (N < 2 || M > 8192 || !pass_info(prec, (int)M, &pi)) return axis_plan_two_level(prec, N, a);
     a.bluestein = true; a.M = M;
     return true;
 }
@@ -182,6 +233,11 @@ static bool axis_plan_bluestein(int prec, size_t N, Axis &a)
 static int axis_upload(int prec, Axis &a)
 {
     const long double PI = 3.141592653589793238462643383279502884L;
+    if (a.two) {
+        for (auto &l : a.lv) TRY(axis_upload(prec, l));
+        if (!a.twN) TRY(make_twiddles(prec, a.N, &a.twN));
+        return 0;
+    }
     if (!a.tw) TRY(make_twiddles(prec, a.M, &a.tw));
     if (a.bluestein && !a.chirp) {
         const size_t N = a.N, M = a.M;
@@ -206,7 +262,7 @@ static int axis_upload(int prec, Axis &a)
 using namespace dfft;
 
 struct Launch {
-    PassArgs args;            // in/out/tw and the device table pointers are filled at enqueue time
+    PassArgs args{};          // in/out/tw and the device table pointers are filled at enqueue time (zeroed: a plan builds only the launches of its kind)
     SegTable lseg{}, sseg{};  // host copies of the segment tables (uploaded by upload_tables)
     size_t ltab = 0, stab = 0;   // byte offsets of the tables in the plan's device table buffer
     size_t lent = SIZE_MAX, sent = SIZE_MAX;   // byte offsets of the per-point address tables (SIZE_MAX: none)
@@ -261,6 +317,8 @@ struct Options {
                              // with three plain launches and 34 us as a graph, 128^3 54 vs 60 us; the launches are already hidden
                              // behind the first kernel (128^3: 50 us of kernels in a 54 us call)
     int native_mixed = 1;    // lengths 2^a 3^b 5^c 7^d with a configuration run the native chain (0: Bluestein, for A/B runs and tests)
+    int two_level = 0;       // 1: every axis whose length splits as N1*N2 runs as a two-level line (tests, A/B runs; 0: only lengths
+                             // that have no other plan)
     int order[6] = {-1, -1, -1, -1, -1, -1};     // workgroup->tile order per pass: fz fy fx ix iy iz; a_fastest + 2*xcd_swizzle
     int variant[6] = {-1, -1, -1, -1, -1, -1};   // kernel configuration per pass, same order (-1 = the plan's choice)
 };
@@ -284,6 +342,7 @@ struct dfft_plan {
     Axis ax[3];                  // [0] = z, [1] = y, [2] = x
     bool zreal_native = false;   // R2C plan whose z axis uses the packed Nz/2-point kernels
     bool yreal_native = false;   // Y_Then_ZX R2C plan whose y axis uses the packed Ny/2-point kernel (strided real lines)
+    size_t lv_off = 0, lv_bytes = 0;   // two-level axes: scratch between the levels, a region of the work area (behind the exchange slices)
     void *tw_zr = nullptr;       // split/merge table exp(-2 pi i k / Nz) (or / Ny) of the packed real kernels
     void *tables_d = nullptr;    // segment tables of every launch, device copy
     hipStream_t stream = nullptr;
@@ -756,6 +815,30 @@ static void fill_tables(dfft_plan *p, const Launch &L, PassArgs &A)
     A.stab = L.sent == SIZE_MAX ? nullptr : reinterpret_cast<const SegEntry *>(static_cast<const char *>(p->tables_d) + L.sent);
 }
 
+// one launch of the generic kernel for the lines (or sub-lines) of `ax`: plain chain or Bluestein
+static int launch_generic(int prec, const Axis &ax, PassArgs &A, hipStream_t s)
+{
+    A.tw = ax.tw; A.tw2 = ax.chirp; A.tw3 = ax.bhat; A.NL = (uint32_t)ax.N; A.plain = ax.bluestein ? 0 : 1;
+    return prec == DFFT_F64 ? launch_bluestein_f64((int)ax.M, A, s) : launch_bluestein_f32((int)ax.M, A, s);
+}
+
+// two-level line (fft_pass.hip.h): level 1 through the pass's load form into the scratch, level 2 from the scratch through its
+// store form.  real_mode / NK as for a one-launch generic pass.
+static int launch_two_level(int prec, const Axis &ax, PassArgs A, int real_mode, size_t NK, void *scratch, hipStream_t s)
+{
+    A.lvN = (uint32_t)ax.N; A.lvNK = (uint32_t)NK; A.NK = (uint32_t)NK; A.real_mode = real_mode; A.lvtw = ax.twN; A.lvw = scratch;
+    for (int level = 1; level <= 2; level++) {
+        PassArgs B = A;
+        B.lv = level; B.lvQ = (uint32_t)ax.lv[2 - level].N;
+        const int r = launch_generic(prec, ax.lv[level - 1], B, s);
+        if (r != 0) return fail(r == -1 ? ERR_UNSUPPORTED : r, "two-level pass launch failed for length " + std::to_string(ax.N));
+    }
+    return 0;
+}
+
+// bytes of scratch a two-level launch needs
+static size_t two_level_bytes(const PassArgs &A, int TL, size_t N, size_t esz) { return (size_t)A.ntiles * (size_t)TL * N * esz; }
+
 // complex axis pass on axis `axis` (0 = z, 1 = y, 2 = x)
 static int launch(dfft_plan *p, const Launch &L, int variant, int axis, const char *in, char *out, bool real_lines = false)
 {
@@ -772,9 +855,13 @@ static int launch(dfft_plan *p, const Launch &L, int variant, int axis, const ch
         return 0;
     }
     if (!ax.bluestein) return launch_pass(p->prec, (int)ax.N, variant, A, p->stream);
-    A.tw2 = ax.chirp; A.tw3 = ax.bhat; A.NL = (uint32_t)ax.N; A.NK = (uint32_t)ax.N; A.real_mode = 0;
+    if (ax.two) {
+        if (two_level_bytes(A, p->TL, ax.N, p->esz) > p->lv_bytes) return fail(ERR_STATE, "two-level pass: scratch region too small");
+        return launch_two_level(p->prec, ax, A, real_lines ? 1 : 0, real_lines ? ax.N / 2 + 1 : ax.N, static_cast<char *>(p->work_d) + p->lv_off, p->stream);
+    }
+    A.NK = (uint32_t)ax.N; A.real_mode = 0;
     if (real_lines) { A.real_mode = 1; A.NK = (uint32_t)(ax.N / 2 + 1); }     // real in, Hermitian half out
-    int r = p->prec == DFFT_F64 ? launch_bluestein_f64((int)ax.M, A, p->stream) : launch_bluestein_f32((int)ax.M, A, p->stream);
+    int r = launch_generic(p->prec, ax, A, p->stream);
     if (r != 0) return fail(r == -1 ? ERR_UNSUPPORTED : r, "Bluestein pass launch failed for length " + std::to_string(ax.N));
     return 0;
 }
@@ -795,9 +882,12 @@ static int launch_real(dfft_plan *p, const Launch &L, int mode, const char *in, 
                                 : launch_real_f32(M, mode, p->opt.real_variant, A, p->stream);
     } else if (!ax.bluestein) {
         return fail(ERR_UNSUPPORTED, "real z pass without a native or Bluestein plan");      // (dfft_init rules this out)
+    } else if (ax.two) {
+        if (two_level_bytes(A, p->TL, ax.N, p->esz) > p->lv_bytes) return fail(ERR_STATE, "two-level pass: scratch region too small");
+        return launch_two_level(p->prec, ax, A, mode, p->Nzc, static_cast<char *>(p->work_d) + p->lv_off, p->stream);
     } else {
-        A.tw2 = ax.chirp; A.tw3 = ax.bhat; A.NL = (uint32_t)p->Nz; A.NK = (uint32_t)p->Nzc; A.real_mode = mode;
-        r = p->prec == DFFT_F64 ? launch_bluestein_f64((int)ax.M, A, p->stream) : launch_bluestein_f32((int)ax.M, A, p->stream);
+        A.NK = (uint32_t)p->Nzc; A.real_mode = mode;
+        r = launch_generic(p->prec, ax, A, p->stream);
     }
     if (r == -1) return fail(ERR_UNSUPPORTED, "unsupported real line length " + std::to_string(p->Nz));
     if (r != 0) return fail(r, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)r));
@@ -1426,6 +1516,7 @@ static const char *const kPassNames[6] = {"fz", "fy", "fx", "ix", "iy", "iz"};
 static int *option_slot(Options &o, const std::string &k)
 {
     if (k == "pipeline_chunks") return &o.chunks;
+    if (k == "two_level") return &o.two_level;
     if (k == "mirror_inverse") return &o.mirror;
     if (k == "point_tables") return &o.tables;
     if (k == "uniform_tables") return &o.uniform_tables;
@@ -1498,21 +1589,22 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         const bool mixed = p->opt.native_mixed != 0;
         // packed real z pass: Nz/2-point complex transform + Hermitian split / merge (powers of two, and even lengths whose
         // half has a mixed-radix configuration)
-        const bool zr_native = !yzx && !c2c && Nz >= 4 && Nz <= 4096 && Nz % 2 == 0 && (is_pow2(Nz) || mixed) &&
+        const int tl = p->opt.two_level;      // 1: two-level lines wherever a split exists (the packed real kernels then stand back)
+        const bool zr_native = !yzx && !c2c && tl != 1 && Nz >= 4 && Nz <= 4096 && Nz % 2 == 0 && (is_pow2(Nz) || mixed) &&
                                (p->prec == DFFT_F64 ? real_supported_f64((int)(Nz / 2)) : real_supported_f32((int)(Nz / 2)));
         const size_t zlen = zr_native ? Nz / 2 : Nz;
         // Y_Then_ZX, R2C: the y pass reads real lines in place, which only the Bluestein kernel does
         // Y_Then_ZX, R2C: the y pass reads real lines in place.  Power-of-two Ny: the packed Ny/2-point real kernel
         // with its strided-line load; any other Ny: the Bluestein kernel's real mode (Ny <= 4096)
-        const bool yr_native = yzx && !c2c && is_pow2(Ny) && Ny >= 4 && Ny <= 2048;
-        const bool yok = yr_native ? axis_plan(p->prec, Ny / 2, ay) : yzx && !c2c ? axis_plan_bluestein(p->prec, Ny, ay) : axis_plan(p->prec, Ny, ay, mixed);
+        const bool yr_native = yzx && !c2c && tl != 1 && is_pow2(Ny) && Ny >= 4 && Ny <= 2048;
+        const bool yok = yr_native ? axis_plan(p->prec, Ny / 2, ay) : yzx && !c2c ? axis_plan_bluestein(p->prec, Ny, ay, tl) : axis_plan(p->prec, Ny, ay, mixed, tl);
         // a real z pass is either the packed Nz/2-point kernel or the Bluestein kernel's real modes: never
         // the plain complex chain (Nz == 2 would otherwise pick it and launch Bluestein without its tables)
         const bool zreal_generic = !yzx && !c2c && !zr_native;
-        const bool zok = zreal_generic ? axis_plan_bluestein(p->prec, Nz, az) : axis_plan(p->prec, zlen, az, mixed);
-        if (!zok || !yok || !axis_plan(p->prec, Nx, axx, mixed))
-            return fail(ERR_UNSUPPORTED, yzx && !c2c && Ny > 2048 ? "unsupported axis length (Y_Then_ZX R2C: Ny up to 4096)"
-                        : "unsupported axis length (powers of two up to 8192 -- 4096 on the real axis of an R2C plan --, any other length up to 4096)");
+        const bool zok = zreal_generic ? axis_plan_bluestein(p->prec, Nz, az, tl) : axis_plan(p->prec, zlen, az, mixed, tl);
+        if (!zok || !yok || !axis_plan(p->prec, Nx, axx, mixed, tl))
+            return fail(ERR_UNSUPPORTED, "unsupported axis length (any length up to 4096, powers of two up to 8192, and beyond that every length "
+                                         "N1*N2 <= 2^24 whose factors are each such a length: not a prime above 4096)");
         for (auto &a : p->ax) axis_free(a);
         p->ax[0] = az; p->ax[1] = ay; p->ax[2] = axx;
         p->zreal_native = zr_native;
@@ -1582,6 +1674,24 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
     if (p->pl.single) {
         const size_t need = (p->pl.single_work_elems * p->esz + 255) & ~(size_t)255;
         p->worksize_d = std::max(p->worksize_d, need);      // the padded L2 buffer lives in the work area
+    }
+    {   // two-level axes: the scratch between the levels is a region of the work area behind the exchange slices, sized for the
+        // largest launch (tiles x TL lines x N points)
+        const Pipeline &pl = p->pl;
+        size_t lvb = 0;
+        auto need = [&](const Launch &L, int axis) {
+            if (p->ax[axis].two) lvb = std::max(lvb, two_level_bytes(L.args, p->TL, p->ax[axis].N, p->esz));
+        };
+        for (auto &L : pl.fz) need(L, 0); for (auto &L : pl.iz) need(L, 0);
+        for (auto &L : pl.fy) need(L, 1); for (auto &L : pl.iy) need(L, 1); for (auto &L : pl.py2) need(L, 1); for (auto &L : pl.qy2) need(L, 1);
+        for (auto &L : pl.zy) need(L, 1); for (auto &L : pl.ziy) need(L, 1);
+        for (auto &L : pl.ix) need(L, 2);
+        need(pl.fx, 2); need(pl.zix, 2); need(pl.pz1, 0); need(pl.qz1, 0); need(pl.yz, 0);
+        if (pl.single) { need(pl.sz, 0); need(pl.sx, 2); need(pl.sy, 1); }
+        p->worksize_d = (p->worksize_d + 255) & ~(size_t)255;
+        p->lv_off = p->worksize_d;
+        p->lv_bytes = (lvb + 255) & ~(size_t)255;
+        p->worksize_d += p->lv_bytes;
     }
     // kernel configuration per pass, by role (PassRole); lengths without a configuration for a role use the default
     {
@@ -2016,18 +2126,21 @@ int dfft_fft1d_batched_ex(int precision, size_t N, size_t batch, void *out, cons
 {
     static thread_local Axis ax;
     static thread_local int axP = -1;
-    static thread_local bool axB = false;
-    const bool force_bluestein = variant < 0;      // variant -1: the Bluestein kernel even where a native configuration exists
-    if (variant > 15) return fail(ERR_ARG, "variant must be -1 (Bluestein) or 0..15");
-    if (force_bluestein) variant = 0;
-    if (ax.N != N || axP != precision || axB != force_bluestein) {
+    static thread_local int axB = 0;
+    static thread_local void *lvw = nullptr;       // scratch of two-level lines, grown on demand
+    static thread_local size_t lvw_bytes = 0;
+    // variant -1: the Bluestein kernel even where a native configuration exists; -2: two levels wherever the length splits
+    const int force = variant == -2 ? 2 : variant < 0 ? 1 : 0;
+    if (variant > 15) return fail(ERR_ARG, "variant must be -2 (two-level), -1 (Bluestein) or 0..15");
+    if (force) variant = 0;
+    if (ax.N != N || axP != precision || axB != force) {
         axis_free(ax);
         ax = Axis();
         axP = -1;
-        if (!(force_bluestein ? axis_plan_bluestein(precision, N, ax) : axis_plan(precision, N, ax))) { ax = Axis(); return fail(ERR_UNSUPPORTED, "unsupported line length"); }
+        if (!(force == 1 ? axis_plan_bluestein(precision, N, ax) : axis_plan(precision, N, ax, true, force == 2))) { ax = Axis(); return fail(ERR_UNSUPPORTED, "unsupported line length"); }
         if (int r = axis_upload(precision, ax)) { axis_free(ax); ax = Axis(); return r; }
         axP = precision;
-        axB = force_bluestein;
+        axB = force;
     }
 #ifdef DFFT_EXPERIMENTS
     if ((variant == 15 || variant == 14) && precision == DFFT_F32 && !ax.bluestein) {      // A/B: the LDS-free shuffle pass (15 bpermute, 14 DPP)
@@ -2042,7 +2155,7 @@ int dfft_fft1d_batched_ex(int precision, size_t N, size_t batch, void *out, cons
     const bool has = !ax.bluestein && variant ? (precision == DFFT_F64 ? pass_info_f64((int)ax.M, variant, &pi) : pass_info_f32((int)ax.M, variant, &pi)) : false;
     if (!has) {
         variant = 0;
-        if (!pass_info(precision, (int)ax.M, &pi)) return fail(ERR_UNSUPPORTED, "unsupported line length");
+        if (!pass_info(precision, ax.two ? 2 : (int)ax.M, &pi)) return fail(ERR_UNSUPPORTED, "unsupported line length");      // (two levels: any configuration gives TL)
     }
     PassArgs A;
     memset(&A, 0, sizeof(A));
@@ -2050,9 +2163,17 @@ int dfft_fft1d_batched_ex(int precision, size_t N, size_t batch, void *out, cons
     A.na = 1; A.LB = (uint32_t)batch; A.nb = ((uint32_t)batch + pi.TL - 1) / pi.TL; A.ntiles = A.nb;
     A.load_kind = LOAD_LINES; A.store_kind = STORE_LINES; A.swap = direction == DFFT_INVERSE;
     if (!ax.bluestein) return launch_pass(precision, (int)N, variant, A, (hipStream_t)hip_stream);
-    A.tw2 = ax.chirp; A.tw3 = ax.bhat; A.NL = (uint32_t)N; A.NK = (uint32_t)N;
-    int r = precision == DFFT_F64 ? launch_bluestein_f64((int)ax.M, A, (hipStream_t)hip_stream)
-                                  : launch_bluestein_f32((int)ax.M, A, (hipStream_t)hip_stream);
+    if (ax.two) {
+        const size_t need = two_level_bytes(A, pi.TL, N, precision == DFFT_F64 ? 16 : 8);
+        if (need > lvw_bytes) {
+            if (lvw) { (void)hipFree(lvw); lvw = nullptr; lvw_bytes = 0; }      // (hipFree waits for the launches that still use it)
+            HIP_TRY(hipMalloc(&lvw, need));
+            lvw_bytes = need;
+        }
+        return launch_two_level(precision, ax, A, 0, N, lvw, (hipStream_t)hip_stream);
+    }
+    A.NK = (uint32_t)N;
+    int r = launch_generic(precision, ax, A, (hipStream_t)hip_stream);
     if (r != 0) return fail(r == -1 ? ERR_UNSUPPORTED : r, "Bluestein launch failed");
     return 0;
 }
@@ -2067,11 +2188,23 @@ int dfft_kernel_info(int precision, size_t N, int *threads, int *lds_bytes, int 
 {
     PassInfo pi;
     Axis a;
-    if (!axis_plan(precision, N, a) || !pass_info(precision, (int)a.M, &pi)) return ERR_UNSUPPORTED;
+    if (!axis_plan(precision, N, a) || !pass_info(precision, (int)(a.two ? a.lv[1].M : a.M), &pi)) return ERR_UNSUPPORTED;      // two levels: the second level's kernel
     if (threads) *threads = pi.threads;
     if (lds_bytes) *lds_bytes = pi.lds_bytes;
     if (points_per_thread) *points_per_thread = pi.E;
     if (lines_per_workgroup) *lines_per_workgroup = pi.TL * pi.G / (pi.sub > 1 ? pi.sub : 1);      // sub-tile workgroups: part of a tile
+    return 0;
+}
+
+int dfft_axis_plan_info(int precision, size_t N, int two_level, size_t info[8])
+{
+    if (!info) return fail(ERR_ARG, "null pointer");
+    Axis a;
+    if (!axis_plan(precision, N, a, true, two_level)) return ERR_UNSUPPORTED;
+    for (int k = 0; k < 8; k++) info[k] = 0;
+    info[0] = a.two ? 2 : a.bluestein ? 1 : 0;
+    info[1] = a.M;
+    for (size_t k = 0; k < a.lv.size(); k++) { info[2 + 3 * k] = a.lv[k].N; info[3 + 3 * k] = a.lv[k].M; info[4 + 3 * k] = a.lv[k].bluestein; }
     return 0;
 }
 

@@ -100,7 +100,13 @@ struct PassArgs {
     const SegTable *lseg, *sseg;
     int32_t lnseg, snseg;
     const SegEntry *ltab, *stab;   // per-point tables (null: search the segment table per point)
-    int32_t luni, suni;            // the side's table may be read with wave-uniform (scalar) loads: every segment starts at a multiple of 16 points
+    int32_t luni, suni;            // the side's table may be read with wave-uniform (scalar) loads: every segment starts at a multiple of 16 points    // two-level lines (fft_bluestein_kernel only): a line of lvN = N1*N2 points over two launches of NL = N1 resp. N2 points
+    int32_t lv;            // 0: the launch transforms whole lines; 1 / 2: first / second level
+    int32_t plain;         // fft_bluestein_kernel: 1 = NL == the configuration's length (a power of two): plain chain, no chirp
+    uint32_t lvQ;          // sub-lines per line: N2 at level 1, N1 at level 2
+    uint32_t lvN, lvNK;    // the line's length and its points on the spectral side of a real transform (as NL / NK of a one-launch pass)
+    const void *lvtw;      // exp(-2*pi*i*j/lvN), lvN entries: twiddles between the levels
+    void *lvw;             // scratch between the levels: ntiles * TL * lvN elements
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1488,6 +1494,17 @@ __device__ __forceinline__ void reorder_natural(typename Cfg::C *v, typename Cfg
     }
 }
 
+// Two-level lines (PassArgs::lv; the reference takes any length through cuFFT, mpicufft_pencil_opt1.cpp:165-197): a line of
+// N = N1*N2 points that has no kernel of its own is transformed by two launches of this kernel (the four-step algorithm):
+//   level 1 (lv = 1, NL = N1, lvQ = N2): sub-line q = n2 of a line holds its points n = n1*N2 + n2, loaded through the pass's
+//            own load address form; N1-point transform; times exp(-2 pi i k1 n2 / N) (lvtw); stored to the scratch lvw
+//   level 2 (lv = 2, NL = N2, lvQ = N1): sub-line q = k1 from the scratch; N2-point transform; output k2 is the line's point
+//            k = k1 + N1*k2, stored through the pass's own store address form
+// so that unpack / transpose / pack stay fused exactly as for a one-launch pass, whatever the layouts.  Scratch layout:
+// element (tile w, k1, n2, line l of the tile) at ((w*N1 + k1)*N2 + n2)*TL + l -- 128-byte runs for level 1, contiguous for level 2.
+// Each level is either the plain chain (PassArgs::plain: NL == Cfg::kN, a power of two) or Bluestein on an arbitrary factor.
+// Real lines: level 1 reads the real line / rebuilds the full spectrum from the Hermitian half, level 2 keeps the half /
+// the real parts (the full complex transform of the line, as in the one-launch real modes).
 template <typename Cfg>
 __global__ __launch_bounds__(Cfg::THREADS) void fft_bluestein_kernel(const PassArgs A)
 {
@@ -1510,6 +1527,11 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_bluestein_kernel(const PassA
         w = logical_block<>(A) * Cfg::kG + lw / TL;
         l = lw % TL;
     }
+    // two-level lines: the launch's tiles are (tile, sub-line) pairs, sub-line fastest
+    const int lv = A.lv;
+    const uint32_t Q = lv ? A.lvQ : 1u;
+    const uint32_t q = lv ? w % Q : 0u;
+    if (lv) w /= Q;
     const bool tile_ok = w < A.ntiles;
     TileCtx<TL> tc;
     tc.a = !tile_ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
@@ -1518,7 +1540,10 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_bluestein_kernel(const PassA
     const uint32_t rem = A.LB - tc.b * TL;
     tc.tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;
     const bool active = tile_ok && (uint32_t)l < tc.tw;
-    const uint32_t NL = A.NL, NK = A.NK;
+    const uint32_t NL = A.NL;
+    // the line as the pass's address forms see it: its length, its points on the spectral side of a real transform
+    const uint32_t NF = lv ? A.lvN : NL, NKF = lv ? A.lvNK : A.NK;
+    const bool plain = A.plain != 0;
     const C *__restrict__ in = reinterpret_cast<const C *>(A.in);
     const R *__restrict__ rin = reinterpret_cast<const R *>(A.in);
     C *__restrict__ out = reinterpret_cast<C *>(A.out);
@@ -1528,102 +1553,139 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_bluestein_kernel(const PassA
     const C *__restrict__ BH = reinterpret_cast<const C *>(A.tw3);
 
     C v[E];
-    // the address form (load kind) and the real mode are chosen once per thread, not per point;
-    // offset_of(n, NP): element offset of point n of this thread's line, NP = points per natural line
-    auto load_all = [&](auto offset_of) {
+    // fetch(n): point n of this thread's (sub-)line, before the chirp
+    auto load_all = [&](auto fetch) {
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             const uint32_t n = t + NT * c;
             C x; x.x = 0; x.y = 0;
             if (active && n < NL) {
-                if (A.real_mode == 1) {            // real input line
-                    x.x = rin[offset_of(n, NL)];
-                } else if (A.real_mode == 2) {     // Hermitian half in, rebuild the full spectrum
-                    if (n < NK) {
-                        x = in[offset_of(n, NK)];
-                        if (n == 0 || 2 * n == NL) x.y = 0;
-                    } else {
-                        x = in[offset_of(NL - n, NK)];
-                        x.y = -x.y;
-                    }
-                } else {
-                    x = in[offset_of(n, NL)];
+                x = fetch(n);
+                if (!plain) {
+                    const C ch = CH[n];
+                    C r; r.x = x.x * ch.x - x.y * ch.y; r.y = x.x * ch.y + x.y * ch.x;
+                    x = r;
                 }
-                if (A.swap) { R tmp = x.x; x.x = x.y; x.y = tmp; }
-                const C ch = CH[n];
-                C r; r.x = x.x * ch.x - x.y * ch.y; r.y = x.x * ch.y + x.y * ch.x;
-                x = r;
             }
             v[c] = x;
         });
     };
+    // the address form (load kind) and the real mode are chosen once per thread, not per point;
+    // offset_of(n, NP): element offset of point n of this thread's line, NP = points per natural line
+    auto load_ext = [&](auto offset_of) {
+        load_all([&](uint32_t n) {
+            const uint32_t nf = lv ? n * Q + q : n;
+            C x; x.x = 0; x.y = 0;
+            if (A.real_mode == 1) {            // real input line
+                x.x = rin[offset_of(nf, NF)];
+            } else if (A.real_mode == 2) {     // Hermitian half in, rebuild the full spectrum
+                if (nf < NKF) {
+                    x = in[offset_of(nf, NKF)];
+                    if (nf == 0 || 2 * nf == NF) x.y = 0;
+                } else {
+                    x = in[offset_of(NF - nf, NKF)];
+                    x.y = -x.y;
+                }
+            } else {
+                x = in[offset_of(nf, NF)];
+            }
+            if (A.swap) { R tmp = x.x; x.x = x.y; x.y = tmp; }
+            return x;
+        });
+    };
     const uint64_t rowline = (uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + tc.l;
-    if (A.load_kind == LOAD_LINES && A.KS_in) {          // strided natural-line rows
+    if (lv == 2) {                                       // second level: sub-line q of the scratch
+        const C *__restrict__ ws = reinterpret_cast<const C *>(A.lvw) + (((uint64_t)w * Q + q) * NL) * TL + l;
+        load_all([&](uint32_t n) { return ws[(uint64_t)n * TL]; });
+    } else if (A.load_kind == LOAD_LINES && A.KS_in) {          // strided natural-line rows
         const uint64_t row = (uint64_t)tc.a * A.AS_in + ((uint64_t)tc.b * TL + tc.l) * A.KS_in;
-        load_all([&](uint32_t n, uint32_t) { return row + n; });
+        load_ext([&](uint32_t n, uint32_t) { return row + n; });
     } else if (A.load_kind == LOAD_LINES) {
-        load_all([&](uint32_t n, uint32_t NP) { return rowline * NP + n; });
+        load_ext([&](uint32_t n, uint32_t NP) { return rowline * NP + n; });
     } else if (A.load_kind == LOAD_KMAJOR) {
         const uint64_t base = (uint64_t)tc.a * A.AS_in + (uint64_t)tc.b * TL + tc.l, ks = A.KS_in;
-        load_all([&](uint32_t n, uint32_t) { return base + (uint64_t)n * ks; });
+        load_ext([&](uint32_t n, uint32_t) { return base + (uint64_t)n * ks; });
     } else if (A.ltab || A.lnseg != 1) {
-        load_all([&](uint32_t n, uint32_t) { return tiled_load_offset<TL>(A, tc, n); });
+        load_ext([&](uint32_t n, uint32_t) { return tiled_load_offset<TL>(A, tc, n); });
     } else {
         const uint64_t len = A.lseg->len[0];
         const uint64_t base = A.lseg->base[0] + (uint64_t)tc.a * (A.IA ? A.IA : len * A.LB) + (uint64_t)tc.b * (A.IB ? A.IB : (uint64_t)TL * len) + tc.l;
         const uint32_t s0 = A.lseg->start[0], tw = tc.tw;
-        load_all([&](uint32_t n, uint32_t) { return base + (uint64_t)(n - s0) * tw; });
+        load_ext([&](uint32_t n, uint32_t) { return base + (uint64_t)(n - s0) * tw; });
     }
     transform<Cfg>(v, lds, W, t, lw, tid);
-    {   // pointwise product with the chirp spectrum, then swap for the inverse transform
-        constexpr int RL = Cfg::RLAST, S = E / RL;
-        static_for<0, E>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
-            const C b = BH[t + k0];
-            C x = v[c];
-            v[c].y = x.x * b.x - x.y * b.y;      // swapped: (im, re)
-            v[c].x = x.x * b.y + x.y * b.x;
-        });
+    if (!plain) {
+        {   // pointwise product with the chirp spectrum, then swap for the inverse transform
+            constexpr int RL = Cfg::RLAST, S = E / RL;
+            static_for<0, E>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
+                const C b = BH[t + k0];
+                C x = v[c];
+                v[c].y = x.x * b.x - x.y * b.y;      // swapped: (im, re)
+                v[c].x = x.x * b.y + x.y * b.x;
+            });
+        }
+        reorder_natural<Cfg>(v, lds, t, lw, tid, Cfg::NPASS > 1);
+        if (Cfg::NPASS > 1) __syncthreads();
+        transform<Cfg>(v, lds, W, t, lw, tid);
     }
-    reorder_natural<Cfg>(v, lds, t, lw, tid, Cfg::NPASS > 1);
-    if (Cfg::NPASS > 1) __syncthreads();
-    transform<Cfg>(v, lds, W, t, lw, tid);
     if (!active) return;
-    const uint32_t kmax = A.real_mode == 1 ? NK : NL;
-    auto store_all = [&](auto offset_of) {
+    // put(k, r): output k of this thread's (sub-)line, after the chirp
+    auto store_all = [&](uint32_t kmax, auto put) {
         constexpr int RL = Cfg::RLAST, S = E / RL;
         static_for<0, E>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
             const uint32_t k = t + k0;
             if (k < kmax) {
-                C x; x.x = v[c].y; x.y = v[c].x;       // swap back
-                const C ch = CH[k];
-                C r; r.x = x.x * ch.x - x.y * ch.y; r.y = x.x * ch.y + x.y * ch.x;
-                if (A.swap) { R tmp = r.x; r.x = r.y; r.y = tmp; }
-                if (A.real_mode == 2) rout[offset_of(k)] = r.x;
-                else out[offset_of(k)] = r;
+                C r = v[c];
+                if (!plain) {
+                    C x; x.x = v[c].y; x.y = v[c].x;       // swap back
+                    const C ch = CH[k];
+                    r.x = x.x * ch.x - x.y * ch.y; r.y = x.x * ch.y + x.y * ch.x;
+                }
+                put(k, r);
             }
+        });
+    };
+    if (lv == 1) {                                       // first level: twiddle, then the scratch
+        C *__restrict__ ws = reinterpret_cast<C *>(A.lvw) + ((uint64_t)w * NL * Q + q) * TL + l;
+        const C *__restrict__ TWN = reinterpret_cast<const C *>(A.lvtw);
+        store_all(NL, [&](uint32_t k, C r) {
+            const C tw = TWN[k * q];
+            C y; y.x = r.x * tw.x - r.y * tw.y; y.y = r.x * tw.y + r.y * tw.x;
+            ws[(uint64_t)k * Q * TL] = y;
+        });
+        return;
+    }
+    const uint32_t kend = A.real_mode == 1 ? NKF : NF;      // points of the line that are stored
+    auto store_ext = [&](auto offset_of) {
+        store_all(lv ? NL : kend, [&](uint32_t k, C r) {
+            const uint32_t kf = lv ? q + Q * k : k;
+            if (lv && kf >= kend) return;
+            if (A.swap) { R tmp = r.x; r.x = r.y; r.y = tmp; }
+            if (A.real_mode == 2) rout[offset_of(kf)] = r.x;
+            else out[offset_of(kf)] = r;
         });
     };
     if (A.store_kind == STORE_LINES) {
         const uint64_t row = A.KS_out ? (uint64_t)tc.a * A.AS_out + ((uint64_t)tc.b * TL + tc.l) * A.KS_out
-                                      : rowline * (A.real_mode == 2 ? NL : kmax);
-        store_all([&](uint32_t k) { return row + k; });
+                                      : rowline * (A.real_mode == 2 ? NF : kend);
+        store_ext([&](uint32_t k) { return row + k; });
     } else if (A.store_kind == STORE_KMAJOR) {
         const uint64_t base = (uint64_t)tc.a * A.AS_out + (uint64_t)tc.b * TL + tc.l, ks = A.KS_out;
-        store_all([&](uint32_t k) { return base + (uint64_t)k * ks; });
+        store_ext([&](uint32_t k) { return base + (uint64_t)k * ks; });
     } else if (A.stab || A.snseg != 1) {
-        store_all([&](uint32_t k) { return generic_store_offset<TL>(A, tc, k, kmax); });
+        store_ext([&](uint32_t k) { return generic_store_offset<TL>(A, tc, k, kend); });
     } else if (A.store_kind == STORE_TILED_TRANSPOSE) {
         const TransposeOne<TL> one(A, tc);
-        store_all([&](uint32_t k) { return one(k); });
+        store_ext([&](uint32_t k) { return one(k); });
     } else {
         const uint64_t base = A.sseg->base[0] + (uint64_t)tc.b * (A.SB ? A.SB : (uint64_t)TL * A.LA) + (uint64_t)tc.a * tc.tw + tc.l;
         const uint64_t step = A.SK ? A.SK : (uint64_t)A.LB * A.LA;
         const uint32_t s0 = A.sseg->start[0];
-        store_all([&](uint32_t k) { return base + (uint64_t)(k - s0) * step; });
+        store_ext([&](uint32_t k) { return base + (uint64_t)(k - s0) * step; });
     }
 }
 

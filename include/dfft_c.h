@@ -265,6 +265,11 @@ const char *dfft_version(void);
 /* kernel configuration for line length N: returns 0 if supported and fills the fields */
 int dfft_kernel_info(int precision, size_t N, int *threads, int *lds_bytes, int *points_per_thread,
                      int *lines_per_workgroup);
+/* how an axis of N points is transformed (the plan cufftMakePlanMany64 hides, mpicufft_pencil_opt1.cpp:165-197): returns 0 and fills
+ * info[0] = 0 native chain / 1 Bluestein / 2 two levels (N = N1*N2 over two launches), info[1] = inner power-of-two length (0 for
+ * two levels), and for two levels info[2..4] = {N1, its inner length, 1 if Bluestein} and info[5..7] likewise for N2.
+ * two_level = 1: two levels wherever N splits (the plan option of the same name).  ERR_UNSUPPORTED: no plan (a prime above 4096 ...). */
+int dfft_axis_plan_info(int precision, size_t N, int two_level, size_t info[8]);
 
 /* ---- placement-aware device memory (no counterpart in the reference, whose buffers are plain cudaMalloc,
  * src/pencil/mpicufft_pencil_opt1.cpp:344-365; the analogue of fftw_malloc + FFTW_MEASURE) ----------------

@@ -54,7 +54,37 @@ def test_kernel_table():
         # every other length runs through Bluestein on the next power of two >= 2N-1 (N <= 4096)
         assert dfft.kernel_info(3, prec)["points_per_thread"] == 8 and dfft.kernel_info(1023, prec)["threads"] > 0
         assert dfft.kernel_info(1025, prec)["threads"] > 0 and dfft.kernel_info(4095, prec)["threads"] > 0
-        assert dfft.kernel_info(16384, prec) is None and dfft.kernel_info(4097, prec) is None
+        # beyond that: two-level lines N = N1*N2 (each factor within reach of the generic kernel); a prime above 4096 has no plan
+        assert dfft.kernel_info(16384, prec)["threads"] > 0 and dfft.kernel_info(5000, prec)["threads"] > 0
+        assert dfft.kernel_info(4099, prec) is None and dfft.kernel_info(2 * 4099, prec) is None
+
+
+def test_axis_plans_cover_every_length_the_factors_allow():
+    """dfft_axis_plan_info: native chain / Bluestein / two levels.  Every length up to 4096 has a plan, powers of two up to 8192
+    have the native one, and beyond that exactly the lengths N1*N2 whose factors are each within reach of the generic kernel
+    (the reference takes any length through cufftMakePlanMany64, mpicufft_pencil_opt1.cpp:165-197)."""
+    def reach(f):      # one launch of the generic kernel: plain power of two <= 8192, or Bluestein with 2f-1 <= 8192
+        return f >= 2 and ((f & (f - 1)) == 0 and f <= 8192 or 2 * f - 1 <= 8192)
+    for prec in ("double", "float"):
+        for n in list(range(2, 4097)) + [8192]:
+            info = dfft.axis_plan_info(n, prec)
+            assert info and info["kind"] in ("native", "bluestein"), n      # no regression: these keep their one-launch plans
+        for n in list(range(4097, 4400)) + [5000, 6000, 8190, 8194, 9999, 10000, 12288, 16384, 65536, 100000, 131072, 3 * 4093,
+                                            4099, 2 * 4099, 4093 * 4093, 4096 * 4096, 4096 * 4096 + 2, 1 << 25]:
+            info = dfft.axis_plan_info(n, prec)
+            splits = [d for d in range(2, int(n ** 0.5) + 1) if n % d == 0 and reach(d) and reach(n // d)] if n <= 1 << 24 else []
+            assert (info is not None) == bool(splits), n
+            if info:
+                assert info["kind"] == "two_level" and info["M"] == 0
+                (n1, m1, b1), (n2, m2, b2) = info["levels"]
+                assert n1 * n2 == n and reach(n1) and reach(n2)
+                for f, m, b in info["levels"]:
+                    assert (m == f and f & (f - 1) == 0) if not b else (m & (m - 1) == 0 and m >= 2 * f - 1 and m < 2 * (2 * f - 1))
+        # the option / variant that forces two levels: every composite length splits, primes keep their plan
+        for n in (4, 6, 15, 64, 1000, 1024, 1155, 4096):
+            info = dfft.axis_plan_info(n, prec, two_level=1)
+            assert info["kind"] == "two_level" and info["levels"][0][0] * info["levels"][1][0] == n
+        assert dfft.axis_plan_info(127, prec, two_level=1)["kind"] == "bluestein" and dfft.axis_plan_info(2, prec, two_level=1)["kind"] == "native"
 
 
 def test_in_register_butterflies_on_the_host(tmp_path):
@@ -200,7 +230,7 @@ def test_init_errors():
     with pytest.raises(dfft.DfftError, match="Invalid Input Partition"):
         pl.initFFT(dfft.GlobalSize(16, 16, 16), dfft.Slab_Partition(2), allocate=False)
     with pytest.raises(dfft.DfftError, match="unsupported"):
-        pl.initFFT(dfft.GlobalSize(16, 16, 5000), dfft.Slab_Partition(1), allocate=False, c2c=True)
+        pl.initFFT(dfft.GlobalSize(16, 16, 4099), dfft.Slab_Partition(1), allocate=False, c2c=True)      # a prime above 4096
     world = dfft.Comm.local(4)
     ps = dfft.MPIcuFFT_Slab_Opt1(dfft.Configurations(), world, rank=0)
     with pytest.raises(dfft.DfftError, match="slab"):

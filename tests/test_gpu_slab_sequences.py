@@ -22,7 +22,7 @@ NPC = {"double": np.complex128, "float": np.complex64}
 NPR = {"double": np.float64, "float": np.float32}
 
 
-def run(cls, shape, P, prec, c2c, chunks=None, field=None, modify=None, seed=21):
+def run(cls, shape, P, prec, c2c, chunks=None, field=None, modify=None, seed=21, options=None):
     world = dfft.Comm.local(P) if P > 1 else None
     esz = 16 if prec == "double" else 8
     plans, ins, outs, backs, host_ins = [], [], [], [], []
@@ -30,6 +30,8 @@ def run(cls, shape, P, prec, c2c, chunks=None, field=None, modify=None, seed=21)
         pl = cls(dfft.Configurations(), world, precision=prec, rank=r)
         if chunks is not None:
             pl.setPipelineChunks(chunks)
+        for k, v in (options or {}).items():
+            pl.setOption(k, v)
         pl.initFFT(dfft.GlobalSize(*shape), dfft.Slab_Partition(P), True, c2c=c2c)
         size, start = pl.getInSize(), pl.getInStart()
         assert tuple(size[1:]) == tuple(shape[1:]) and tuple(start[1:]) == (0, 0)
@@ -159,7 +161,7 @@ def test_z_then_yx_errors_and_single_rank():
 # ------------------------------------------------------------------------------------------
 # Y_Then_ZX (src/slab/y_then_zx/): R2C along y, output [Nx][(Ny/2+1)/P][Nz], forward only
 # ------------------------------------------------------------------------------------------
-def run_yzx(shape, P, prec, c2c, chunks=None, seed=33):
+def run_yzx(shape, P, prec, c2c, chunks=None, seed=33, options=None):
     world = dfft.Comm.local(P) if P > 1 else None
     esz = 16 if prec == "double" else 8
     plans, ins, outs, host_ins = [], [], [], []
@@ -167,6 +169,8 @@ def run_yzx(shape, P, prec, c2c, chunks=None, seed=33):
         pl = dfft.MPIcuFFT_Slab_Y_Then_ZX(dfft.Configurations(), world, precision=prec, rank=r)
         if chunks is not None:
             pl.setPipelineChunks(chunks)
+        for k, v in (options or {}).items():
+            pl.setOption(k, v)
         pl.initFFT(dfft.GlobalSize(*shape), dfft.Slab_Partition(P), True, c2c=c2c)
         size, start = pl.getInSize(), pl.getInStart()
         blk = orc.fill_block(shape, start, size, 2 if c2c else 1, seed=seed).astype(NPC[prec] if c2c else NPR[prec])
@@ -225,8 +229,8 @@ def test_y_then_zx_pipeline_depths_tables_and_errors(chunks):
     with pytest.raises(dfft.DfftError, match="forward only"):
         plans[0].execC2R(1, 1)
     one = dfft.MPIcuFFT_Slab_Y_Then_ZX(dfft.Configurations())
-    with pytest.raises(dfft.DfftError, match="Ny up to 4096"):      # not a power of two and beyond the Bluestein kernel
-        one.initFFT(dfft.GlobalSize(16, 5000, 16), dfft.Slab_Partition(1), True)
+    with pytest.raises(dfft.DfftError, match="unsupported axis length"):      # a prime above 4096: beyond the Bluestein kernel, no two-level split
+        one.initFFT(dfft.GlobalSize(16, 4099, 16), dfft.Slab_Partition(1), True)
 
 
 @pytest.mark.parametrize("prec", ["double", "float"])
