@@ -824,12 +824,19 @@ static int launch_generic(int prec, const Axis &ax, PassArgs &A, hipStream_t s)
 
 // two-level line (fft_pass.hip.h): level 1 through the pass's load form into the scratch, level 2 from the scratch through its
 // store form.  real_mode / NK as for a one-launch generic pass.
-static int launch_two_level(int prec, const Axis &ax, PassArgs A, int real_mode, size_t NK, void *scratch, hipStream_t s)
+static int launch_two_level(int prec, const Axis &ax, PassArgs A, int real_mode, size_t NK, void *scratch, int TL, hipStream_t s)
 {
     A.lvN = (uint32_t)ax.N; A.lvNK = (uint32_t)NK; A.NK = (uint32_t)NK; A.real_mode = real_mode; A.lvtw = ax.twN; A.lvw = scratch;
+    // lanes over the lines of a tile, or over neighbouring sub-lines of one line where the level's outer side has natural lines;
+    // the scratch layout that keeps both levels in runs (fft_pass.hip.h)
+    const bool q1 = A.load_kind == LOAD_LINES, q2 = A.store_kind == STORE_LINES;
+    const uint32_t N1 = (uint32_t)ax.lv[0].N, N2 = (uint32_t)ax.lv[1].N;
+    if (!q1 && !q2) { A.lvlay = 0; A.lvs1 = N2 * (uint32_t)TL; A.lvs2 = (uint32_t)TL; }
+    else if (q1) { A.lvlay = 1; A.lvs1 = N2; A.lvs2 = 1; }
+    else { A.lvlay = 1; A.lvs1 = 1; A.lvs2 = N1; }
     for (int level = 1; level <= 2; level++) {
         PassArgs B = A;
-        B.lv = level; B.lvQ = (uint32_t)ax.lv[2 - level].N;
+        B.lv = level; B.lvQ = (uint32_t)ax.lv[2 - level].N; B.lvqm = level == 1 ? q1 : q2;
         const int r = launch_generic(prec, ax.lv[level - 1], B, s);
         if (r != 0) return fail(r == -1 ? ERR_UNSUPPORTED : r, "two-level pass launch failed for length " + std::to_string(ax.N));
     }
@@ -857,7 +864,7 @@ static int launch(dfft_plan *p, const Launch &L, int variant, int axis, const ch
     if (!ax.bluestein) return launch_pass(p->prec, (int)ax.N, variant, A, p->stream);
     if (ax.two) {
         if (two_level_bytes(A, p->TL, ax.N, p->esz) > p->lv_bytes) return fail(ERR_STATE, "two-level pass: scratch region too small");
-        return launch_two_level(p->prec, ax, A, real_lines ? 1 : 0, real_lines ? ax.N / 2 + 1 : ax.N, static_cast<char *>(p->work_d) + p->lv_off, p->stream);
+        return launch_two_level(p->prec, ax, A, real_lines ? 1 : 0, real_lines ? ax.N / 2 + 1 : ax.N, static_cast<char *>(p->work_d) + p->lv_off, p->TL, p->stream);
     }
     A.NK = (uint32_t)ax.N; A.real_mode = 0;
     if (real_lines) { A.real_mode = 1; A.NK = (uint32_t)(ax.N / 2 + 1); }     // real in, Hermitian half out
@@ -884,7 +891,7 @@ static int launch_real(dfft_plan *p, const Launch &L, int mode, const char *in, 
         return fail(ERR_UNSUPPORTED, "real z pass without a native or Bluestein plan");      // (dfft_init rules this out)
     } else if (ax.two) {
         if (two_level_bytes(A, p->TL, ax.N, p->esz) > p->lv_bytes) return fail(ERR_STATE, "two-level pass: scratch region too small");
-        return launch_two_level(p->prec, ax, A, mode, p->Nzc, static_cast<char *>(p->work_d) + p->lv_off, p->stream);
+        return launch_two_level(p->prec, ax, A, mode, p->Nzc, static_cast<char *>(p->work_d) + p->lv_off, p->TL, p->stream);
     } else {
         A.NK = (uint32_t)p->Nzc; A.real_mode = mode;
         r = launch_generic(p->prec, ax, A, p->stream);
@@ -2170,7 +2177,7 @@ int dfft_fft1d_batched_ex(int precision, size_t N, size_t batch, void *out, cons
             HIP_TRY(hipMalloc(&lvw, need));
             lvw_bytes = need;
         }
-        return launch_two_level(precision, ax, A, 0, N, lvw, (hipStream_t)hip_stream);
+        return launch_two_level(precision, ax, A, 0, N, lvw, pi.TL, (hipStream_t)hip_stream);
     }
     A.NK = (uint32_t)N;
     int r = launch_generic(precision, ax, A, (hipStream_t)hip_stream);

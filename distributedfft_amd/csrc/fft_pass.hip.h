@@ -107,6 +107,9 @@ struct PassArgs {
     uint32_t lvN, lvNK;    // the line's length and its points on the spectral side of a real transform (as NL / NK of a one-launch pass)
     const void *lvtw;      // exp(-2*pi*i*j/lvN), lvN entries: twiddles between the levels
     void *lvw;             // scratch between the levels: ntiles * TL * lvN elements
+    int32_t lvqm;          // this level's lanes run over neighbouring sub-lines of one line (its outer side has natural lines)
+    int32_t lvlay;         // scratch layout: 0 tiled ((w*N1 + i1)*N2 + i2)*TL + l, 1 per line: line*lvN + i1*lvs1 + i2*lvs2
+    uint32_t lvs1, lvs2;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1500,8 +1503,12 @@ __device__ __forceinline__ void reorder_natural(typename Cfg::C *v, typename Cfg
 //            own load address form; N1-point transform; times exp(-2 pi i k1 n2 / N) (lvtw); stored to the scratch lvw
 //   level 2 (lv = 2, NL = N2, lvQ = N1): sub-line q = k1 from the scratch; N2-point transform; output k2 is the line's point
 //            k = k1 + N1*k2, stored through the pass's own store address form
-// so that unpack / transpose / pack stay fused exactly as for a one-launch pass, whatever the layouts.  Scratch layout:
-// element (tile w, k1, n2, line l of the tile) at ((w*N1 + k1)*N2 + n2)*TL + l -- 128-byte runs for level 1, contiguous for level 2.
+// so that unpack / transpose / pack stay fused exactly as for a one-launch pass, whatever the layouts.  The lanes of a kernel
+// tile run over the TL lines of a tile of the pass (outer side tiled or point-major: 128-byte runs) or over TL neighbouring
+// sub-lines of one line (outer side natural lines: contiguous points), PassArgs::lvqm, per level.  Scratch layout by the pair:
+//   both over lines:                 tiled, element (tile w, k1, n2, line l) at ((w*N1 + k1)*N2 + n2)*TL + l
+//   level 1 over sub-lines:          [line][k1][n2] -- level 1 stores runs over n2, level 2 reads runs over n2 (its threads of a line)
+//   level 2 only over sub-lines:     [line][n2][k1] -- level 1 stores runs over k1 (its threads of a line), level 2 reads runs over k1
 // Each level is either the plain chain (PassArgs::plain: NL == Cfg::kN, a power of two) or Bluestein on an arbitrary factor.
 // Real lines: level 1 reads the real line / rebuilds the full spectrum from the Hermitian half, level 2 keeps the half /
 // the real parts (the full complex transform of the line, as in the one-launch real modes).
@@ -1527,19 +1534,36 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_bluestein_kernel(const PassA
         w = logical_block<>(A) * Cfg::kG + lw / TL;
         l = lw % TL;
     }
-    // two-level lines: the launch's tiles are (tile, sub-line) pairs, sub-line fastest
+    // two-level lines: the launch's tiles are (tile, sub-line) pairs, sub-line fastest -- or, where the level's outer side has
+    // natural lines (lvqm), (line, block of TL sub-lines) pairs: the lanes of a tile then run over neighbouring sub-lines of ONE
+    // line, i.e. over contiguous points of the natural line, instead of over the lines of a tile
     const int lv = A.lv;
+    const bool qm = lv && A.lvqm;
     const uint32_t Q = lv ? A.lvQ : 1u;
-    const uint32_t q = lv ? w % Q : 0u;
-    if (lv) w /= Q;
-    const bool tile_ok = w < A.ntiles;
+    uint32_t q = 0;
     TileCtx<TL> tc;
-    tc.a = !tile_ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
-    tc.b = !tile_ok ? 0 : (A.a_fastest ? w / A.na : w % A.nb);
-    tc.l = l;
-    const uint32_t rem = A.LB - tc.b * TL;
-    tc.tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;
-    const bool active = tile_ok && (uint32_t)l < tc.tw;
+    bool active;
+    if (!qm) {
+        if (lv) { q = w % Q; w /= Q; }
+        const bool tile_ok = w < A.ntiles;
+        tc.a = !tile_ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
+        tc.b = !tile_ok ? 0 : (A.a_fastest ? w / A.na : w % A.nb);
+        tc.l = l;
+        const uint32_t rem = A.LB - tc.b * TL;
+        tc.tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;
+        active = tile_ok && (uint32_t)l < tc.tw;
+    } else {
+        const uint32_t QB = (Q + TL - 1) / TL;
+        const uint32_t lam = w / QB;                    // line a*LB + (b*TL + l)
+        q = (w % QB) * TL + (uint32_t)l;
+        active = lam < A.na * A.LB && q < Q;
+        const uint32_t r = active ? lam % A.LB : 0u;
+        tc.a = active ? lam / A.LB : 0u;
+        tc.b = r / TL;
+        tc.l = (int)(r % TL);
+        const uint32_t rem = A.LB - tc.b * TL;
+        tc.tw = rem < (uint32_t)TL ? rem : (uint32_t)TL;
+    }
     const uint32_t NL = A.NL;
     // the line as the pass's address forms see it: its length, its points on the spectral side of a real transform
     const uint32_t NF = lv ? A.lvN : NL, NKF = lv ? A.lvNK : A.NK;
@@ -1594,9 +1618,13 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_bluestein_kernel(const PassA
         });
     };
     const uint64_t rowline = (uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + tc.l;
-    if (lv == 2) {                                       // second level: sub-line q of the scratch
-        const C *__restrict__ ws = reinterpret_cast<const C *>(A.lvw) + (((uint64_t)w * Q + q) * NL) * TL + l;
-        load_all([&](uint32_t n) { return ws[(uint64_t)n * TL]; });
+    // scratch element (i1, i2) of this thread's line: tiled (lvlay 0, both levels with lanes over the lines of a tile) at
+    // ((w*N1 + i1)*N2 + i2)*TL + l, else in the line's own N points at i1*lvs1 + i2*lvs2
+    const uint64_t sbase = A.lvlay == 0 ? (uint64_t)w * NF * TL + (uint32_t)l : rowline * NF;
+    if (lv == 2) {                                       // second level: sub-line q = i1 of the scratch
+        const C *__restrict__ ws = reinterpret_cast<const C *>(A.lvw) + sbase + (uint64_t)q * A.lvs1;
+        const uint64_t s2 = A.lvs2;
+        load_all([&](uint32_t n) { return ws[(uint64_t)n * s2]; });
     } else if (A.load_kind == LOAD_LINES && A.KS_in) {          // strided natural-line rows
         const uint64_t row = (uint64_t)tc.a * A.AS_in + ((uint64_t)tc.b * TL + tc.l) * A.KS_in;
         load_ext([&](uint32_t n, uint32_t) { return row + n; });
@@ -1650,12 +1678,13 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_bluestein_kernel(const PassA
         });
     };
     if (lv == 1) {                                       // first level: twiddle, then the scratch
-        C *__restrict__ ws = reinterpret_cast<C *>(A.lvw) + ((uint64_t)w * NL * Q + q) * TL + l;
+        C *__restrict__ ws = reinterpret_cast<C *>(A.lvw) + sbase + (uint64_t)q * A.lvs2;      // sub-line q = i2
+        const uint64_t s1 = A.lvs1;
         const C *__restrict__ TWN = reinterpret_cast<const C *>(A.lvtw);
         store_all(NL, [&](uint32_t k, C r) {
             const C tw = TWN[k * q];
             C y; y.x = r.x * tw.x - r.y * tw.y; y.y = r.x * tw.y + r.y * tw.x;
-            ws[(uint64_t)k * Q * TL] = y;
+            ws[(uint64_t)k * s1] = y;
         });
         return;
     }

@@ -49,7 +49,7 @@ enum dfft_kind {
     DFFT_SLAB_Z_THEN_YX = 4,       /* MPIcuFFT_Slab_Z_Then_YX      include/mpicufft_slab_z_then_yx.hpp      */
     DFFT_SLAB_Z_THEN_YX_OPT1 = 5,  /* MPIcuFFT_Slab_Z_Then_YX_Opt1 include/mpicufft_slab_z_then_yx_opt1.hpp */
     /* forward only, like the reference: R2C along y, one all-to-all, 2-D (z,x) pass.  Output
-     * [Nx][(Ny/2+1)/P][Nz] (include/mpicufft_slab_y_then_zx.hpp:40-43).  R2C plans: Ny a power of two up to 2048, or any Ny <= 4096.  Unlike
+     * [Nx][(Ny/2+1)/P][Nz] (include/mpicufft_slab_y_then_zx.hpp:40-43).  R2C plans: any Ny dfft_init accepts.  Unlike
      * the reference's single-rank branch (a z-Hermitian cufftPlan3d, mpicufft_slab_y_then_zx.cpp:111-121),
      * one rank produces the same y-Hermitian layout as several. */
     DFFT_SLAB_Y_THEN_ZX = 6        /* MPIcuFFT_Slab_Y_Then_ZX      include/mpicufft_slab_y_then_zx.hpp      */
@@ -113,8 +113,10 @@ int dfft_plan_destroy(dfft_plan *plan);
 /* initFFT(GlobalSize*, Partition*, bool allocate)   include/mpicufft.hpp:60,
  * src/pencil/mpicufft_pencil_opt1.cpp:46-326, src/slab/default/mpicufft_slab.cpp:97-281.
  * P1*P2 must equal the number of ranks.  Axis lengths: powers of two up to 8192 (4096 on the real axis of an R2C
- * plan) and the lengths 2^a 3^b 5^c 7^d <= 2048 listed in csrc/kernels_mixed.inc (native chain), or any other length
- * up to 4096 (Bluestein).  c2c = 0: R2C/C2R plan (Nz_out = Nz/2+1,
+ * plan) and the lengths 2^a 3^b 5^c 7^d <= 2048 listed in csrc/kernels_mixed.inc (native chain), any other length
+ * up to 4096 (Bluestein), and beyond that every length N1*N2 <= 2^24 whose factors are each such a length (two-level
+ * lines: two launches per pass and a scratch region in the work area, dfft_axis_plan_info shows the split); a length
+ * that does not split that way (e.g. a prime factor above 4096) is ERR_UNSUPPORTED.  c2c = 0: R2C/C2R plan (Nz_out = Nz/2+1,
  * include/params.hpp:30); c2c = 1: complex plan (Nz_out = Nz). */
 int dfft_init(dfft_plan *plan, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int c2c, int allocate);
 /* setWorkArea(void *device, void *host)   mpicufft_pencil_opt1.cpp:329-387.  NULL device =

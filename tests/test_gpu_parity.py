@@ -261,7 +261,9 @@ def test_pipelined_exchange_chunks(shape, P1, P2, chunks):
 @pytest.mark.parametrize("c2c", [False, True])
 @pytest.mark.parametrize("shape,P1,P2", [((16, 16, 16), 1, 1), ((32, 32, 32), 2, 4), ((16, 32, 64), 3, 2), ((64, 32, 16), 4, 1)])
 @pytest.mark.parametrize("d", [1, 2])
-def test_partial_dimension_transforms(shape, P1, P2, d, c2c):
+@pytest.mark.parametrize("two_level", [0, 1])
+def test_partial_dimension_transforms(shape, P1, P2, d, c2c, two_level):
+    """execR2C / execC2R(out, in, d) (src/pencil/mpicufft_pencil.cpp:1644-1839); two_level = 1: the same on two-level lines"""
     P = P1 * P2
     world = dfft.Comm.local(P) if P > 1 else None
     Nx, Ny, Nz = shape
@@ -274,6 +276,7 @@ def test_partial_dimension_transforms(shape, P1, P2, d, c2c):
     plans, ins, outs, backs = [], [], [], []
     for r in range(P):
         pl = dfft.MPIcuFFT_Pencil(dfft.Configurations(), world, precision="double", rank=r)
+        pl.setOption("two_level", two_level)
         pl.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(P1, P2), True, c2c=c2c)
         s, o = pl.getInSize(), pl.getInStart()
         blk = np.ascontiguousarray(g[o[0]:o[0] + s[0], o[1]:o[1] + s[1], :])
