@@ -2253,8 +2253,68 @@ static int placement_measure(dfft_plan *p, const void *in, void *out, void *back
 // tuned backings the x pass goes 5.66 -> 5.44 ms (profiles/r3_yx_variants_on_tuned_buffers.txt); at fp32 2048 points they take
 // a quarter off two passes of the 8-GPU plan and double another (profiles/r3_f32_2048_tiled_variants.txt).
 static int stream_sibling(int role) { return role == ROLE_DEFAULT ? ROLE_STREAM : role == ROLE_TILED ? ROLE_TILED_STREAM : -1; }
+
+// The workgroup -> tile order of every pass (PassArgs::a_fastest, xcd_swizzle: which tiles are in flight together, and on which
+// XCD's L2 neighbours meet), chosen by measurement like the configurations below.  The rules of build_pipeline were fitted on the
+// single-GPU 1024^3 plan; on the per-GPU plans of the 8-GPU grids other orders win some passes (rank 0 of 2 x 4 at 1024^3 fp64:
+// y 1.02 -> 0.88 ms with a fastest, x 0.86 -> 0.82, x^-1 1.02 -> 1.00; 2048^3 fp32: x 3.91 -> 3.79, x^-1 5.55 -> 5.42;
+// profiles/r3_pass_orders_8gpu_plans.txt).  Four trial settings -- every pass in order 0, 1, 2, 3 --, per-pass times from the
+// phase timers, so each pass picks its own order from the same four executions; the number of executions does not depend on
+// the rank (collective safety), the choices are each rank's own.
+static int tune_orders(dfft_plan *p, const void *in, void *o, void *b, const std::function<void(float)> &note)
+{
+    if (p->zyx || p->yzx) return 0;                 // the slab sequences keep their rules
+    Pipeline &pl = p->pl;
+    const bool single = pl.single && !p->opt.mirror && p->c2c;      // z, x, y order of one rank: forward and inverse share three launches
+    const bool one_chain = p->nranks == 1 && !p->opt.mirror && p->c2c;   // a single rank's complex inverse runs the forward chain
+    std::vector<Launch> *vecs[6] = {&pl.fz, &pl.fy, nullptr, &pl.ix, &pl.iy, &pl.iz};
+    auto launches = [&](int k, const std::function<void(Launch &)> &f) {
+        if (single) { if (k < 3) f(k == 0 ? pl.sz : k == 1 ? pl.sy : pl.sx); return; }
+        if (k == 2) f(pl.fx); else for (auto &L : *vecs[k]) f(L);
+    };
+    int keep[6], pick[6];
+    float t[4][6];
+    for (int k = 0; k < 6; k++) {
+        keep[k] = -1;
+        launches(k, [&](Launch &L) { if (keep[k] < 0) keep[k] = (L.args.a_fastest ? 1 : 0) + (L.args.xcd_swizzle ? 2 : 0); });
+        pick[k] = keep[k];
+    }
+    auto apply = [&](int k, int d) { launches(k, [&](Launch &L) { L.args.a_fastest = d & 1; L.args.xcd_swizzle = (d >> 1) & 1; }); };
+    auto tunable = [&](int k) { return keep[k] >= 0 && p->opt.order[k] < 0 && !(k >= 3 && (!b || one_chain)); };
+    for (int d = 0; d < 4; d++) {
+        for (int k = 0; k < 6; k++) if (tunable(k)) apply(k, d);
+        for (int k = 0; k < 6; k++) t[d][k] = 1e30f;
+        float total = 1e30f;
+        for (int rep = 0; rep < 3; rep++) {            // first execution untimed in effect: the minimum of three
+            float ph[5], sum = 0;
+            if (p->c2c) TRY(dfft_exec_c2c(p, o, const_cast<void *>(in), DFFT_FORWARD)); else TRY(dfft_exec_r2c(p, o, in));
+            int n = dfft_get_phase_times(p, ph, 5);
+            for (int i = 0; i < n && i < 5; i += 2) { t[d][i / 2] = std::min(t[d][i / 2], ph[i]); sum += ph[i]; }
+            if (b) {
+                if (p->c2c) TRY(dfft_exec_c2c(p, b, o, DFFT_INVERSE)); else TRY(dfft_exec_c2r(p, b, o));
+                n = dfft_get_phase_times(p, ph, 5);
+                for (int i = 0; i < n && i < 5; i += 2) { t[d][3 + i / 2] = std::min(t[d][3 + i / 2], ph[i]); sum += ph[i]; }
+            }
+            total = std::min(total, sum);
+        }
+        note(total);
+    }
+    for (int k = 0; k < 6; k++) {
+        if (!tunable(k)) continue;
+        // a single rank's z, x, y order shares its launches between the directions: judge a pass by both
+        auto cost = [&](int d) { return single && b ? t[d][k] + t[d][5 - k] : t[d][k]; };
+        for (int d = 0; d < 4; d++)
+            if (cost(d) < 0.99f * cost(pick[k]) && cost(d) < 1e29f) pick[k] = d;
+        apply(k, pick[k]);
+    }
+    return 0;
+}
+
 static int tune_variants(dfft_plan *p, const void *in, void *o, void *b, float &best, const std::function<void(float)> &note)
 {
+    TRY(tune_orders(p, in, o, b, note));
+    TRY(placement_measure(p, in, o, b, 2, &best));      // the reference time of the configuration trials: the chosen orders
+    note(best);
     auto exists = [&](int axis, int role) {
         PassInfo pi;
         return role >= 0 && (p->prec == DFFT_F64 ? pass_info_f64((int)p->ax[axis].N, role, &pi) : pass_info_f32((int)p->ax[axis].N, role, &pi));
