@@ -327,8 +327,9 @@ def main():
                 trial_ms = plan.tuneVariants(d_in, d_out, None if aliased else d_back)
             variants = {"trial_fft_ms": [round(v, 3) for v in trial_ms],
                         "what": "dfft_tune_variants before the warm-up: first entry = the plan as built (rule-based workgroup orders and kernel "
-                                "configurations), then the four workgroup-order settings (each pass keeps its fastest), the chosen orders, then one entry "
-                                "per y / x pass that has a streaming (nontemporal) sibling; a sibling is kept when the pass time drops by more than 0.3 %"}
+                                "configurations), then the four workgroup-order settings (each pass keeps its fastest), the chosen orders, one entry per "
+                                "kernel-configuration number of the plan's line lengths (each pass keeps a configuration that is more than 1 % faster), "
+                                "the final choice"}
         except Exception as e:   # noqa: BLE001
             variants = {"error": str(e)}
 

@@ -247,7 +247,7 @@ class MPIcuFFT:
         (want_back) a new buffer for the inverse transform's output, and keeps for each the one this plan's own passes run
         fastest on.  `in_` must hold a valid input block.  Returns (out, back or None, [ms of every trial])."""
         o, b = C.c_void_p(), C.c_void_p()
-        rep = (C.c_float * (3 * max(1, int(tries)) + 16))()
+        rep = (C.c_float * (3 * max(1, int(tries)) + 32))()
         n = C.c_int(0)
         check(lib().dfft_tune_placement(self._h, _ptr(in_), int(tries), C.byref(o), C.byref(b) if want_back else None, rep, len(rep), C.byref(n)))
         isz = self.getInSize()
@@ -258,10 +258,10 @@ class MPIcuFFT:
         return out, back, [float(rep[i]) for i in range(n.value)]
 
     def tuneVariants(self, in_, out, back=None):
-        """dfft_tune_variants: every pass tries the four workgroup orders, the y / x passes the streaming sibling of their kernel
-        configuration, on these buffers; a pass keeps what runs faster here.  Returns the measured FFT ms (forward + inverse) of every
-        trial: the plan as built, the four order settings, the chosen orders, then one entry per sibling trial."""
-        rep = (C.c_float * 16)()
+        """dfft_tune_variants: every pass tries the four workgroup orders and every kernel configuration of its length on these
+        buffers and keeps what runs faster here.  Returns the measured FFT ms (forward + inverse) of every trial: the plan as built,
+        the four order settings, the chosen orders, one entry per configuration number, the final choice."""
+        rep = (C.c_float * 32)()
         n = C.c_int(0)
         check(lib().dfft_tune_variants(self._h, _ptr(in_), _ptr(out), _ptr(back), rep, len(rep), C.byref(n)))
         return [float(rep[i]) for i in range(n.value)]

@@ -2252,90 +2252,119 @@ static int placement_measure(dfft_plan *p, const void *in, void *out, void *back
 // buffers: on plain hipMalloc buffers they gained nothing repeatable on the 128-byte-run stores of 1024^3 fp64 (round 2), on
 // tuned backings the x pass goes 5.66 -> 5.44 ms (profiles/r3_yx_variants_on_tuned_buffers.txt); at fp32 2048 points they take
 // a quarter off two passes of the 8-GPU plan and double another (profiles/r3_f32_2048_tiled_variants.txt).
-static int stream_sibling(int role) { return role == ROLE_DEFAULT ? ROLE_STREAM : role == ROLE_TILED ? ROLE_TILED_STREAM : -1; }
+// One trial of the tuners below: the plan executes forward in -> o and, if b, inverse o -> b three times; t[0..5] receive the
+// smallest time of every pass (fz fy fx ix iy iz, from the phase timers), *total their smallest sum.
+static int tune_trial(dfft_plan *p, const void *in, void *o, void *b, float t[6], float *total)
+{
+    for (int k = 0; k < 6; k++) t[k] = 1e30f;
+    *total = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+        float ph[5], sum = 0;
+        if (p->c2c) TRY(dfft_exec_c2c(p, o, const_cast<void *>(in), DFFT_FORWARD)); else TRY(dfft_exec_r2c(p, o, in));
+        int n = dfft_get_phase_times(p, ph, 5);
+        for (int i = 0; i < n && i < 5; i += 2) { t[i / 2] = std::min(t[i / 2], ph[i]); sum += ph[i]; }
+        if (b) {
+            if (p->c2c) TRY(dfft_exec_c2c(p, b, o, DFFT_INVERSE)); else TRY(dfft_exec_c2r(p, b, o));
+            n = dfft_get_phase_times(p, ph, 5);
+            for (int i = 0; i < n && i < 5; i += 2) { t[3 + i / 2] = std::min(t[3 + i / 2], ph[i]); sum += ph[i]; }
+        }
+        *total = std::min(*total, sum);
+    }
+    return 0;
+}
 
 // The workgroup -> tile order of every pass (PassArgs::a_fastest, xcd_swizzle: which tiles are in flight together, and on which
-// XCD's L2 neighbours meet), chosen by measurement like the configurations below.  The rules of build_pipeline were fitted on the
-// single-GPU 1024^3 plan; on the per-GPU plans of the 8-GPU grids other orders win some passes (rank 0 of 2 x 4 at 1024^3 fp64:
-// y 1.02 -> 0.88 ms with a fastest, x 0.86 -> 0.82, x^-1 1.02 -> 1.00; 2048^3 fp32: x 3.91 -> 3.79, x^-1 5.55 -> 5.42;
-// profiles/r3_pass_orders_8gpu_plans.txt).  Four trial settings -- every pass in order 0, 1, 2, 3 --, per-pass times from the
-// phase timers, so each pass picks its own order from the same four executions; the number of executions does not depend on
-// the rank (collective safety), the choices are each rank's own.
-static int tune_orders(dfft_plan *p, const void *in, void *o, void *b, const std::function<void(float)> &note)
+// XCD's L2 neighbours meet) and its kernel configuration (the variants of its length: streaming siblings, other lane mappings,
+// other tile shapes), chosen by measurement on the buffers the plan will run on.  The rules of build_pipeline / dfft_init were
+// fitted on the single-GPU 1024^3 plans; on the per-GPU plans of the 8-GPU grids other choices win some passes (rank 0 of 2 x 4 at
+// 1024^3 fp64: y 1.02 -> 0.88 ms with a-fastest tiles; 2048^3 fp32: y 4.89 -> 3.86 ms with the streaming configuration, y^-1
+// 5.59 -> 4.73 with the point-fastest store mapping on half tiles; profiles/r3_pass_orders_8gpu_plans.txt,
+// r3_pass_variants_8gpu_plans.txt) -- and whether the nontemporal hints pay depends on the pass, the layout and the physical backing
+// (profiles/r3_yx_variants_on_tuned_buffers.txt, r3_f32_2048_tiled_variants.txt).
+// A trial sets EVERY pass to order d (to variant v) at once and reads the per-pass times from the phase timers, so each pass
+// picks for itself from the same few executions: 4 order settings, then one setting per variant number that any axis length of
+// the plan has.  Which trials run depends on the global grid only, never on the rank (every trial executes the plan, exchanges
+// included: collective safety); the choices are each rank's own.  Passes the caller pinned (order_* / variant_*) are left alone.
+static int tune_variants(dfft_plan *p, const void *in, void *o, void *b, float &best, const std::function<void(float)> &note)
 {
     if (p->zyx || p->yzx) return 0;                 // the slab sequences keep their rules
     Pipeline &pl = p->pl;
-    const bool single = pl.single && !p->opt.mirror && p->c2c;      // z, x, y order of one rank: forward and inverse share three launches
-    const bool one_chain = p->nranks == 1 && !p->opt.mirror && p->c2c;   // a single rank's complex inverse runs the forward chain
+    const bool shared = p->nranks == 1 && !p->opt.mirror && p->c2c;      // a single rank's complex inverse runs the forward launches
+    const bool single = pl.single && shared;                            // ... in the z, x, y order (three launches)
     std::vector<Launch> *vecs[6] = {&pl.fz, &pl.fy, nullptr, &pl.ix, &pl.iy, &pl.iz};
     auto launches = [&](int k, const std::function<void(Launch &)> &f) {
         if (single) { if (k < 3) f(k == 0 ? pl.sz : k == 1 ? pl.sy : pl.sx); return; }
         if (k == 2) f(pl.fx); else for (auto &L : *vecs[k]) f(L);
     };
-    int keep[6], pick[6];
-    float t[4][6];
-    for (int k = 0; k < 6; k++) {
-        keep[k] = -1;
-        launches(k, [&](Launch &L) { if (keep[k] < 0) keep[k] = (L.args.a_fastest ? 1 : 0) + (L.args.xcd_swizzle ? 2 : 0); });
-        pick[k] = keep[k];
-    }
-    auto apply = [&](int k, int d) { launches(k, [&](Launch &L) { L.args.a_fastest = d & 1; L.args.xcd_swizzle = (d >> 1) & 1; }); };
-    auto tunable = [&](int k) { return keep[k] >= 0 && p->opt.order[k] < 0 && !(k >= 3 && (!b || one_chain)); };
-    for (int d = 0; d < 4; d++) {
-        for (int k = 0; k < 6; k++) if (tunable(k)) apply(k, d);
-        for (int k = 0; k < 6; k++) t[d][k] = 1e30f;
-        float total = 1e30f;
-        for (int rep = 0; rep < 3; rep++) {            // first execution untimed in effect: the minimum of three
-            float ph[5], sum = 0;
-            if (p->c2c) TRY(dfft_exec_c2c(p, o, const_cast<void *>(in), DFFT_FORWARD)); else TRY(dfft_exec_r2c(p, o, in));
-            int n = dfft_get_phase_times(p, ph, 5);
-            for (int i = 0; i < n && i < 5; i += 2) { t[d][i / 2] = std::min(t[d][i / 2], ph[i]); sum += ph[i]; }
-            if (b) {
-                if (p->c2c) TRY(dfft_exec_c2c(p, b, o, DFFT_INVERSE)); else TRY(dfft_exec_c2r(p, b, o));
-                n = dfft_get_phase_times(p, ph, 5);
-                for (int i = 0; i < n && i < 5; i += 2) { t[d][3 + i / 2] = std::min(t[d][3 + i / 2], ph[i]); sum += ph[i]; }
-            }
-            total = std::min(total, sum);
-        }
-        note(total);
-    }
-    for (int k = 0; k < 6; k++) {
-        if (!tunable(k)) continue;
-        // a single rank's z, x, y order shares its launches between the directions: judge a pass by both
-        auto cost = [&](int d) { return single && b ? t[d][k] + t[d][5 - k] : t[d][k]; };
-        for (int d = 0; d < 4; d++)
-            if (cost(d) < 0.99f * cost(pick[k]) && cost(d) < 1e29f) pick[k] = d;
-        apply(k, pick[k]);
-    }
-    return 0;
-}
+    auto axis_of = [](int k) { return k < 3 ? k : 5 - k; };
+    auto slot = [&](int k) -> int & { return k < 3 ? p->vfwd[k] : p->vinv[5 - k]; };
+    auto usable = [&](int k) { return !(k >= 3 && (!b || shared)); };
+    float t[6], total = 0;
+    // judge a pass by both directions where they share its launches
+    auto cost = [&](const float *tt, int k) { return shared && b ? tt[k] + tt[5 - k] : tt[k]; };
 
-static int tune_variants(dfft_plan *p, const void *in, void *o, void *b, float &best, const std::function<void(float)> &note)
-{
-    TRY(tune_orders(p, in, o, b, note));
-    TRY(placement_measure(p, in, o, b, 2, &best));      // the reference time of the configuration trials: the chosen orders
-    note(best);
-    auto exists = [&](int axis, int role) {
-        PassInfo pi;
-        return role >= 0 && (p->prec == DFFT_F64 ? pass_info_f64((int)p->ax[axis].N, role, &pi) : pass_info_f32((int)p->ax[axis].N, role, &pi));
-    };
-    for (int k = 0; k < 4; k++) {
-        const int axis = 1 + (k & 1);                    // y, x of the forward chain, then of the inverse chain
-        int *slot = k < 2 ? &p->vfwd[axis] : &p->vinv[axis];
-        // Which trials run must not depend on the rank: every trial executes the plan, exchanges included.  A rank whose own role
-        // for the pass has no sibling (the strided-read role is chosen per rank: it depends on the local z extent) runs the trial
-        // with its configuration unchanged.
-        if (k >= 2 && (!b || (p->nranks == 1 && !p->opt.mirror && p->c2c))) continue;      // a single rank's complex inverse runs the forward chain
-        if (p->opt.variant[k < 2 ? axis : 5 - axis] >= 0 || p->ax[axis].bluestein) continue;
-        if (!exists(axis, ROLE_STREAM) && !exists(axis, ROLE_TILED_STREAM)) continue;
-        const int old = *slot, sib = stream_sibling(old);
-        const bool mine = exists(axis, sib);
-        if (mine) *slot = sib;
-        float ms = 0;
-        TRY(placement_measure(p, in, o, b, 2, &ms));
-        note(ms);
-        if (mine && ms < 0.997f * best) best = ms; else *slot = old;
+    // ---- orders
+    {
+        int keep[6];
+        float tb[6] = {0, 0, 0, 0, 0, 0}, td[4][6];
+        for (int k = 0; k < 6; k++) {
+            keep[k] = -1;
+            launches(k, [&](Launch &L) { if (keep[k] < 0) keep[k] = (L.args.a_fastest ? 1 : 0) + (L.args.xcd_swizzle ? 2 : 0); });
+        }
+        auto apply = [&](int k, int d) { launches(k, [&](Launch &L) { L.args.a_fastest = d & 1; L.args.xcd_swizzle = (d >> 1) & 1; }); };
+        auto tunable = [&](int k) { return keep[k] >= 0 && p->opt.order[k] < 0 && usable(k); };
+        for (int d = 0; d < 4; d++) {
+            for (int k = 0; k < 6; k++) if (tunable(k)) apply(k, d);
+            TRY(tune_trial(p, in, o, b, td[d], &total));
+            note(total);
+        }
+        for (int k = 0; k < 6; k++) {
+            if (!tunable(k)) continue;
+            int pick = keep[k];
+            for (int d = 0; d < 4; d++)
+                if (cost(td[d], k) < 1e29f && cost(td[d], k) < 0.99f * cost(td[pick], k)) pick = d;
+            apply(k, pick);
+            tb[k] = td[pick][k];
+        }
+        (void)tb;
     }
+    // ---- kernel configurations
+    TRY(tune_trial(p, in, o, b, t, &total));        // the chosen orders with the rule-based configurations: the reference of the trials
+    note(total);
+    float cur[6];
+    for (int k = 0; k < 6; k++) cur[k] = t[k];
+    auto exists = [&](int k, int v) {
+        PassInfo pi;
+        const Axis &a = p->ax[axis_of(k)];
+        return !a.bluestein && (p->prec == DFFT_F64 ? pass_info_f64((int)a.N, v, &pi) : pass_info_f32((int)a.N, v, &pi));
+    };
+    auto tunable = [&](int k) { return usable(k) && p->opt.variant[k] < 0 && !p->ax[axis_of(k)].bluestein && !(p->c2c == false && axis_of(k) == 0); };
+    for (int v = 0; v < 16; v++) {
+        // does any axis length of the plan have this variant?  (global lengths: the same answer on every rank)
+        bool any = false;
+        for (int k = 0; k < 3; k++) any = any || exists(k, v);
+        if (!any) continue;
+        int old[6];
+        bool tried[6];
+        for (int k = 0; k < 6; k++) {
+            old[k] = slot(k);
+            tried[k] = tunable(k) && exists(k, v) && old[k] != v;
+            if (tried[k]) slot(k) = v;
+        }
+        if (shared) for (int k = 0; k < 3; k++) if (tried[k]) tried[5 - k] = false;      // (vinv is not used; judged through cost())
+        float tv[6];
+        TRY(tune_trial(p, in, o, b, tv, &total));
+        note(total);
+        for (int k = 0; k < 6; k++) {
+            if (!tried[k]) continue;
+            float c0[6], c1[6];
+            for (int q = 0; q < 6; q++) { c0[q] = cur[q]; c1[q] = tv[q]; }
+            if (cost(c1, k) < 1e29f && cost(c1, k) < 0.99f * cost(c0, k)) { cur[k] = tv[k]; if (shared && b) cur[5 - k] = tv[5 - k]; }
+            else slot(k) = old[k];
+        }
+    }
+    TRY(placement_measure(p, in, o, b, 2, &best));
+    note(best);
     return 0;
 }
 

@@ -287,17 +287,19 @@ int dfft_free(void *ptr);
  * (forward in -> out, inverse out -> back; exchanges not counted) run fastest.  `in` must hold a valid input block; it
  * is only read.  Afterwards the y / x passes try their streaming (nontemporal) kernel configuration on the chosen buffers and
  * keep it where it measures faster.  *out / *back are freed with dfft_free.  On a multi-rank plan the call is collective (it
- * executes the plan about 3 * tries + 10 times).  report_ms (optional): the measured pass time of every trial in order, *n_report
+ * executes the plan about 3 * tries + 30 times).  report_ms (optional): the measured pass time of every trial in order, *n_report
  * entries. */
 int dfft_tune_placement(dfft_plan *plan, const void *in, int tries, void **out, void **back, float *report_ms,
                         int max_report, int *n_report);
 /* The second half of dfft_tune_placement on the caller's own buffers (no allocation).  First every pass tries the four
- * workgroup -> tile orders (four trial settings, each pass picks its own order from its own phase times, 1 % threshold; passes
- * whose order the caller pinned with order_* keep it); then every y / x pass whose kernel configuration has a streaming
- * (nontemporal) sibling tries it and keeps it where the plan's FFT passes get faster by more than 0.3 %.  A trial executes the
- * plan forward in -> out and, if back != NULL, inverse out -> back, which destroys `out` like every inverse.  Collective on a
- * multi-rank plan: the number of executions is the same on every rank, every rank decides for its own kernels.  report_ms: the
- * plan as built, the four order settings, the chosen orders, then one entry per sibling trial. */
+ * workgroup -> tile orders, then every kernel configuration its line length has (streaming siblings, other lane mappings and
+ * tile shapes: the role variants of csrc/cfg_*.hip.h).  A trial sets all passes at once and reads the per-pass times from the
+ * phase timers, so each pass picks for itself (1 % threshold) from 4 + (number of configuration numbers) trials; passes the
+ * caller pinned with order_* / variant_* keep their setting, Bluestein / two-level axes and the slab sequences are not tuned.
+ * A trial executes the plan three times forward in -> out and, if back != NULL, inverse out -> back, which destroys `out` like
+ * every inverse.  Collective on a multi-rank plan: which trials run depends on the global grid only, every rank decides for its
+ * own kernels.  report_ms: the plan as built, the four order settings, the chosen orders, one entry per configuration number,
+ * the final choice. */
 int dfft_tune_variants(dfft_plan *plan, const void *in, void *out, void *back, float *report_ms, int max_report, int *n_report);
 
 #ifdef __cplusplus
