@@ -23,7 +23,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                        predicts the per-GPU compute of the multi-GPU runs
   config.per_gpu_kernels_8gpu (N = 1 only) -- rank 0's plan of the 8-GPU decompositions (pencil 2x4 = BASELINE C4, slab 8)
                        executed on this GPU with the exchange stubbed out: the kernels one GPU of the 8-GPU run launches
-                       (its 1/8 of the volume, its segment tables and pipeline chunks), timed with HIP events
+                       (its 1/8 of the volume, its segment tables and pipeline chunks), timed with HIP events.  Both legs
+                       call the plan's own tuner first (dfft_tune_variants, as bench.py does at N > 1; `tune_variants`
+                       holds the as-built and the chosen time; --no-tune-variants measures the rule-based plan)
   xgmi (N > 1)      -- bytes per link and the time the links need at the guide's 153 GB/s (predicted_ms) next to the
                        measured exchange spans; overlap.hidden_frac = 1 - (step - sum kernels) / sum exchanges
 
@@ -443,6 +445,16 @@ def main():
         nv = isz_v[0] * isz_v[1] * isz_v[2]
         v_in = d_in[:nv]
         v_out = d_out[:pl.getDomainSize() // esz]
+        tuned = None
+        if not args.no_tune_variants:
+            # the plan's own tuner (dfft_tune_variants: workgroup order and kernel configuration per pass, by measurement) -- what
+            # bench.py calls at N > 1 before the warm-up, so these are the kernels a rank of the 8-GPU run would launch
+            try:
+                with torch.cuda.stream(side):
+                    tr = pl.tuneVariants(v_in, v_out, None if aliased else d_back[:nv])   # without a third buffer: forward passes only
+                tuned = {"as_built_ms": round(tr[0], 3), "chosen_ms": round(tr[-1], 3), "trials": len(tr)}
+            except Exception as e:   # noqa: BLE001
+                tuned = {"error": str(e)}
         pl.enablePhaseTiming(True)
         acc = {}
         for i in range(steps + 2):
@@ -462,7 +474,7 @@ def main():
         res = {"decomposition": f"slab P={P1v}" if P2v == 1 else f"pencil {P1v}x{P2v}", "rank": 0,
                "pipeline_chunks": pl.getPipelineChunks(), "kernels_ms_per_step": round(tot, 3), "per_pass": passes,
                "alg_bytes_per_pass": vb, "avg_TBps": round(6 * vb / (tot * 1e-3) / 1e12, 3) if tot > 0 else None,
-               "xgmi_model_per_transform": xgmi_model(esz, N, nr, P1v, P2v)}
+               "tune_variants": tuned, "xgmi_model_per_transform": xgmi_model(esz, N, nr, P1v, P2v)}
         del pl
         stub.destroy()
         return res
@@ -477,6 +489,16 @@ def main():
     if ngpus == 1 and not args.no_multi_rank_path:
         plan_m, _, _, _ = make_plan(1, 1, {"mirror_inverse": 1, "pipeline_chunks": 8})
         ksteps = max(1, min(args.steps, 10))
+        tuned_m = None
+        if not args.no_tune_variants:
+            try:
+                with torch.cuda.stream(side):
+                    tr = plan_m.tuneVariants(d_in, d_out, None if aliased else d_back)
+                tuned_m = {"as_built_ms": round(tr[0], 3), "chosen_ms": round(tr[-1], 3), "trials": len(tr)}
+            except Exception as e:   # noqa: BLE001
+                tuned_m = {"error": str(e)}
+            if aliased:
+                fill(d_in)
         run_steps(plan_m, 2, d_out, d_back)
         rt_m = round_trip_error(d_back)
         if aliased:
@@ -487,7 +509,7 @@ def main():
                                    "API layout), every pass cut into 8 pipeline chunks with segmented address tables",
                            "ms_per_step": round(dtm / ksteps * 1e3, 3), "steps": ksteps, "round_trip_rel_linf": rt_m,
                            "value_GFLOPs": round(2 * flops_per_direction(N) * ksteps / dtm / 1e9, 1),
-                           "per_pass": per_pass(phm, ksteps)}
+                           "tune_variants": tuned_m, "per_pass": per_pass(phm, ksteps)}
         del plan_m
 
     # N = 1: the kernels one GPU of the 8-GPU runs launches (BASELINE C4 / C5 grids: pencil 2x4; and slab 8), exchange stubbed
