@@ -746,8 +746,21 @@ __device__ __forceinline__ void load_tile(const PassArgs &A, const typename Cfg:
             const C *p = in + row + t;
             static_for<C0, C1>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = stream_load<Cfg>(p + NT * c); });
         } else if (A.load_kind == LOAD_KMAJOR) {
-            const C *p = in + (uint64_t)a * A.AS_in + (uint64_t)b * TL + l + (uint64_t)t * A.KS_in;
-            static_for<C0, C1>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = stream_load<Cfg>(p + (uint64_t)(NT * c) * A.KS_in); });
+            if (((uint64_t)(NT - 1) * A.KS_in + (uint64_t)A.na * A.AS_in + A.LB + TL) * sizeof(C) < (1ull << 32)) {
+                // Address = scalar 64-bit base of the point (SALU: in + NT*c*KS, the same for every lane) + ONE 32-bit byte offset
+                // of the lane (its tile, its line and its t rows; below 4 GiB for the API layouts: a lane's points lie N/E rows
+                // apart): the loads take the base from a scalar register pair (global_load ... v_off, s[base:base+1]) instead of
+                // a 64-bit vector multiply-add, a 32-bit add and a register PAIR per point.
+                const uint32_t lane = (uint32_t)(((uint64_t)t * A.KS_in + (uint64_t)a * A.AS_in + P.e) * sizeof(C));
+                const char *ub = reinterpret_cast<const char *>(in);
+                static_for<C0, C1>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    v[c] = stream_load<Cfg>(reinterpret_cast<const C *>(ub + (uint64_t)(NT * c) * A.KS_in * sizeof(C) + lane));
+                });
+            } else {
+                const C *p = in + (uint64_t)a * A.AS_in + (uint64_t)b * TL + l + (uint64_t)t * A.KS_in;
+                static_for<C0, C1>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = stream_load<Cfg>(p + (uint64_t)(NT * c) * A.KS_in); });
+            }
         } else {
             if (Cfg::UNI_LOAD && A.ltab && A.luni) {
                 const int t0 = __builtin_amdgcn_readfirstlane(t);
@@ -770,8 +783,19 @@ __device__ __forceinline__ void load_tile(const PassArgs &A, const typename Cfg:
             } else if (A.lnseg == 1) {
                 const uint64_t len = A.lseg->len[0];
                 const uint64_t ia = A.IA ? A.IA : len * A.LB, ib = A.IB ? A.IB : (uint64_t)TL * len;
-                const C *p = in + A.lseg->base[0] + (uint64_t)a * ia + (uint64_t)b * ib + l + (uint64_t)t * tw;
-                static_for<C0, C1>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = stream_load<Cfg>(p + (uint64_t)(NT * c) * tw); });
+                if (Cfg::kG == 1 && Cfg::kSUB == 1 && !A.shift) {
+                    // one tile per workgroup: (a, b, tw) are scalars, so the tile's chunk and the point's offset in it make a
+                    // scalar base; the lane adds its 32-bit (t*tw + l) bytes (see LOAD_KMAJOR)
+                    const char *ub = reinterpret_cast<const char *>(in + (A.lseg->base[0] + (uint64_t)a * ia + (uint64_t)b * ib));
+                    const uint32_t lane = ((uint32_t)t * tw + (uint32_t)l) * (uint32_t)sizeof(C);
+                    static_for<C0, C1>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        v[c] = stream_load<Cfg>(reinterpret_cast<const C *>(ub + (uint64_t)(NT * c) * tw * sizeof(C) + lane));
+                    });
+                } else {
+                    const C *p = in + A.lseg->base[0] + (uint64_t)a * ia + (uint64_t)b * ib + l + (uint64_t)t * tw;
+                    static_for<C0, C1>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = stream_load<Cfg>(p + (uint64_t)(NT * c) * tw); });
+                }
             } else {
                 static_for<C0, C1>([&](auto cc) {
                     constexpr int c = decltype(cc)::value;
@@ -813,12 +837,23 @@ __device__ __forceinline__ void store_tile(const PassArgs &A, typename Cfg::C *_
             stream_store<Cfg>(p + k0, v[c]);
         });
     } else if (A.store_kind == STORE_KMAJOR) {
-        C *p = out + (uint64_t)a2 * A.AS_out + e2 + (uint64_t)t2 * A.KS_out;
-        static_for<C0, C1>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
-            stream_store<Cfg>(p + (uint64_t)k0 * A.KS_out, v[c]);
-        });
+        if (((uint64_t)(NT - 1) * A.KS_out + (uint64_t)A.na * A.AS_out + A.LB + TL) * sizeof(C) < (1ull << 32)) {
+            // scalar base per point + one 32-bit lane offset, as in load_tile
+            const uint32_t lane = (uint32_t)(((uint64_t)t2 * A.KS_out + (uint64_t)a2 * A.AS_out + e2) * sizeof(C));
+            char *ub = reinterpret_cast<char *>(out);
+            static_for<C0, C1>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
+                stream_store<Cfg>(reinterpret_cast<C *>(ub + (uint64_t)k0 * A.KS_out * sizeof(C) + lane), v[c]);
+            });
+        } else {
+            C *p = out + (uint64_t)a2 * A.AS_out + e2 + (uint64_t)t2 * A.KS_out;
+            static_for<C0, C1>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
+                stream_store<Cfg>(p + (uint64_t)k0 * A.KS_out, v[c]);
+            });
+        }
     } else if ((A.store_kind == STORE_TILED_SAME ? Cfg::UNI_STORE_SAME : Cfg::UNI_STORE_TRANSPOSE) && A.stab && A.suni) {
         // wave-uniform entries (see seg_entry_uniform): lane 0's entry per register, the lane's own t2 - t0 added in closed form
         const int t0 = __builtin_amdgcn_readfirstlane(t2);
@@ -858,6 +893,18 @@ __device__ __forceinline__ void store_tile(const PassArgs &A, typename Cfg::C *_
             const SegEntry e = seg_entry(A.stab + (t2 + k0));
             const uint64_t off = same ? e.base + fixed : e.base + (uint64_t)e.ln * aLB + (uint64_t)line * e.aux;
             stream_store<Cfg>(out + off, v[c]);
+        });
+    } else if (Cfg::kG == 1 && Cfg::kSUB == 1 && A.store_kind == STORE_TILED_SAME && A.snseg == 1 && !A.shift &&
+               ((uint64_t)NT * (A.SK ? A.SK : (uint64_t)A.LB * A.LA) + TL) * sizeof(C) < (1ull << 32)) {
+        // one block, one tile per workgroup: scalar base per point (block, tile, (k0 - start) rows of SK) + the lane's 32-bit
+        // (t2*SK + l) bytes (see STORE_KMAJOR)
+        const uint64_t sk = A.SK ? A.SK : (uint64_t)A.LB * A.LA, sb = A.SB ? A.SB : (uint64_t)TL * A.LA;
+        char *ub = reinterpret_cast<char *>(out + (A.sseg->base[0] + (uint64_t)b2 * sb + (uint64_t)a2 * tws - (uint64_t)A.sseg->start[0] * sk));
+        const uint32_t lane = (uint32_t)(((uint64_t)t2 * sk + (uint32_t)l2) * sizeof(C));
+        static_for<C0, C1>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
+            stream_store<Cfg>(reinterpret_cast<C *>(ub + (uint64_t)k0 * sk * sizeof(C) + lane), v[c]);
         });
     } else {
         static_for<C0, C1>([&](auto cc) {
