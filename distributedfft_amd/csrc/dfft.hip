@@ -2363,6 +2363,22 @@ static int tune_variants(dfft_plan *p, const void *in, void *o, void *b, float &
             else slot(k) = old[k];
         }
     }
+    // ---- address forms: scalar base + 32-bit lane offset (the default) against per-point 64-bit vector addresses.  The scalar
+    // form saves a 64-bit multiply-add and a register pair per point and wins wherever instruction issue matters (fp32 passes
+    // 4-6 %, the fp32 strided read 23 %, profiles/r3_scalar_base_addresses.txt); a few fp64 tiled passes run 1-2 % faster with
+    // the old form (their loads leave in one burst after all addresses are known)
+    {
+        TRY(tune_trial(p, in, o, b, t, &total));
+        float tv[6];
+        for (int k = 0; k < 6; k++) if (usable(k)) launches(k, [&](Launch &L) { L.args.addr64 = 1; });
+        TRY(tune_trial(p, in, o, b, tv, &total));
+        note(total);
+        for (int k = 0; k < 6; k++) {
+            if (!usable(k)) continue;
+            const bool keep64 = cost(tv, k) < 1e29f && cost(tv, k) < 0.99f * cost(t, k);
+            launches(k, [&](Launch &L) { L.args.addr64 = keep64 ? 1 : 0; });
+        }
+    }
     TRY(placement_measure(p, in, o, b, 2, &best));
     note(best);
     return 0;

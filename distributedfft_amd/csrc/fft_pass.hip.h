@@ -82,7 +82,9 @@ struct PassArgs {
     int32_t xcd_swizzle;   // 1: consecutive tiles go to the same XCD (block b runs on XCD b % 8), so that
                            //    neighbouring tiles that share a cache line meet in one L2
     int32_t debug;         // measurement only: bit 0 = skip the transform (the pass becomes a copy with the same
-                           //    access pattern: its time is the pattern's own roofline), results are then wrong
+                           //    access pattern: its time is the pattern's own roofline), results are then wrong;
+                           //    bit 1 = per-point 64-bit vector addresses instead of scalar base + 32-bit lane offset (A/B)
+    int32_t addr64;        // 1: this pass keeps the per-point 64-bit vector addresses (dfft_tune_variants measured them faster here)
     int32_t shift;         // 1: STORE_KMAJOR with an odd row pitch: tile windows follow the cache lines of each
                            //    output row (nb counts one extra tile per row); fft_pass_kernel only
     uint32_t LA;           // STORE_TILED_SAME: extent of the a axis
@@ -746,7 +748,7 @@ __device__ __forceinline__ void load_tile(const PassArgs &A, const typename Cfg:
             const C *p = in + row + t;
             static_for<C0, C1>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = stream_load<Cfg>(p + NT * c); });
         } else if (A.load_kind == LOAD_KMAJOR) {
-            if (((uint64_t)(NT - 1) * A.KS_in + (uint64_t)A.na * A.AS_in + A.LB + TL) * sizeof(C) < (1ull << 32)) {
+            if (!(A.debug & 2) && !A.addr64 && ((uint64_t)(NT - 1) * A.KS_in + (uint64_t)A.na * A.AS_in + A.LB + TL) * sizeof(C) < (1ull << 32)) {
                 // Address = scalar 64-bit base of the point (SALU: in + NT*c*KS, the same for every lane) + ONE 32-bit byte offset
                 // of the lane (its tile, its line and its t rows; below 4 GiB for the API layouts: a lane's points lie N/E rows
                 // apart): the loads take the base from a scalar register pair (global_load ... v_off, s[base:base+1]) instead of
@@ -783,14 +785,17 @@ __device__ __forceinline__ void load_tile(const PassArgs &A, const typename Cfg:
             } else if (A.lnseg == 1) {
                 const uint64_t len = A.lseg->len[0];
                 const uint64_t ia = A.IA ? A.IA : len * A.LB, ib = A.IB ? A.IB : (uint64_t)TL * len;
-                if (Cfg::kG == 1 && Cfg::kSUB == 1 && !A.shift) {
-                    // one tile per workgroup: (a, b, tw) are scalars, so the tile's chunk and the point's offset in it make a
-                    // scalar base; the lane adds its 32-bit (t*tw + l) bytes (see LOAD_KMAJOR)
-                    const char *ub = reinterpret_cast<const char *>(in + (A.lseg->base[0] + (uint64_t)a * ia + (uint64_t)b * ib));
-                    const uint32_t lane = ((uint32_t)t * tw + (uint32_t)l) * (uint32_t)sizeof(C);
+                if (Cfg::kG == 1 && Cfg::kSUB == 1 && !A.shift && !(A.debug & 2) && !A.addr64) {
+                    // one tile per workgroup: (a, b, tw) are the same in every lane (readfirstlane: the compiler sees them merged
+                    // with the per-lane values of the A.shift case), so the tile's chunk and the point's offset in it make a scalar
+                    // base; the lane adds its 32-bit (t*tw + l) bytes (see LOAD_KMAJOR)
+                    const uint32_t au = (uint32_t)__builtin_amdgcn_readfirstlane((int)a), bu = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                    const uint32_t twu = (uint32_t)__builtin_amdgcn_readfirstlane((int)tw);
+                    const char *ub = reinterpret_cast<const char *>(in + (A.lseg->base[0] + (uint64_t)au * ia + (uint64_t)bu * ib));
+                    const uint32_t lane = ((uint32_t)t * twu + (uint32_t)l) * (uint32_t)sizeof(C);
                     static_for<C0, C1>([&](auto cc) {
                         constexpr int c = decltype(cc)::value;
-                        v[c] = stream_load<Cfg>(reinterpret_cast<const C *>(ub + (uint64_t)(NT * c) * tw * sizeof(C) + lane));
+                        v[c] = stream_load<Cfg>(reinterpret_cast<const C *>(ub + (uint64_t)(NT * c) * twu * sizeof(C) + lane));
                     });
                 } else {
                     const C *p = in + A.lseg->base[0] + (uint64_t)a * ia + (uint64_t)b * ib + l + (uint64_t)t * tw;
@@ -837,7 +842,7 @@ __device__ __forceinline__ void store_tile(const PassArgs &A, typename Cfg::C *_
             stream_store<Cfg>(p + k0, v[c]);
         });
     } else if (A.store_kind == STORE_KMAJOR) {
-        if (((uint64_t)(NT - 1) * A.KS_out + (uint64_t)A.na * A.AS_out + A.LB + TL) * sizeof(C) < (1ull << 32)) {
+        if (!(A.debug & 2) && !A.addr64 && ((uint64_t)(NT - 1) * A.KS_out + (uint64_t)A.na * A.AS_out + A.LB + TL) * sizeof(C) < (1ull << 32)) {
             // scalar base per point + one 32-bit lane offset, as in load_tile
             const uint32_t lane = (uint32_t)(((uint64_t)t2 * A.KS_out + (uint64_t)a2 * A.AS_out + e2) * sizeof(C));
             char *ub = reinterpret_cast<char *>(out);
@@ -894,12 +899,14 @@ __device__ __forceinline__ void store_tile(const PassArgs &A, typename Cfg::C *_
             const uint64_t off = same ? e.base + fixed : e.base + (uint64_t)e.ln * aLB + (uint64_t)line * e.aux;
             stream_store<Cfg>(out + off, v[c]);
         });
-    } else if (Cfg::kG == 1 && Cfg::kSUB == 1 && A.store_kind == STORE_TILED_SAME && A.snseg == 1 && !A.shift &&
+    } else if (Cfg::kG == 1 && Cfg::kSUB == 1 && A.store_kind == STORE_TILED_SAME && A.snseg == 1 && !A.shift && !(A.debug & 2) && !A.addr64 &&
                ((uint64_t)NT * (A.SK ? A.SK : (uint64_t)A.LB * A.LA) + TL) * sizeof(C) < (1ull << 32)) {
         // one block, one tile per workgroup: scalar base per point (block, tile, (k0 - start) rows of SK) + the lane's 32-bit
         // (t2*SK + l) bytes (see STORE_KMAJOR)
         const uint64_t sk = A.SK ? A.SK : (uint64_t)A.LB * A.LA, sb = A.SB ? A.SB : (uint64_t)TL * A.LA;
-        char *ub = reinterpret_cast<char *>(out + (A.sseg->base[0] + (uint64_t)b2 * sb + (uint64_t)a2 * tws - (uint64_t)A.sseg->start[0] * sk));
+        const uint32_t au = (uint32_t)__builtin_amdgcn_readfirstlane((int)a2), bu = (uint32_t)__builtin_amdgcn_readfirstlane((int)b2);
+        const uint32_t twu = (uint32_t)__builtin_amdgcn_readfirstlane((int)tws);
+        char *ub = reinterpret_cast<char *>(out + (A.sseg->base[0] + (uint64_t)bu * sb + (uint64_t)au * twu - (uint64_t)A.sseg->start[0] * sk));
         const uint32_t lane = (uint32_t)(((uint64_t)t2 * sk + (uint32_t)l2) * sizeof(C));
         static_for<C0, C1>([&](auto cc) {
             constexpr int c = decltype(cc)::value;

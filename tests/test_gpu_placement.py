@@ -49,7 +49,7 @@ def test_tune_placement_returns_working_buffers(prec, c2c):
     out, back, trials = plan.tunePlacement(d_in, tries=3, want_back=True)
     # 1 baseline + 2 further candidates for each of work area, out, back; then dfft_tune_variants' part on the kept buffers: four
     # workgroup-order settings + the chosen orders (no pass of this grid has a streaming sibling)
-    assert len(trials) == 14 and all(t > 0 for t in trials)      # ... + one configuration number (0: these lengths have no other) + the final choice
+    assert len(trials) == 15 and all(t > 0 for t in trials)      # ... + one configuration number (0: these lengths have no other) + the address-form trial + the final choice
     assert out.nbytes == plan.getDomainSize() and back.nbytes == d_in.numel() * d_in.element_size()
     if c2c:
         plan.execC2C(out, d_in, dfft.FORWARD)
@@ -77,7 +77,7 @@ def test_tune_placement_keeps_a_callers_work_area():
     plan.setWorkArea(work)
     d_in = torch.randn(shape, dtype=torch.complex128, device="cuda")
     out, back, trials = plan.tunePlacement(d_in, tries=2, want_back=False)
-    assert back is None and len(trials) == 9            # baseline + one more `out` (the caller's work area is not replaced) + 4 order settings + the chosen orders + configuration 0 + final
+    assert back is None and len(trials) == 10           # baseline + one more `out` (the caller's work area is not replaced) + 4 order settings + the chosen orders + configuration 0 + address forms + final
     assert plan.getWorkAreaDevice() == work.data_ptr()
     plan.execC2C(out, d_in, dfft.FORWARD)
     want = torch.fft.fftn(d_in)
@@ -104,8 +104,8 @@ def test_tune_variants_keeps_the_transform_exact(prec):
         d_back = torch.empty_like(d_in)
         trials = plan.tuneVariants(d_in, d_out, d_back)
         # the plan as built + four order settings + the chosen orders + one trial per configuration number of the 512- / 1024-point
-        # lengths (fp64: 0, 1, 2, 3; fp32: 0, 4, 5, 6, 9) + the final choice -- pinned or not: the trials do not depend on it
-        assert len(trials) == (11 if prec == "double" else 12) and all(t > 0 for t in trials)
+        # lengths (fp64: 0, 1, 2, 3; fp32: 0, 4, 5, 6, 9) + the address-form trial + the final choice -- pinned or not: the trials do not depend on it
+        assert len(trials) == (12 if prec == "double" else 13) and all(t > 0 for t in trials)
         plan.execC2C(d_out, d_in, dfft.FORWARD)
         got = d_out[:g.size].cpu().numpy().reshape(shape)
         assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < TOL_FWD[prec]
@@ -135,7 +135,7 @@ def test_tune_variants_is_collective_with_rank_dependent_roles():
     torch.cuda.synchronize()
     with ThreadPoolExecutor(P1 * P2) as ex:
         trials = list(ex.map(lambda r: plans[r].tuneVariants(ins[r], outs[r], backs[r]), range(P1 * P2)))
-    assert len({len(t) for t in trials}) == 1 and len(trials[0]) == 11      # as built + 4 order settings + chosen orders + configurations 0..3 + final, on every rank
+    assert len({len(t) for t in trials}) == 1 and len(trials[0]) == 12      # as built + 4 order settings + chosen orders + configurations 0..3 + address forms + final, on every rank
     with ThreadPoolExecutor(P1 * P2) as ex:
         list(ex.map(lambda r: plans[r].execR2C(outs[r], ins[r]), range(P1 * P2)))
     scale = np.max(np.abs(want))

@@ -368,9 +368,9 @@ template <typename R> static int run_plan(const Args &a)
     fill_random<R><<<nblk, 256>>>((R *)in, nreal);
     HIPCHK(hipDeviceSynchronize());
     if (a.tune_variants) {
-        float rep[8];
+        float rep[32];
         int nrep = 0;
-        DCHK(dfft_tune_variants(plan, in, out, alias_back ? nullptr : back, rep, 8, &nrep));
+        DCHK(dfft_tune_variants(plan, in, out, alias_back ? nullptr : back, rep, 32, &nrep));
         printf("TUNE-VARIANTS FFT ms per trial (first = rule-based configurations):");
         for (int i = 0; i < nrep; i++) printf(" %.3f", rep[i]);
         printf("\n");
