@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--cpu-n", type=int, default=0, help="cube edge of the CPU-baseline sample (0 = 1024 if RAM allows, else 512)")
     ap.add_argument("--tune-placement", type=int, default=-1,
                     help="physical backings tried per buffer (work area, out, back) before the warm-up: dfft_tune_placement keeps the one "
-                         "the plan's own passes run fastest on.  -1 = 4 on one GPU, off otherwise; 0 / 1 = plain allocations")
+                         "the plan's own passes run fastest on.  -1 = 6 on one GPU, off otherwise; 0 / 1 = plain allocations")
     ap.add_argument("--no-tune-variants", action="store_true",
                     help="skip dfft_tune_variants (the y / x passes try the streaming sibling of their kernel configuration on the run's own "
                          "buffers before the warm-up; already part of the placement tuner where that runs)")
@@ -303,9 +303,9 @@ def main():
     # Placement: the passes that scatter 128-byte runs depend on the physical backing of the buffer they write
     # to.  Before the warm-up the plan tries a few backings for its work area and for out / back (virtual-memory API, chunks
     # of different sizes) and keeps the fastest; that needs room for two candidates of a buffer at a time.
-    tries = args.tune_placement if args.tune_placement >= 0 else (4 if world == 1 else 0)
+    tries = args.tune_placement if args.tune_placement >= 0 else (6 if world == 1 else 0)
     placement = None
-    if tries > 1 and work is None and not aliased and free_b > 4 * domain + (4 << 30):
+    if tries > 1 and work is None and not aliased and free_b > 4 * domain + (4 << 30):      # (fewer candidates where memory is short: the library checks before each)
         t_tune = time.perf_counter()
         b_out, b_back, trial_ms = plan.tunePlacement(d_in, tries, want_back=True)
         d_out = b_out.tensor(cdt)

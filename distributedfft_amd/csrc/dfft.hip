@@ -2365,8 +2365,8 @@ static int tune_variants(dfft_plan *p, const void *in, void *o, void *b, float &
     }
     // ---- address forms: scalar base + 32-bit lane offset (the default) against per-point 64-bit vector addresses.  The scalar
     // form saves a 64-bit multiply-add and a register pair per point and wins wherever instruction issue matters (fp32 passes
-    // 4-6 %, the fp32 strided read 23 %, profiles/r3_scalar_base_addresses.txt); a few fp64 tiled passes run 1-2 % faster with
-    // the old form (their loads leave in one burst after all addresses are known)
+    // 4-9 %, the fp32 strided read 23 %, profiles/r3_scalar_base_addresses.txt); the y and z passes of 1024^3 fp64 on one rank
+    // run 1-1.5 % faster with the old form (their accesses leave in one burst after all addresses are known)
     {
         TRY(tune_trial(p, in, o, b, t, &total));
         float tv[6];
@@ -2375,7 +2375,7 @@ static int tune_variants(dfft_plan *p, const void *in, void *o, void *b, float &
         note(total);
         for (int k = 0; k < 6; k++) {
             if (!usable(k)) continue;
-            const bool keep64 = cost(tv, k) < 1e29f && cost(tv, k) < 0.99f * cost(t, k);
+            const bool keep64 = cost(tv, k) < 1e29f && cost(tv, k) < 0.995f * cost(t, k);      // (the two forms differ by 0.5 - 1.5 % where the old one wins)
             launches(k, [&](Launch &L) { L.args.addr64 = keep64 ? 1 : 0; });
         }
     }

@@ -913,6 +913,21 @@ __device__ __forceinline__ void store_tile(const PassArgs &A, typename Cfg::C *_
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
             stream_store<Cfg>(reinterpret_cast<C *>(ub + (uint64_t)k0 * sk * sizeof(C) + lane), v[c]);
         });
+    } else if (Cfg::kG == 1 && Cfg::kSUB == 1 && NT % 16 == 0 && (N / RL) % 16 == 0 && A.store_kind == STORE_TILED_TRANSPOSE && A.snseg == 1 &&
+               !A.shift && !(A.debug & 2) && !A.addr64 && A.T2shift <= 4 && A.sseg->start[0] == 0 &&
+               (A.sseg->len[0] & ((1u << A.T2shift) - 1)) == 0 && ((uint64_t)NT * A.LB + 16 * TL) * sizeof(C) < (1ull << 32)) {
+        // one block of whole consumer tiles, one tile per workgroup, every k0 a multiple of the consumer's tile (T2 <= 16): the tile
+        // index and the position inside it separate, kt = (t2 >> sh) + k0 / T2 and kr = t2 % T2, so the point's part k0*LB joins the
+        // scalar base (block, a*len*LB, b*TL*T2) and the lane adds 32-bit ((t2 / T2)*T2*LB + l*T2 + kr) bytes (see STORE_KMAJOR)
+        const uint32_t sh = A.T2shift, T2 = 1u << sh;
+        const uint32_t au = (uint32_t)__builtin_amdgcn_readfirstlane((int)a2), bu = (uint32_t)__builtin_amdgcn_readfirstlane((int)b2);
+        char *ub = reinterpret_cast<char *>(out + (A.sseg->base[0] + (uint64_t)au * A.sseg->len[0] * A.LB + (uint64_t)bu * TL * T2));
+        const uint32_t lane = ((((uint32_t)t2 >> sh) << sh) * A.LB + (uint32_t)l2 * T2 + ((uint32_t)t2 & (T2 - 1))) * (uint32_t)sizeof(C);
+        static_for<C0, C1>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
+            stream_store<Cfg>(reinterpret_cast<C *>(ub + (uint64_t)k0 * A.LB * sizeof(C) + lane), v[c]);
+        });
     } else {
         static_for<C0, C1>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
