@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 3, GPU batch 17: scalar-base address forms (global_load / global_store v_off, s[base:base+1]: one scalar 64-bit base per
+# round 3, GPU batch 20: scalar-base address forms (global_load / global_store v_off, s[base:base+1]: one scalar 64-bit base per
 # point, one 32-bit lane offset) against the per-point 64-bit vector addresses they replace (debug bit 1 = the old forms), each
 # pair IN ONE PROCESS ON THE SAME BUFFERS (tools/kbench --sweep), twice over to see the noise
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r3b17
+OUT=$R/gpurun_out/r3b20
 mkdir -p $OUT
 cd $R
 K=$R/tools/kbench

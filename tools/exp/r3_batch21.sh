@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 3, GPU batch 18: as batch 17 (scalar-base address forms against the per-point 64-bit vector addresses, debug bit 1, each
+# round 3, GPU batch 21: as batch 20 (scalar-base address forms against the per-point 64-bit vector addresses, debug bit 1, each
 # pair in one process on the same buffers) after the wave-uniform table paths got scalar tile coordinates too: the plans with
 # segmented sides (multi-rank path, rank 0 of the 8-GPU grids), then dfft_tune_variants with its address-form trial
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r3b18
+OUT=$R/gpurun_out/r3b21
 mkdir -p $OUT
 cd $R
 K=$R/tools/kbench

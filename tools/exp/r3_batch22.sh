@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 3, GPU batch 19: the scalar-base form of the transposed-tile store (z passes of one-rank and chunked plans) against the old
+# round 3, GPU batch 22: the scalar-base form of the transposed-tile store (z passes of one-rank and chunked plans) against the old
 # forms (debug bit 1 switches ALL scalar-base forms off), pairs in one process on the same buffers
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r3b19
+OUT=$R/gpurun_out/r3b22
 mkdir -p $OUT
 cd $R
 K=$R/tools/kbench
