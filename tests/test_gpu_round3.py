@@ -7,6 +7,7 @@
   padded and packed rows, ragged tiles, mixed-radix, Bluestein and one 4096-point axis.
 * the packed real z passes of EVERY generated mixed-radix length (DFFT_*_LIST_RMIXED* of csrc/kernels_mixed.inc).
 * wave-uniform (scalar) table reads against the per-lane table reads on segmented plans (option uniform_tables).
+* scalar-base address forms against the per-point 64-bit vector addresses (debug bit 1), bit for bit.
 """
 import ctypes as C
 import math
@@ -258,6 +259,47 @@ def test_uniform_table_reads_match_per_lane_reads(shape, P1, P2, chunks, prec):
         assert np.array_equal(backs_u[r], backs_v[r])
         assert np.max(np.abs(spec_u[r] - want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]])) / scale < TOL_FWD[prec]
         assert rel(backs_u[r] / float(np.prod(shape)), ins[r]) < TOL_RT[prec]
+
+
+# ------------------------------------------------------------------------------------------
+# scalar-base address forms
+# ------------------------------------------------------------------------------------------
+SCALAR_BASE_SINGLE = [((512, 512, 16), {}), ((16, 512, 512), {}), ((1024, 8, 1024), {}), ((512, 24, 1024), {}), ((2048, 16, 512), {}),
+                      ((1024, 16, 512), {"mirror_inverse": 1, "pipeline_chunks": 4}), ((1000, 12, 600), {})]
+
+
+@pytest.mark.parametrize("prec", ["double", "float"])
+@pytest.mark.parametrize("shape,options", SCALAR_BASE_SINGLE)
+def test_scalar_base_addresses_match_vector_addresses_single_rank(shape, options, prec):
+    """the closed-form address sides of one-tile workgroups (lines of 512 points and more) take a scalar 64-bit base per point
+    and one 32-bit lane offset; debug bit 1 (option debug_skip = 2) restores the per-point 64-bit vector
+    addresses, which are also what dfft_tune_variants may give a pass back.  Same arithmetic, so bit-identical results:
+    natural -> transposed tiles (z), tiled -> same tiles (y), tiled -> API layout (x), and the strided read of the mirrored inverse."""
+    g, got_s, back_s = run_single_order(shape, prec, dict(options))
+    _, got_v, back_v = run_single_order(shape, prec, dict(options, debug_skip=2))
+    assert np.array_equal(got_s, got_v)
+    assert np.array_equal(back_s, back_v)
+    want = orc.fft3d_c2c(g.astype(np.complex128), -1)
+    assert rel(got_s, want) < 2 * TOL_FWD[prec]
+    assert rel(back_s / g.size, g) < TOL_RT[prec]
+
+
+@pytest.mark.parametrize("prec", ["double", "float"])
+@pytest.mark.parametrize("shape,P1,P2,chunks", [((512, 512, 32), 2, 2, 2), ((1024, 512, 16), 2, 1, 4), ((512, 1024, 16), 1, 2, 1)])
+def test_scalar_base_addresses_match_vector_addresses_distributed(shape, P1, P2, chunks, prec):
+    """the same on multi-rank plans: the point-major API layout on both sides of the x passes (load of the inverse, store of the
+    forward transform) next to the table paths, which keep their vector arithmetic"""
+    _, ins, spec_s, backs_s = run_distributed(shape, P1, P2, prec, chunks=chunks)
+    plans, _, spec_v, backs_v = run_distributed(shape, P1, P2, prec, chunks=chunks, options={"debug_skip": 2})
+    g = orc.fill_block(shape, (0, 0, 0), shape, 2, seed=7).astype(NPDT[prec]).astype(np.complex128)
+    want = orc.fft3d_c2c(g, -1)
+    scale = np.max(np.abs(want))
+    for r, pl in enumerate(plans):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        assert np.array_equal(spec_s[r], spec_v[r])
+        assert np.array_equal(backs_s[r], backs_v[r])
+        assert np.max(np.abs(spec_s[r] - want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]])) / scale < TOL_FWD[prec]
+        assert rel(backs_s[r] / float(np.prod(shape)), ins[r]) < TOL_RT[prec]
 
 
 def test_variant_options_outside_the_key_range_are_rejected():
