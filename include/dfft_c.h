@@ -145,8 +145,10 @@ int dfft_get_pipeline_chunks(const dfft_plan *plan);
  *                      exec on ROCm 7.2 (profiles/r2_graph_latency.txt)
  *   "native_mixed"     1 (default): lengths that are not powers of two but have a mixed-radix configuration run the
  *                      native chain; 0: they run the Bluestein kernel like every other length (A/B runs, tests)
- *   "debug_skip"       measurement only: 1 = every pass skips its transform and becomes a copy with the same
- *                      access pattern (results are wrong); used to measure the pattern's own roofline
+ *   "debug_skip"       measurement only, a bit set: bit 0 (value 1) = every pass skips its transform and becomes a copy with
+ *                      the same access pattern (results are wrong); used to measure the pattern's own roofline.  Bit 1
+ *                      (value 2) = the closed-form address sides compute per-point 64-bit vector addresses instead of a scalar
+ *                      base + 32-bit lane offset (same results bit for bit; A/B of the address forms)
  *   "variant_<pass>", "order_<pass>", "real_variant"   kernel configuration / workgroup order per pass
  *                      (<pass> = fz fy fx ix iy iz; -1 = the plan's choice), for A/B measurements
  * Returns nonzero for an unknown key.  dfft_get_option returns -1 for an unknown key. */
