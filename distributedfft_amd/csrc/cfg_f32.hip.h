@@ -54,10 +54,15 @@ using F32_1024_v10 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 2>;
 using F32_2048_v10 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 2>;
 // persistent, software-pipelined forms (PassCfg::PERSIST): measured and rejected (profiles/r3_strided_read_variants.txt), A/B builds only
 using F32_2048_v13 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 0, 1, 1>;
+// PERSIST = 3: stores of a tile fused with the loads of the next (fft_pass_kernel), without / with nontemporal hints; prepared at the
+// end of round 3 (no scratch, see profiles/r3_persist3_resources.txt), to be measured: tools/kbench --opt variant_<pass>=14 | 15
+using F32_2048_v14 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 0, 1, 3>;
+using F32_2048_v15 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3, 0, 1, 3>;
+using F32_1024_v14 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 0, 1, 3>;
 #ifdef DFFT_EXPERIMENTS
 #define DFFT_F32_EXP_SMALL(X)
-#define DFFT_F32_EXP_1024(X) X(1024, 10, F32_1024_v10)
-#define DFFT_F32_EXP_2048(X) X(2048, 13, F32_2048_v13) X(2048, 10, F32_2048_v10)
+#define DFFT_F32_EXP_1024(X) X(1024, 10, F32_1024_v10) X(1024, 14, F32_1024_v14)
+#define DFFT_F32_EXP_2048(X) X(2048, 13, F32_2048_v13) X(2048, 10, F32_2048_v10) X(2048, 14, F32_2048_v14) X(2048, 15, F32_2048_v15)
 #else
 #define DFFT_F32_EXP_SMALL(X)
 #define DFFT_F32_EXP_1024(X)

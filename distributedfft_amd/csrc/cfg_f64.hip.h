@@ -51,10 +51,14 @@ using F64_8192 = PassCfg<double, 8192, 32, 8, 1, 32, 16, 16, 1, 1, 1, 0, 0, 8>;
 // whole-tile 64-point forms, 32-point fp64 2048, ...) were removed after they were measured: results in profiles/r2_*.txt and
 // DESIGN.md section 6, definitions in the git history (commit c38cf04).  New ones go here, under -DDFFT_EXPERIMENTS:
 
-// persistent, software-pipelined forms (PassCfg::PERSIST) under test
-using F64_1024_v8 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 3, 0, 1, 1>;
-using F64_1024_v9 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 0, 0, 1, 1>;
-using F64_2048_v8 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 0, 0, 1, 1>;
+// persistent, software-pipelined forms (PassCfg::PERSIST) under test.  8 / 9 were PERSIST = 1 (whole next tile prefetched into a
+// second register set: 13.3 / 14.1 ms against 7.68, profiles/r3_strided_read_variants.txt); they now hold PERSIST = 3 (stores of a
+// tile fused with the loads of the next, no second register set), prepared at the end of round 3 and not yet measured
+// (as FixForms<.., 1>: compiled for the strided read -> same-tile table store of the multi-rank inverse x pass only; with all address
+// forms in the loop the registers spill, profiles/r3_persist3_resources.txt; any other launch falls back to F64_1024_v1)
+using F64_1024_v8 = FixForms<PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 3, 0, 1, 3>, F64_1024_v1, 1>;
+using F64_1024_v9 = FixForms<PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 0, 0, 1, 3>, F64_1024_v1, 1>;
+using F64_2048_v8 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 0, 0, 1, 3>;      // (was PERSIST = 1)
 using F64_2048_v9 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 0, 0, 1, 0>;
 using F64_2048_v10 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 3, 0, 1, 2>;
 using F64_1024_v10 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 3, 0, 1, 2>;

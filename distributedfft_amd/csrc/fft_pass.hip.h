@@ -340,6 +340,7 @@ struct PassCfg {
     static constexpr int r1 = R1, r2 = R2, r3 = R3, r4 = R4, kPLANES = PLANES, kTWCHAIN = TWCHAIN, kNTMEM = NTMEM, kMAP = MAP;
     static constexpr int kSUB = SUB, TLK = TL / SUB;  // lines of a tile one workgroup transforms
     static constexpr int kPERSIST = PERSIST;
+    static constexpr int kFIX = 0;                   // address forms fixed at compile time (FixForms below); 0 = all forms, chosen at run time
     static constexpr int RLAST = R4 > 1 ? R4 : (R3 > 1 ? R3 : (R2 > 1 ? R2 : R1));
     static constexpr int NT = N / E;                 // threads per line
     static constexpr int TW = TLK * G;               // lines per workgroup
@@ -376,6 +377,27 @@ struct PassCfg {
     static_assert(E % R1 == 0 && (R2 <= 1 || E % R2 == 0) && (R3 <= 1 || E % R3 == 0) && (R4 <= 1 || E % R4 == 0), "radix must divide E");
     static_assert(THREADS <= 1024, "workgroup too large");
 };
+
+// A configuration compiled for ONE pair of address forms.  The kernel is an "uber-kernel": load_tile / store_tile branch (uniformly,
+// at run time) over every address form, which costs nothing in a straight-line kernel but makes the persistent forms spill -- every
+// branch the transformed registers flow through multiplies their live ranges (PERSIST = 3 with all forms: 684 B of scratch at 32 fp64
+// points per thread; with one form on each side: 247 VGPRs, no scratch).  kFIX = 1: point-major load with a scalar base (the strided
+// read of the API layout) and same-tile store through wave-uniform tables -- the inverse x pass of a multi-rank plan.  fix_ok() is the
+// launcher's test that a launch has exactly these forms; every other launch goes to Generic.
+template <typename Base, typename GenericCfg, int FIX> struct FixForms : Base {
+    using Generic = GenericCfg;
+    static constexpr int kFIX = FIX;
+};
+template <typename Cfg> inline bool fix_ok(const PassArgs &A)
+{
+    if constexpr (Cfg::kFIX == 1) {
+        using C = typename Cfg::C;
+        const uint64_t sk = A.SK ? A.SK : (uint64_t)A.LB * A.LA;
+        (void)sk;
+        return A.load_kind == LOAD_KMAJOR && A.store_kind == STORE_TILED_SAME && Cfg::UNI_STORE_SAME && A.stab && A.suni && !A.shift &&
+               ((uint64_t)(Cfg::NT - 1) * A.KS_in + (uint64_t)A.na * A.AS_in + A.LB + Cfg::kTL) * sizeof(C) < (1ull << 32);
+    } else return true;
+}
 
 template <typename Cfg> __host__ __device__ __forceinline__ int lds_pad(int idx)
 {
@@ -741,6 +763,20 @@ __device__ __forceinline__ void load_tile(const PassArgs &A, const typename Cfg:
     constexpr int N = Cfg::kN, TL = Cfg::kTL, NT = Cfg::NT;
     const uint32_t a = P.a, b = P.b, tw = P.tw;
     const int l = P.l;
+    if constexpr (Cfg::kFIX == 1) {          // LOAD_KMAJOR, scalar base (fix_ok has checked the range)
+        if (P.ok) {
+            const uint32_t lane = (uint32_t)(((uint64_t)t * A.KS_in + (uint64_t)a * A.AS_in + P.e) * sizeof(C));
+            const char *ub = reinterpret_cast<const char *>(in);
+            static_for<C0, C1>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                v[c] = stream_load<Cfg>(reinterpret_cast<const C *>(ub + (uint64_t)(NT * c) * A.KS_in * sizeof(C) + lane));
+            });
+        } else {
+            static_for<C0, C1>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].x = 0; v[c].y = 0; });
+        }
+        (void)b; (void)tw; (void)l;
+        return;
+    }
     if (P.ok) {
         if (A.load_kind == LOAD_LINES) {
             const uint64_t row = A.KS_in ? (uint64_t)a * A.AS_in + ((uint64_t)b * TL + l) * A.KS_in
@@ -831,6 +867,21 @@ __device__ __forceinline__ void store_tile(const PassArgs &A, typename Cfg::C *_
     if (!P.ok) return;
     const uint32_t a2 = P.a, b2 = P.b, tws = P.tw, e2 = P.e;
     const int l2 = P.l;
+    if constexpr (Cfg::kFIX == 1) {          // STORE_TILED_SAME through wave-uniform tables (the branch below, alone)
+        const int t0 = __builtin_amdgcn_readfirstlane(t2);
+        const uint32_t dt = (uint32_t)(t2 - t0);
+        const SegEntry *tab = A.stab + t0;
+        const uint64_t sk = A.SK ? A.SK : (uint64_t)A.LB * A.LA;
+        C *pl = out + ((uint64_t)b2 * (A.SB ? A.SB : (uint64_t)TL * A.LA) + (uint64_t)a2 * tws + l2 + (uint64_t)dt * sk);
+        static_for<C0, C1>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
+            const SegEntry e = seg_entry_uniform(tab + k0);
+            stream_store<Cfg>(pl + e.base, v[c]);
+        });
+        (void)e2;
+        return;
+    }
     if (A.store_kind == STORE_LINES) {
         // natural lines, or (KS_out != 0) rows at a*AS_out + line*KS_out: the z pass of the Y_Then_ZX sequence
         const uint64_t row = A.KS_out ? (uint64_t)a2 * A.AS_out + ((uint64_t)b2 * TL + l2) * A.KS_out
@@ -1008,6 +1059,35 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
             if (!(A.debug & 1)) transform<Cfg>(v, lds, W, t, lw, t2, lw2);
             static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].y *= sgn; });
             store_tile<Cfg>(A, out, tile_pos<Cfg>(A, cur, lw2), t2, v);
+            if (!more) break;
+            if constexpr (Cfg::NPASS > 1) __syncthreads();      // the next tile's first scatter reuses the LDS plane
+        }
+    } else if constexpr (Cfg::kPERSIST == 3) {
+        // PERSIST == 3 (round 3, prepared on the CPU, NOT yet measured): the same walk with the STORES of a tile fused with the LOADS
+        // of the next one, register by register.  A register that has been handed to a store is free, so the next tile's load can go
+        // into the very same register: no second register set (the reason PERSIST 1 / 2 spilled), and while the loads of tile i + 1
+        // are in flight the stores of tile i drain -- a one-workgroup-per-CU configuration then pays max(load, store) + compute per
+        // tile instead of load + compute + store.  The chunks of CH registers bound the code size (each chunk carries the uniform
+        // address-form branches of store_tile and load_tile once).
+        const uint32_t nwg = (A.ntiles + Cfg::kG - 1) / Cfg::kG * Cfg::kSUB;
+        uint32_t vid = blockIdx.x;
+        C v[E];
+        load_tile<Cfg>(A, in, tile_pos<Cfg>(A, logical_block<(Cfg::kSUB > 1)>(A, vid, nwg), lw), t, v);
+        for (;;) {
+            static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].y *= sgn; });
+            const uint32_t cur = logical_block<(Cfg::kSUB > 1)>(A, vid, nwg);
+            vid += gridDim.x;
+            const bool more = vid < nwg;
+            if (!(A.debug & 1)) transform<Cfg>(v, lds, W, t, lw, t2, lw2);
+            static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].y *= sgn; });
+            const TilePos<Cfg::kTL> Ps = tile_pos<Cfg>(A, cur, lw2);
+            const TilePos<Cfg::kTL> Pn = tile_pos<Cfg>(A, logical_block<(Cfg::kSUB > 1)>(A, more ? vid : cur, nwg), lw);
+            constexpr int CH = E >= 16 ? 8 : E;
+            static_for<0, E / CH>([&](auto qq) {
+                constexpr int q = decltype(qq)::value;
+                store_tile<Cfg, q * CH, (q + 1) * CH>(A, out, Ps, t2, v);
+                if (more) load_tile<Cfg, q * CH, (q + 1) * CH>(A, in, Pn, t, v);
+            });
             if (!more) break;
             if constexpr (Cfg::NPASS > 1) __syncthreads();      // the next tile's first scatter reuses the LDS plane
         }
