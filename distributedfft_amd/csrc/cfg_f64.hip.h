@@ -61,8 +61,10 @@ using F64_1024_v9 = FixForms<PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1,
 using F64_2048_v8 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 0, 0, 1, 3>;      // (was PERSIST = 1)
 using F64_2048_v9 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 0, 0, 1, 0>;
 using F64_2048_v10 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 3, 0, 1, 2>;
-using F64_1024_v10 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 3, 0, 1, 2>;
-using F64_1024_v11 = PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 0, 0, 1, 2>;
+// 10 / 11 (were PERSIST = 2, half of the next tile prefetched: 14.8 / 16.2 ms): PERSIST = 3 compiled for the strided read -> same-tile
+// store into ONE block (FixForms<.., 2>: P1 = 1, e.g. one rank with mirror_inverse), so that the one-GPU multi-rank-path line can run it
+using F64_1024_v10 = FixForms<PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 3, 0, 1, 3>, F64_1024_v1, 2>;
+using F64_1024_v11 = FixForms<PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 0, 0, 1, 3>, F64_1024_v1, 2>;
 // 32 points per thread on ONE tile of 8 lines: 256 threads, 68 KiB of LDS -> two independent workgroups per CU
 using F64_1024_v12 = PassCfg<double, 1024, 32, 8, 1, 32, 32, 1, 1, 1, 1, 3>;
 using F64_1024_v13 = PassCfg<double, 1024, 32, 8, 1, 32, 32, 1, 1, 1, 1, 0>;

@@ -396,6 +396,10 @@ template <typename Cfg> inline bool fix_ok(const PassArgs &A)
         (void)sk;
         return A.load_kind == LOAD_KMAJOR && A.store_kind == STORE_TILED_SAME && Cfg::UNI_STORE_SAME && A.stab && A.suni && !A.shift &&
                ((uint64_t)(Cfg::NT - 1) * A.KS_in + (uint64_t)A.na * A.AS_in + A.LB + Cfg::kTL) * sizeof(C) < (1ull << 32);
+    } else if constexpr (Cfg::kFIX == 2) {      // ... -> same-tile store into ONE block, scalar base (one rank, slab plans: no exchange 2)
+        using C = typename Cfg::C;
+        return A.load_kind == LOAD_KMAJOR && A.store_kind == STORE_TILED_SAME && !A.stab && A.snseg == 1 && !A.shift &&
+               ((uint64_t)(Cfg::NT - 1) * A.KS_in + (uint64_t)A.na * A.AS_in + A.LB + Cfg::kTL) * sizeof(C) < (1ull << 32);
     } else return true;
 }
 
@@ -763,7 +767,7 @@ __device__ __forceinline__ void load_tile(const PassArgs &A, const typename Cfg:
     constexpr int N = Cfg::kN, TL = Cfg::kTL, NT = Cfg::NT;
     const uint32_t a = P.a, b = P.b, tw = P.tw;
     const int l = P.l;
-    if constexpr (Cfg::kFIX == 1) {          // LOAD_KMAJOR, scalar base (fix_ok has checked the range)
+    if constexpr (Cfg::kFIX == 1 || Cfg::kFIX == 2) {          // LOAD_KMAJOR, scalar base (fix_ok has checked the range)
         if (P.ok) {
             const uint32_t lane = (uint32_t)(((uint64_t)t * A.KS_in + (uint64_t)a * A.AS_in + P.e) * sizeof(C));
             const char *ub = reinterpret_cast<const char *>(in);
@@ -878,6 +882,18 @@ __device__ __forceinline__ void store_tile(const PassArgs &A, typename Cfg::C *_
             constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
             const SegEntry e = seg_entry_uniform(tab + k0);
             stream_store<Cfg>(pl + e.base, v[c]);
+        });
+        (void)e2;
+        return;
+    }
+    if constexpr (Cfg::kFIX == 2) {          // STORE_TILED_SAME into one block: the lane's part once (tiles may differ from lane to lane:
+        // two tiles per workgroup), the point's k0 rows as a scalar offset
+        const uint64_t sk = A.SK ? A.SK : (uint64_t)A.LB * A.LA, sb = A.SB ? A.SB : (uint64_t)TL * A.LA;
+        C *pl = out + (A.sseg->base[0] - (uint64_t)A.sseg->start[0] * sk + (uint64_t)b2 * sb + (uint64_t)a2 * tws + l2 + (uint64_t)t2 * sk);
+        static_for<C0, C1>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
+            stream_store<Cfg>(pl + (uint64_t)k0 * sk, v[c]);
         });
         (void)e2;
         return;

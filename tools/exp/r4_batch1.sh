@@ -8,10 +8,11 @@ OUT=$R/gpurun_out/r4b1
 mkdir -p $OUT
 cd $R
 K=$R/tools/kbench
-S="variant_ix=1;variant_ix=8;variant_ix=9;variant_ix=1"
+S="variant_ix=1;variant_ix=8;variant_ix=9;variant_ix=1"          # table store (P1 > 1)
+S1="variant_ix=1;variant_ix=10;variant_ix=11;variant_ix=1"       # one-block store (P1 = 1: one rank)
 {
-echo "== 1024^3 fp64 multi-rank path: x^-1 plain (1) | PERSIST 3 + hints (8) | PERSIST 3 (9) | plain"
-timeout 200 $K --size 1024 --prec f64 --iters 5 --check --opt mirror_inverse=1 --opt pipeline_chunks=8 --sweep "$S" 2>&1 | grep -E "^PLAN|FFT|total"
+echo "== 1024^3 fp64 multi-rank path: x^-1 plain (1) | PERSIST 3 + hints (10) | PERSIST 3 (11) | plain"
+timeout 200 $K --size 1024 --prec f64 --iters 5 --check --opt mirror_inverse=1 --opt pipeline_chunks=8 --sweep "$S1" 2>&1 | grep -E "^PLAN|FFT|total"
 echo "== rank 0 of 2x4"
 timeout 100 $K --size 1024 --prec f64 --iters 10 --ranks 2x4 --sweep "$S" 2>&1 | grep -E "^PLAN|FFT|total"
 echo "== rank 0 of 8x1"
