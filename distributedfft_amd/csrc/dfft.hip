@@ -306,6 +306,7 @@ struct Options {
     int uniform_tables = 1;  // sides whose segments all start at multiples of 16 points: table entries through wave-uniform
                              // (scalar) loads, PassArgs::luni / suni (0: per-lane vector loads, for A/B runs)
     int shift = -1;          // row-aligned tile windows of odd-pitch point-major stores: -1 auto (fp64), 0 off, 2 always
+    int shift_load = 0;      // 1: row-aligned tile windows for odd-pitch point-major LOADS (the inverse x pass of an R2C plan, fp64)
     int debug = 0;           // PassArgs::debug of every launch (measurement only; results are wrong when set)
     int real_variant = 0;    // A/B configurations of the real z passes (DFFT_EXPERIMENTS builds)
     int single_order = -1;   // single-rank complex plans: 1 = pass order z, x, y with padded private layouts, 0 = z, y, x,
@@ -400,6 +401,18 @@ static void set_shift(const dfft_plan *p, PassArgs &X)
     if (p->prec != DFFT_F64 && p->opt.shift != 2) return;
     if (X.AS_out % TL == 0 || X.KS_out % TL != 0 || X.LB < TL) return;
     X.shift = 1;
+    X.nb += 1;
+    X.ntiles = X.na * X.nb;
+}
+
+// the mirror image for the inverse x pass, which LOADS the point-major API layout: windows aligned to the cache lines of each
+// input row; row0 = first row of the launch (a pipeline chunk starts at row k0 of the caller's block)
+static void set_shift_load(const dfft_plan *p, PassArgs &X, size_t row0)
+{
+    const uint32_t TL = (uint32_t)p->TL;
+    if (!p->opt.shift_load || p->ax[2].bluestein || p->ax[2].two) return;
+    if (X.AS_in % TL == 0 || X.KS_in % TL != 0 || X.LB < TL || (row0 * X.AS_in) % TL != 0) return;
+    X.shift = 2;
     X.nb += 1;
     X.ntiles = X.na * X.nb;
 }
@@ -507,6 +520,7 @@ static int build_pipeline(dfft_plan *p, Pipeline &pl)
             L.in_off = e * k0[c] * zs;
             for (int q = 0; q < P1; q++) seg_push(L.sseg, p->xstart[q], p->xs[q], S2i + p->xstart[q] * zs * kl[c]);
             L.args.LA = (uint32_t)kl[c];
+            set_shift_load(p, L.args, k0[c]);
         }
         {   // exchange 2 backwards
             A2A &T = pl.i2[c];
@@ -1372,6 +1386,9 @@ static int dev_free(void *ptr)
         if (it != g_allocs.end()) { rec = it->second; g_allocs.erase(it); }
     }
     if (!rec.chunk) { HIP_TRY(hipFree(ptr)); return 0; }
+    // hipFree synchronises implicitly, hipMemUnmap does not: work still in flight on ANY stream (the plan's, torch's, a peer
+    // device's pull in an in-process world) must not lose its mapping under it
+    HIP_TRY(hipDeviceSynchronize());
     for (size_t off = 0; off < rec.bytes; off += rec.chunk) HIP_TRY(hipMemUnmap(static_cast<char *>(ptr) + off, rec.chunk));
     HIP_TRY(hipMemAddressFree(ptr, rec.bytes));
     return 0;
@@ -1398,9 +1415,15 @@ static int dev_alloc(size_t bytes, size_t chunk_mib, void **out)
     if (!gran) gran = 4096;
     size_t chunk = chunk_mib << 20;
     chunk = (chunk + gran - 1) / gran * gran;
+    // a buffer smaller than the chunk gets one chunk of its own (granularity-rounded) size: a 1 GiB recipe must not turn a
+    // buffer of a few MiB into 1 GiB of physical memory
+    const size_t whole = (bytes + gran - 1) / gran * gran;
+    if (chunk > whole) chunk = whole;
     const size_t total = (bytes + chunk - 1) / chunk * chunk;
     void *va = nullptr;
-    HIP_TRY(hipMemAddressReserve(&va, total, chunk, nullptr, 0));
+    // alignment: the chunk when it is a power of two (physical chunks then sit on their natural boundaries), else the granularity
+    const size_t align = (chunk & (chunk - 1)) == 0 ? chunk : gran;
+    HIP_TRY(hipMemAddressReserve(&va, total, align, nullptr, 0));
     size_t mapped = 0;
     hipError_t err = hipSuccess;
     for (; mapped < total && err == hipSuccess; mapped += chunk) {
@@ -1412,10 +1435,30 @@ static int dev_alloc(size_t bytes, size_t chunk_mib, void **out)
         if (err != hipSuccess) break;
     }
     if (err == hipSuccess) {
-        hipMemAccessDesc acc = {};
-        acc.location = prop.location;
-        acc.flags = hipMemAccessFlagsProtReadWrite;
-        err = hipMemSetAccess(va, total, &acc, 1);
+        // read/write for this device and for every device that can reach it: the virtual ranks of an in-process world on several
+        // GPUs pull from each other's buffers with device-to-device copies (hipMalloc memory is peer-visible once peer access is
+        // enabled; a virtual-memory range needs the grant per device)
+        std::vector<hipMemAccessDesc> acc;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = dev + 1;
+        for (int d = 0; d < ndev; d++) {
+            int can = d == dev;
+            if (d != dev && hipDeviceCanAccessPeer(&can, d, dev) != hipSuccess) can = 0;
+            if (!can) continue;
+            hipMemAccessDesc a = {};
+            a.location.type = hipMemLocationTypeDevice;
+            a.location.id = d;
+            a.flags = hipMemAccessFlagsProtReadWrite;
+            acc.push_back(a);
+        }
+        err = hipMemSetAccess(va, total, acc.data(), acc.size());
+        if (err != hipSuccess && acc.size() > 1) {      // a peer grant the driver refuses must not cost the local mapping
+            hipMemAccessDesc own = {};
+            own.location = prop.location;
+            own.flags = hipMemAccessFlagsProtReadWrite;
+            (void)hipGetLastError();
+            err = hipMemSetAccess(va, total, &own, 1);
+        }
     }
     if (err != hipSuccess) {
         for (size_t off = 0; off < mapped; off += chunk) (void)hipMemUnmap(static_cast<char *>(va) + off, chunk);
@@ -1528,6 +1571,7 @@ static int *option_slot(Options &o, const std::string &k)
     if (k == "point_tables") return &o.tables;
     if (k == "uniform_tables") return &o.uniform_tables;
     if (k == "shift") return &o.shift;
+    if (k == "shift_load") return &o.shift_load;
     if (k == "debug_skip") return &o.debug;
     if (k == "real_variant") return &o.real_variant;
     if (k == "single_order") return &o.single_order;
@@ -2440,7 +2484,10 @@ int dfft_tune_placement(dfft_plan *p, const void *in, int tries, void **out, voi
         std::vector<void *> cands;
         for (int t = 1; t < tries; t++) {
             void *cand = nullptr;
-            if (!room_for(bytes) || dev_alloc(bytes, kPlacementRecipes[(size_t)t % nrec], &cand) != 0) break;      // out of memory: fewer candidates
+            const size_t rec_chunk = kPlacementRecipes[(size_t)t % nrec] << 20;
+            if (rec_chunk > bytes) continue;      // a chunk larger than the buffer: dev_alloc would clamp it to one chunk, which the smaller recipes already cover
+            const size_t rounded = rec_chunk ? (bytes + rec_chunk - 1) / rec_chunk * rec_chunk : bytes;
+            if (!room_for(rounded) || dev_alloc(bytes, kPlacementRecipes[(size_t)t % nrec], &cand) != 0) break;      // out of memory: fewer candidates
             cands.push_back(cand);
         }
         void *keep = which == 0 ? p->work_d : which == 1 ? o : b;

@@ -87,6 +87,8 @@ struct PassArgs {
     int32_t addr64;        // 1: this pass keeps the per-point 64-bit vector addresses (dfft_tune_variants measured them faster here)
     int32_t shift;         // 1: STORE_KMAJOR with an odd row pitch: tile windows follow the cache lines of each
                            //    output row (nb counts one extra tile per row); fft_pass_kernel only
+                           // 2: the same for LOAD_KMAJOR: windows follow the cache lines of each INPUT row (AS_in), the
+                           //    stores then go to the two tiles of the private layout a window straddles
     uint32_t LA;           // STORE_TILED_SAME: extent of the a axis
     uint32_t T2shift;      // STORE_TILED_TRANSPOSE: log2 of the consumer's tile size
     uint64_t KS_in;        // LOAD_KMAJOR point stride
@@ -721,7 +723,7 @@ template <typename Cfg> __device__ __forceinline__ TilePos<Cfg::kTL> tile_pos(co
     P.a = !ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
     P.b = !ok ? 0 : (A.a_fastest ? w / A.na : w % A.nb);
     if (A.shift) {
-        const uint32_t s = (uint32_t)((uint64_t)P.a * A.AS_out) & (uint32_t)(TL - 1);
+        const uint32_t s = (uint32_t)((uint64_t)P.a * (A.shift == 2 ? A.AS_in : A.AS_out)) & (uint32_t)(TL - 1);
         const int ei = (int)(P.b * TL + P.l) - (int)s;
         ok = ok && ei >= 0 && (uint32_t)ei < A.LB;
         P.e = ok ? (uint32_t)ei : 0;

@@ -11,6 +11,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "baseline_config: parity test of a BASELINE.json configuration at its real size; on an MI355X "
+                            "(>= 250 GiB of HBM) a skip of such a test is reported as a FAILURE")
     # Built artefacts are not in git history.  On a fresh checkout compile them once (hipcc
     # cross-compiles gfx950 without a GPU; gcc for the oracle) -- the same thing
     # __graft_entry__.build() does.  The package itself never builds or falls back at import time.
@@ -21,3 +23,46 @@ def pytest_configure(config):
                                os.path.join(ROOT, "distributedfft_amd", "csrc")])
     if not os.path.exists(orc):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+
+
+def _hbm_total_gib():
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return 0.0
+        return torch.cuda.mem_get_info()[1] / 2 ** 30
+    except Exception:  # noqa: BLE001
+        return 0.0
+
+
+@pytest.fixture(autouse=True)
+def _release_device_memory_around_large_tests(request):
+    """BASELINE-sized tests need most of the 288 GB: drop what earlier tests left in torch's caching allocator (and the plans
+    whose work areas the library owns) before their memory gates look at the free figure, and again afterwards."""
+    big = request.node.get_closest_marker("baseline_config") is not None
+    if big:
+        import gc
+        import torch
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+    yield
+    if big:
+        import gc
+        import torch
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_makereport(item, call):
+    """A test of a BASELINE configuration that skips on a box able to run it is a failure, not a skip (round 3: the 2048^3
+    test skipped by its own memory gate in every log while the documents called it green)."""
+    outcome = yield
+    rep = outcome.get_result()
+    if rep.skipped and not hasattr(rep, "wasxfail") and item.get_closest_marker("baseline_config") is not None and _hbm_total_gib() >= 250:
+        why = rep.longrepr[2] if isinstance(rep.longrepr, tuple) else str(rep.longrepr)
+        rep.outcome = "failed"
+        rep.longrepr = f"BASELINE configuration test skipped on a box with {_hbm_total_gib():.0f} GiB of HBM: {why}"

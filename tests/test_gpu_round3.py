@@ -48,6 +48,7 @@ def gpu_free_gib():
 # ------------------------------------------------------------------------------------------
 # C4 at every point
 # ------------------------------------------------------------------------------------------
+@pytest.mark.baseline_config
 @pytest.mark.parametrize("P1,P2,c2c", [(2, 4, True), (8, 1, True), (2, 4, False)])
 def test_c4_1024_fp64_every_point_vs_oracle(P1, P2, c2c):
     """BASELINE C4: 1024^3 fp64 on the pencil 2x4 grid (and slab 8, and the reference's own R2C API on 2x4), every rank a
@@ -93,17 +94,24 @@ def test_c4_1024_fp64_every_point_vs_oracle(P1, P2, c2c):
 # ------------------------------------------------------------------------------------------
 # C5 at full size on one GPU
 # ------------------------------------------------------------------------------------------
+@pytest.mark.baseline_config
 def test_c5_2048_fp32_full_size_single_gpu():
     """BASELINE C5's grid, 2048^3 fp32 complex (64 GiB per buffer), on one MI355X with the inverse written back over the
     input like bench.py does: spectrum entries against a direct DFT accumulated in fp64 slab by slab, Parseval, and the
     round trip against the regenerated input.  (The 8-GPU decomposition of this grid does not fit one GPU as virtual
-    ranks: 8 x (in + out + 3 work slices); its kernels and layouts run in test_c5_fp32_axis_2048_and_1024_cube.)"""
+    ranks: 8 x (in + out + 3 work slices); its kernels and layouts run in test_c5_fp32_axis_2048_and_1024_cube and, on the
+    2 x 4 grid at every point, in test_c5_shaped_2048x2048x1024_fp32_pencil_2x4_every_point.)
+    The gate is computed from the plan: in + out (domain size) + the library's work area + 3 GiB of temporaries (the fp64
+    slabs of the direct DFT); conftest.py empties torch's cache first and turns a skip on an MI355X into a failure."""
     N = 2048
-    if gpu_free_gib() < 215:
-        pytest.skip(f"needs 215 GiB of free HBM (in 64 + out 64 + padded work area 64-72 GiB), {gpu_free_gib():.0f} GiB free")
     n = N ** 3
     plan = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), precision="float")
-    plan.initFFT(dfft.GlobalSize(N, N, N), dfft.Pencil_Partition(1, 1), True, c2c=True)
+    plan.initFFT(dfft.GlobalSize(N, N, N), dfft.Pencil_Partition(1, 1), False, c2c=True)      # sizes first, no allocation
+    need = (8 * n + plan.getDomainSize() + plan.getWorkSizeDevice()) / 2 ** 30 + 3
+    if gpu_free_gib() < need:
+        pytest.skip(f"needs {need:.0f} GiB of free HBM (in 64 + out {plan.getDomainSize() / 2 ** 30:.0f} + work area "
+                    f"{plan.getWorkSizeDevice() / 2 ** 30:.0f} + 3 GiB), {gpu_free_gib():.0f} GiB free")
+    plan.setWorkArea()
     x = torch.empty(n, dtype=torch.complex64, device="cuda")
     out = torch.empty(plan.getDomainSize() // 8, dtype=torch.complex64, device="cuda")
     planes = 16                                  # x planes per slab: 16 * 2048^2 points = 512 MiB of complex64
@@ -154,6 +162,59 @@ def test_c5_2048_fp32_full_size_single_gpu():
         worst = torch.maximum(worst, (x[i * N * N:(i + planes) * N * N] / float(n) - v).abs().max())
     regenerate(compare)
     assert float(worst) / 255.0 < 5e-5
+
+
+@pytest.mark.baseline_config
+def test_c5_shaped_2048x2048x1024_fp32_pencil_2x4_every_point():
+    """The largest C5-SHAPED decomposed case one GPU holds as virtual ranks: 2048 x 2048 x 1024 fp32 complex on the pencil
+    2 x 4 grid (BASELINE C5's partition, precision and its 2048-point tiled y / x passes with their 8-peer segment tables;
+    8 x (in 4 + out 4 + work 12 GiB) = 160 GiB), compared with the CPU oracle at EVERY point (reference testcase 1:
+    distributed == single transform of the same global array, tests/src/pencil/random_dist_3D.cu:386-403), then the
+    round trip with the inverse written over the input (testcase 3, :641-666)."""
+    shape = (2048, 2048, 1024)
+    P1, P2 = 2, 4
+    n3 = float(np.prod(shape))
+    need_host = 16 * n3 / 2 ** 30 + 12
+    if host_free_gib() < need_host:
+        pytest.skip(f"needs {need_host:.0f} GiB of free host memory for the oracle transform, {host_free_gib():.0f} GiB free")
+    if gpu_free_gib() < 180:
+        pytest.skip(f"needs 180 GiB of free HBM (8 virtual ranks x 20 GiB + comparison slabs), {gpu_free_gib():.0f} GiB free")
+    world = dfft.Comm.local(P1 * P2)
+    ranks = []
+
+    def block(r, size):
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(4096 + r)
+        return torch.view_as_complex(torch.rand((size[0] * size[1] * size[2], 2), dtype=torch.float32, device="cuda", generator=gen) * 255).reshape(size)
+    for r in range(P1 * P2):
+        pl = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), world, precision="float", rank=r)
+        pl.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(P1, P2), True, c2c=True)
+        ranks.append(dict(plan=pl, x=block(r, pl.getInSize()), out=torch.zeros(pl.getDomainSize() // 8, dtype=torch.complex64, device="cuda")))
+    g = np.empty(shape, dtype=np.complex128)
+    for rk in ranks:
+        s, o = rk["plan"].getInSize(), rk["plan"].getInStart()
+        g[o[0]:o[0] + s[0], o[1]:o[1] + s[1], :] = rk["x"].cpu().numpy()
+    torch.cuda.synchronize()
+    run_all(ranks, lambda rk: rk["plan"].execC2C(rk["out"], rk["x"], dfft.FORWARD))
+    orc.lib().orc_fft3d_c2c(g.ctypes.data_as(C.c_void_p), *shape, -1)       # in place: g is the spectrum now
+    scale = float(np.abs(g[0, 0, 0]))        # the DC term is the largest entry of a non-negative input
+    worst = 0.0
+    step = 256
+    for rk in ranks:
+        s, o = rk["plan"].getOutSize(), rk["plan"].getOutStart()
+        assert s[0] == shape[0]
+        got = spectrum_block(rk)
+        for k0 in range(0, s[0], step):
+            ref = torch.from_numpy(np.ascontiguousarray(g[k0:k0 + step, o[1]:o[1] + s[1], o[2]:o[2] + s[2]])).cuda()
+            worst = max(worst, float((got[k0:k0 + step].to(torch.complex128) - ref).abs().max()) / scale)
+            del ref
+    assert worst < 1e-4, worst       # fp32 forward tolerance (SURVEY 8c)
+    del g
+    run_all(ranks, lambda rk: rk["plan"].execC2C(rk["x"], rk["out"], dfft.INVERSE))       # in = back aliased
+    for r, rk in enumerate(ranks):
+        want = block(r, rk["plan"].getInSize())
+        assert float((rk["x"] / n3 - want).abs().max()) / 255.0 < 5e-5
+        del want
 
 
 # ------------------------------------------------------------------------------------------
