@@ -71,6 +71,13 @@ def parse():
     ap.add_argument("--tune-placement", type=int, default=-1,
                     help="physical backings tried per buffer (work area, out, back) before the warm-up: dfft_tune_placement keeps the one "
                          "the plan's own passes run fastest on.  -1 = 6 on one GPU, off otherwise; 0 / 1 = plain allocations")
+    ap.add_argument("--plain-buffers", action="store_true",
+                    help="the reference's ownership contract as it stands: out / back from the caller's plain allocator (torch / hipMalloc) "
+                         "and a hipMalloc work area, no tuner (the N = 1 line carries this figure anyway: config.plain_buffers)")
+    ap.add_argument("--no-plain-leg", action="store_true", help="N = 1: skip the plain-buffer measurement next to the headline")
+    ap.add_argument("--relay", type=int, default=-1,
+                    help="N > 1, pencil grids: two-hop relay of the group exchanges (dfft_comm_set_option 'relay'; 1 = exchange 2, 3 = both). "
+                         "-1 = headline direct, the relayed run measured next to it (config.relay); 0 = no relay leg")
     ap.add_argument("--no-tune-variants", action="store_true",
                     help="skip dfft_tune_variants (the y / x passes try the streaming sibling of their kernel configuration on the run's own "
                          "buffers before the warm-up; already part of the placement tuner where that runs)")
@@ -104,6 +111,12 @@ def xgmi_model(esz, N, ngpus, P1, P2):
             per_link = vol / P
             out[name] = {"group_ranks": P, "links": P - 1, "bytes_per_link": per_link, "bytes_out": per_link * (P - 1),
                          "predicted_ms": round(per_link / (XGMI_LINK_GBS * 1e9) * 1e3, 3)}
+            if P < ngpus:
+                # two-hop relay (dfft_comm_set_option "relay", csrc/comm.hip): a message to a partner is cut into n_gpus parts, per
+                # partner two world-wide phases in each of which every link of the GPU carries ONE part
+                part = per_link / ngpus
+                out[name]["relay"] = {"links": ngpus - 1, "phases": 2 * (P - 1), "bytes_per_link_per_phase": part,
+                                      "predicted_ms": round(2 * (P - 1) * part / (XGMI_LINK_GBS * 1e9) * 1e3, 3)}
     return out
 
 
@@ -157,14 +170,66 @@ def cpu_baseline(n_req):
     got = orc.fft3d_c2c(s, -1)
     t_or = time.perf_counter() - t0
     dev = float(np.max(np.abs(got - want)) / np.max(np.abs(want)))
+    mpi = cpu_baseline_mpi(n)
+    omp = {"value": round(2 * fl * iters / (tf + tb) / 1e9, 3), "cores": orc.num_threads(),
+           "forward_ms": round(tf / iters * 1e3, 1), "inverse_ms": round(tb / iters * 1e3, 1),
+           "what": "oracle/dfft_oracle.c orc_fft3d_c2c: one process, OpenMP over lines, no decomposition"}
+    if mpi.get("value"):
+        # the headline of this object is the DECOMPOSED path, one MPI process per rank (what the reference's CPU/MPI run would be:
+        # SURVEY.md 8d); the single-process OpenMP transform of the same grid stays next to it
+        return {"value": mpi["value"], "unit": "GFLOP/s", "cores": mpi["cores"], "kind": "port",
+                "forward_ms": mpi["forward_ms"], "inverse_ms": mpi["inverse_ms"],
+                "forward_GFLOPs": round(fl / (mpi["forward_ms"] * 1e-3) / 1e9, 2), "inverse_GFLOPs": round(fl / (mpi["inverse_ms"] * 1e-3) / 1e9, 2),
+                "mpi": mpi, "openmp_single_process": omp,
+                "numpy_check": {"grid": f"{m}^3", "numpy_fftn_ms": round(t_np * 1e3, 1), "oracle_ms": round(t_or * 1e3, 1), "max_rel_dev": dev},
+                "sample": f"{n}^3 fp64 complex, pencil {mpi['P1']}x{mpi['P2']} over {mpi['cores']} MPI ranks (mpiexec -n {mpi['cores']} oracle/mpi_pencil: "
+                          f"z-FFT, MPI_Alltoallv in the row communicator, y-FFT, MPI_Alltoallv in the column communicator, x-FFT and the mirror), "
+                          f"1 warm-up + {mpi['iters']} timed forward and inverse transforms; host has {os.cpu_count()} cores; next to it the "
+                          f"single-process OpenMP oracle on {orc.num_threads()} threads ({omp['forward_ms']} / {omp['inverse_ms']} ms)"}
     return {"value": round(2 * fl * iters / (tf + tb) / 1e9, 3), "unit": "GFLOP/s", "cores": orc.num_threads(),
-            "kind": "port",
+            "kind": "port", "mpi": mpi,
             "forward_ms": round(tf / iters * 1e3, 1), "inverse_ms": round(tb / iters * 1e3, 1),
             "forward_GFLOPs": round(fl * iters / tf / 1e9, 2), "inverse_GFLOPs": round(fl * iters / tb / 1e9, 2),
             "numpy_check": {"grid": f"{m}^3", "numpy_fftn_ms": round(t_np * 1e3, 1), "oracle_ms": round(t_or * 1e3, 1),
                             "max_rel_dev": dev},
             "sample": f"{n}^3 fp64 complex, 1 warm-up + {iters} timed forward and inverse transforms ({tf + tb:.1f} s), "
                       f"oracle/dfft_oracle.c with {orc.num_threads()} OpenMP threads, host has {os.cpu_count()} cores"}
+
+
+def cpu_baseline_mpi(n):
+    """The restated reference path as ONE MPI PROCESS PER RANK on this host's cores (oracle/mpi_pencil.c: the opt1 pencil chain with
+    MPI_Comm_split + MPI_Alltoallv, src/pencil/mpicufft_pencil_opt1.cpp:103-104, 1422-1600): R = the largest power of two <= cores
+    (at most 256), P1 x P2 as square as possible, 1 warm-up + 2 timed forward and inverse transforms of the n^3 fp64 complex grid."""
+    import shutil
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "mpi_pencil")
+    launcher = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if not os.path.exists(exe) or not os.path.exists(launcher):
+        return {"error": "oracle/mpi_pencil or mpiexec not available (make -C oracle mpi_pencil)"}
+    cores = os.cpu_count() or 1
+    R = 1
+    while R * 2 <= min(cores, 256):
+        R *= 2
+    P1 = 1
+    while P1 * P1 * 4 <= R:
+        P1 *= 2
+    P2 = R // P1
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.perf_counter()
+    try:
+        out = subprocess.run([launcher, "-n", str(R), exe, str(n), str(P1), str(P2), "2"], capture_output=True, text=True, timeout=240, env=env)
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        if out.returncode != 0 or not line:
+            return {"error": (out.stderr or out.stdout)[-300:], "ranks": R}
+        r = json.loads(line[-1])
+    except Exception as e:   # noqa: BLE001
+        return {"error": str(e), "ranks": R}
+    fl = flops_per_direction(n)
+    return {"value": round(2 * fl / ((r["forward_ms"] + r["inverse_ms"]) * 1e-3) / 1e9, 3), "unit": "GFLOP/s", "cores": R, "P1": P1, "P2": P2,
+            "forward_ms": round(r["forward_ms"], 1), "inverse_ms": round(r["inverse_ms"], 1), "iters": r["iters"],
+            "round_trip_rel_linf": r["round_trip_rel_linf"], "wall_s": round(time.perf_counter() - t0, 1)}
 
 
 def dry_run():
@@ -235,6 +300,13 @@ def main():
     tmode = "torch" if args.backend == "gloo" else args.transport
     tmode_box = [tmode]
 
+    def lib_buffer(nbytes, dtype):
+        """device memory with the library's default backing (dfft_malloc(DFFT_CHUNK_DEFAULT): virtual-memory API, no search) as a
+        torch view -- what a drop-in caller gets by allocating `out` through the library; --plain-buffers: the caller's allocator"""
+        if args.plain_buffers:
+            return torch.empty(nbytes // torch.empty((), dtype=dtype).element_size(), dtype=dtype, device="cuda")
+        return dfft.DeviceBuffer.alloc(nbytes).tensor(dtype)
+
     def make_plan(P1, P2, options=None):
         comm, transport = None, "none"
         if world > 1:
@@ -255,13 +327,16 @@ def main():
         plan.initFFT(dfft.GlobalSize(N, N, N), dfft.Partition(P1, P2), allocate=False, c2c=True)
         plan.setStream(stream)
         if comm is not None and transport == "torch":
-            # the torch transport maps raw pointers back to tensors, so the work area must be one
-            work = torch.empty(plan.getWorkSizeDevice(), dtype=torch.uint8, device="cuda")
+            # the torch transport maps raw pointers back to tensors, so the work area must be one (a view of library memory)
+            work = lib_buffer(plan.getWorkSizeDevice(), torch.uint8)
             plan.setWorkArea(work)
             comm.register(work)
+        elif args.plain_buffers:
+            work = torch.empty(plan.getWorkSizeDevice(), dtype=torch.uint8, device="cuda")
+            plan.setWorkArea(work)
         else:
             work = None
-            plan.setWorkArea(None)       # library-owned (hipMalloc), like the reference's allocate = true
+            plan.setWorkArea(None)       # library-owned (the default backing), like the reference's allocate = true
         return plan, comm, transport, work
 
     plan, comm, transport, work = make_plan(P1, P2)
@@ -304,6 +379,8 @@ def main():
     # to.  Before the warm-up the plan tries a few backings for its work area and for out / back (virtual-memory API, chunks
     # of different sizes) and keeps the fastest; that needs room for two candidates of a buffer at a time.
     tries = args.tune_placement if args.tune_placement >= 0 else (6 if world == 1 else 0)
+    if args.plain_buffers:
+        tries = 0
     placement = None
     if tries > 1 and work is None and not aliased and free_b > 4 * domain + (4 << 30):      # (fewer candidates where memory is short: the library checks before each)
         t_tune = time.perf_counter()
@@ -315,13 +392,16 @@ def main():
                              "back one at a time on other physical backings; a candidate is kept when the plan's own passes run faster on it",
                      "seconds": round(time.perf_counter() - t_tune, 2)}
     else:
-        d_out = torch.empty(domain // esz, dtype=cdt, device="cuda")
-        d_back = d_in if aliased else torch.empty(n_in, dtype=cdt, device="cuda")
+        d_out = lib_buffer(domain, cdt)
+        d_back = d_in if aliased else lib_buffer(n_in * esz, cdt)
+        placement = {"tries_per_buffer": 0, "what": "no search: out / back from the caller's plain allocator, hipMalloc work area (--plain-buffers)"
+                     if args.plain_buffers else "no search: out / back from dfft_malloc(DFFT_CHUNK_DEFAULT) and the library-owned work area on the "
+                     "same default backing (virtual-memory API, 1 GiB physical chunks)"}
     if comm is not None and transport == "torch":
         comm.register(d_out)
     torch.cuda.synchronize()
     variants = None
-    if placement is None and not args.no_tune_variants:
+    if not (placement or {}).get("tries_per_buffer") and not args.no_tune_variants:
         # no placement tuner in this run (N > 1, or a grid that leaves no room for candidates): the kernel-configuration half of it
         # on the buffers as they are.  Collective at N > 1 (it executes the plan); every rank decides for its own kernels.
         try:
@@ -479,6 +559,57 @@ def main():
         stub.destroy()
         return res
 
+    # N = 1: the same plan on the buffers a caller gets from its own allocator (the reference's ownership contract as it stands:
+    # cudaMalloc'd in / out, tests/src/pencil/random_dist_3D.cu:197-205) and a hipMalloc work area, no tuner of any kind
+    plain_leg = None
+    free_b, _ = torch.cuda.mem_get_info()
+    if ngpus == 1 and not args.no_plain_leg and not args.plain_buffers and not aliased and free_b > 3 * domain + n_in * esz + (4 << 30):
+        pp = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), None, precision=prec, rank=0)
+        pp.initFFT(dfft.GlobalSize(N, N, N), dfft.Partition(1, 1), allocate=False, c2c=True)
+        pp.setStream(stream)
+        p_work = torch.empty(pp.getWorkSizeDevice(), dtype=torch.uint8, device="cuda")
+        pp.setWorkArea(p_work)
+        p_out = torch.empty(domain // esz, dtype=cdt, device="cuda")
+        p_back = torch.empty(n_in, dtype=cdt, device="cuda")
+        ksteps = max(1, min(args.steps, 10))
+        run_steps(pp, 2, p_out, p_back)
+        rt_p = round_trip_error(p_back)
+        pp.enablePhaseTiming(True)
+        dtp, php, _ = run_steps(pp, ksteps, p_out, p_back, collect=True)
+        plain_leg = {"what": "the same plan on plain buffers: out / back from torch's allocator (hipMalloc), hipMalloc work area, rule-based "
+                             "kernel configurations, no tuner -- what a caller that follows the reference's ownership contract to the letter gets",
+                     "ms_per_step": round(dtp / ksteps * 1e3, 3), "steps": ksteps, "round_trip_rel_linf": rt_p,
+                     "value_GFLOPs": round(2 * flops_per_direction(N) * ksteps / dtp / 1e9, 1), "per_pass": per_pass(php, ksteps)}
+        del pp, p_work, p_out, p_back
+        torch.cuda.empty_cache()
+
+    # N > 1, pencil grids: the same plan with the two-hop relay on its group exchanges (every rank sets the option; collective)
+    relay_leg = None
+    want_relay = args.relay if args.relay >= 0 else 1
+    if world > 1 and comm is not None and want_relay and (P1 < world and P1 > 1 or (want_relay & 2 and P2 < world and P2 > 1)):
+        try:
+            comm.setOption("relay", want_relay)
+            if aliased:
+                fill(d_in)
+            run_steps(plan, 2, d_out, d_back)
+            rt_r = round_trip_error(d_back)
+            if aliased:
+                fill(d_in)
+            dtr, phr, _ = run_steps(plan, args.steps, d_out, d_back, collect=True)
+            exr = {name: round(ms / args.steps / 2.0, 3) for name, ms in phr.items() if "FFT" not in name}
+            relay_leg = {"what": "the headline plan with dfft_comm_set_option(comm, 'relay', %d): every message of the relayed exchanges cut into "
+                                 "n_gpus parts, two direct and the others through the ranks outside the pair, as two world-wide all-to-alls per "
+                                 "partner (csrc/comm.hip)" % want_relay,
+                         "relay": want_relay, "ms_per_step": round(dtr / args.steps * 1e3, 3), "round_trip_rel_linf": rt_r,
+                         "value": round(2 * flops_per_direction(N) * args.steps / dtr / 1e9, 1),
+                         "exchange_ms_per_transform": exr, "per_pass": per_pass(phr, args.steps)}
+            relay_leg["overlap"] = overlap_report(relay_leg["ms_per_step"], sum(ms for n_, ms in phr.items() if "FFT" in n_) / args.steps,
+                                                  sum(ms for n_, ms in phr.items() if "FFT" not in n_) / args.steps)
+        except Exception as e:   # noqa: BLE001
+            relay_leg = {"error": str(e)}
+        finally:
+            comm.setOption("relay", 0)
+
     # N = 1: the code path of the N > 1 runs on the same grid (mirrored inverse order, 8-chunk segment tables)
     multi_rank_path = None
     chunks_main = plan.getPipelineChunks()
@@ -571,14 +702,27 @@ def main():
 
     # HBM bytes per launch: NOT measured by this run.  It is the figure of the committed PMC profile of this kernel
     # on this workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 read correction applied)
+    # The committed figure is only carried if it was measured on THIS library: the profile records the sha256 of the libdfft_amd.so
+    # it ran; a different library loaded here means the figure is stale (traffic stays null, traffic_stale says why).
     try:
+        import hashlib
+        so = os.path.join(ROOT, "distributedfft_amd", "libdfft_amd.so")
+        sha = hashlib.sha256(open(so, "rb").read()).hexdigest()
+        roofline["library_sha256"] = sha
         # newest committed PMC run of the headline kernel (tools/pmc_traffic.sh + tools/pmc_traffic.py)
-        pmc = [f for f in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+        pmc = [f for f in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")
+               if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
         pm = json.load(open(os.path.join(ROOT, "profiles", pmc)))
         if ngpus == 1 and N == 1024 and prec == "double" and pm.get("hbm_bytes_per_launch"):
-            roofline["traffic"] = pm["hbm_bytes_per_launch"]
-            roofline["traffic_static"] = True
             roofline["traffic_source"] = f"profiles/{pmc} (a committed rocprofv3 PMC run, not this run)"
+            if pm.get("library_sha256") == sha:
+                roofline["traffic"] = pm["hbm_bytes_per_launch"]
+                roofline["traffic_static"] = True
+            else:
+                roofline["traffic_stale"] = True
+                roofline["traffic_stale_value"] = pm["hbm_bytes_per_launch"]
+                roofline["traffic_stale_why"] = ("the profile was measured on library sha256 %s, this run loaded %s" %
+                                                 (str(pm.get("library_sha256"))[:12], sha[:12]))
     except Exception:   # noqa: BLE001
         pass
 
@@ -604,6 +748,11 @@ def main():
             "round_trip_rel_linf": rt_err,
             "roofline": roofline,
         }
+        if plain_leg is not None:
+            out["config"]["plain_buffers"] = plain_leg
+            out["config"]["plain_buffers_ms_per_step"] = plain_leg["ms_per_step"]
+        if relay_leg is not None:
+            out["config"]["relay"] = relay_leg
         if multi_rank_path is not None:
             out["config"]["multi_rank_path"] = multi_rank_path
         if per_gpu_8 is not None:

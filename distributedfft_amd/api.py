@@ -104,10 +104,14 @@ class DeviceBuffer:
     def __init__(self, address, nbytes, owned=True):
         self.address, self.nbytes, self._owned = int(address), int(nbytes), owned
 
+    CHUNK_DEFAULT = 2 ** (8 * C.sizeof(C.c_size_t)) - 1      # DFFT_CHUNK_DEFAULT of include/dfft_c.h
+
     @classmethod
-    def alloc(cls, nbytes, chunk_mib=0):
+    def alloc(cls, nbytes, chunk_mib=None):
+        """chunk_mib: None = the library's default backing (virtual-memory API, 1 GiB physical chunks; what the library uses for
+        the work areas it owns), 0 = plain hipMalloc, k = physical chunks of k MiB"""
         h = C.c_void_p()
-        check(lib().dfft_malloc(int(nbytes), int(chunk_mib), C.byref(h)))
+        check(lib().dfft_malloc(int(nbytes), cls.CHUNK_DEFAULT if chunk_mib is None else int(chunk_mib), C.byref(h)))
         return cls(h.value, nbytes)
 
     def data_ptr(self):

@@ -52,17 +52,21 @@ using F32_2048_v9 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3>;
 // inverse y pass (transposed-tile stores in whole lines instead of 32-byte pieces): 4.42 vs 4.30 ms at 1024 points, 10.55 vs 10.35 at 2048
 using F32_1024_v10 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 2>;
 using F32_2048_v10 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 2>;
-// persistent, software-pipelined forms (PassCfg::PERSIST): measured and rejected (profiles/r3_strided_read_variants.txt), A/B builds only
-using F32_2048_v13 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 0, 1, 1>;
-// PERSIST = 3: stores of a tile fused with the loads of the next (fft_pass_kernel), without / with nontemporal hints; prepared at the
-// end of round 3 (no scratch, see profiles/r3_persist3_resources.txt), to be measured: tools/kbench --opt variant_<pass>=14 | 15
-using F32_2048_v14 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 0, 1, 3>;
-using F32_2048_v15 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3, 0, 1, 3>;
-using F32_1024_v14 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 0, 1, 3>;
+// Round 4, under test (A/B builds): getting the tiled 2048-point passes to TWO workgroups per CU.  16 lines x 2048 points are 256 KiB,
+// half of a CU's register file, so whole tiles mean one workgroup per CU and load -> compute -> store in sequence.
+//   12 / 13 = sub-tile workgroups of 8 lines (PassCfg::SUB = 2: 64-byte runs on the tiled sides, two workgroups per CU), line-fastest
+//             mapping, 64 points per thread, without / with nontemporal hints (variant 5 is the same with the point-fastest store
+//             mapping: the tuner already picks it for the inverse y pass of C5, 5.59 -> 4.77 ms)
+//   14 / 15 = sub-tile workgroups of 8 lines with 32 points per thread: 512 threads, <= 128 VGPRs, 66 KiB of LDS -> two workgroups =
+//             32 waves per CU, three radix passes
+using F32_2048_v12 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 0, 2>;
+using F32_2048_v13 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3, 0, 2>;
+using F32_2048_v14 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 0, 2>;
+using F32_2048_v15 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3, 0, 2>;
 #ifdef DFFT_EXPERIMENTS
 #define DFFT_F32_EXP_SMALL(X)
-#define DFFT_F32_EXP_1024(X) X(1024, 10, F32_1024_v10) X(1024, 14, F32_1024_v14)
-#define DFFT_F32_EXP_2048(X) X(2048, 13, F32_2048_v13) X(2048, 10, F32_2048_v10) X(2048, 14, F32_2048_v14) X(2048, 15, F32_2048_v15)
+#define DFFT_F32_EXP_1024(X) X(1024, 10, F32_1024_v10)
+#define DFFT_F32_EXP_2048(X) X(2048, 10, F32_2048_v10) X(2048, 12, F32_2048_v12) X(2048, 13, F32_2048_v13) X(2048, 14, F32_2048_v14) X(2048, 15, F32_2048_v15)
 #else
 #define DFFT_F32_EXP_SMALL(X)
 #define DFFT_F32_EXP_1024(X)

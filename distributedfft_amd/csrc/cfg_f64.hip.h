@@ -51,38 +51,29 @@ using F64_8192 = PassCfg<double, 8192, 32, 8, 1, 32, 16, 16, 1, 1, 1, 0, 0, 8>;
 // whole-tile 64-point forms, 32-point fp64 2048, ...) were removed after they were measured: results in profiles/r2_*.txt and
 // DESIGN.md section 6, definitions in the git history (commit c38cf04).  New ones go here, under -DDFFT_EXPERIMENTS:
 
-// persistent, software-pipelined forms (PassCfg::PERSIST) under test.  8 / 9 were PERSIST = 1 (whole next tile prefetched into a
-// second register set: 13.3 / 14.1 ms against 7.68, profiles/r3_strided_read_variants.txt); they now hold PERSIST = 3 (stores of a
-// tile fused with the loads of the next, no second register set), prepared at the end of round 3 and not yet measured
-// (as FixForms<.., 1>: compiled for the strided read -> same-tile table store of the multi-rank inverse x pass only; with all address
-// forms in the loop the registers spill, profiles/r3_persist3_resources.txt; any other launch falls back to F64_1024_v1)
-using F64_1024_v8 = FixForms<PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 3, 0, 1, 3>, F64_1024_v1, 1>;
-using F64_1024_v9 = FixForms<PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 0, 0, 1, 3>, F64_1024_v1, 1>;
-using F64_2048_v8 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 0, 0, 1, 3>;      // (was PERSIST = 1)
-using F64_2048_v9 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 0, 0, 1, 0>;
-using F64_2048_v10 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 3, 0, 1, 2>;
-// 10 / 11 (were PERSIST = 2, half of the next tile prefetched: 14.8 / 16.2 ms): PERSIST = 3 compiled for the strided read -> same-tile
-// store into ONE block (FixForms<.., 2>: P1 = 1, e.g. one rank with mirror_inverse), so that the one-GPU multi-rank-path line can run it
-using F64_1024_v10 = FixForms<PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 3, 0, 1, 3>, F64_1024_v1, 2>;
-using F64_1024_v11 = FixForms<PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 0, 0, 1, 3>, F64_1024_v1, 2>;
-// 32 points per thread on ONE tile of 8 lines: 256 threads, 68 KiB of LDS -> two independent workgroups per CU
+//   8 = strided read on a plan without a second exchange (P1 = 1: the mirrored inverse of one rank, 1 x P2 grids): variant 1 as
+//       persistent workgroups with the stores of a tile fused with the loads of the next (PassCfg::PERSIST), compiled for that one
+//       pair of address forms (FixForms: with every form in the loop the registers spill): 8.27 -> 7.64 ms at 1024^3 on plain
+//       buffers (profiles/r4_persist3.txt); 249 VGPRs, no scratch.  Any other launch runs variant 1.  Measured and NOT adopted:
+//       the same form for the table store of P1 > 1 plans (rank 0 of 2 x 4: 1.02-1.09 -> 1.03-1.10 ms, of 8 x 1: 1.07 -> 1.10-1.17)
+//       and, in round 3, prefetching the next tile into a second register set (13.3-16.2 ms: it spills).
+using F64_1024_v8 = FixForms<PassCfg<double, 1024, 32, 8, 2, 32, 32, 1, 1, 1, 1, 3, 0, 1, 1>, F64_1024_v1, 1>;
+// A/B only (measured, profiles/r3_strided_read_variants.txt): 32 points per thread on ONE tile of 8 lines (256 threads, 68 KiB of
+// LDS -> two workgroups per CU) 8.49 ms against 7.68; 16 lines on 1024 threads (16 points per thread) 8.9
 using F64_1024_v12 = PassCfg<double, 1024, 32, 8, 1, 32, 32, 1, 1, 1, 1, 3>;
-using F64_1024_v13 = PassCfg<double, 1024, 32, 8, 1, 32, 32, 1, 1, 1, 1, 0>;
-using F64_2048_v12 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 3, 0, 2>;
-// strided read with 16 lines on 1024 threads (16 points per thread, four waves per SIMD instead of two)
 using F64_1024_v14 = PassCfg<double, 1024, 16, 8, 2, 16, 16, 4, 1, 1, 1, 3>;
-using F64_1024_v15 = PassCfg<double, 1024, 16, 8, 2, 16, 16, 4, 1, 1, 1, 0>;
+using F64_2048_v12 = PassCfg<double, 2048, 32, 8, 1, 32, 32, 2, 1, 1, 1, 3, 0, 2>;
 #ifdef DFFT_EXPERIMENTS
 #define DFFT_F64_EXP_SMALL(X)
-#define DFFT_F64_EXP_1024(X) X(1024, 8, F64_1024_v8) X(1024, 9, F64_1024_v9) X(1024, 10, F64_1024_v10) X(1024, 11, F64_1024_v11) X(1024, 12, F64_1024_v12) X(1024, 13, F64_1024_v13) X(1024, 14, F64_1024_v14) X(1024, 15, F64_1024_v15)
-#define DFFT_F64_EXP_2048(X) X(2048, 8, F64_2048_v8) X(2048, 9, F64_2048_v9) X(2048, 10, F64_2048_v10) X(2048, 12, F64_2048_v12)
+#define DFFT_F64_EXP_1024(X) X(1024, 12, F64_1024_v12) X(1024, 14, F64_1024_v14)
+#define DFFT_F64_EXP_2048(X) X(2048, 12, F64_2048_v12)
 #else
 #define DFFT_F64_EXP_SMALL(X)
 #define DFFT_F64_EXP_1024(X)
 #define DFFT_F64_EXP_2048(X)
 #endif
 #define DFFT_F64_LIST_SMALL(X) X(512, 1, F64_512_v1) X(512, 3, F64_512_v3) X(2, 0, F64_2) X(4, 0, F64_4) X(8, 0, F64_8) X(16, 0, F64_16) X(32, 0, F64_32) X(64, 0, F64_64) X(128, 0, F64_128) X(256, 0, F64_256) X(512, 0, F64_512) DFFT_F64_EXP_SMALL(X)
-#define DFFT_F64_LIST_1024(X) X(1024, 1, F64_1024_v1) X(1024, 2, F64_1024_v2) X(1024, 3, F64_1024_v3) X(1024, 0, F64_1024) DFFT_F64_EXP_1024(X)
+#define DFFT_F64_LIST_1024(X) X(1024, 1, F64_1024_v1) X(1024, 2, F64_1024_v2) X(1024, 3, F64_1024_v3) X(1024, 8, F64_1024_v8) X(1024, 0, F64_1024) DFFT_F64_EXP_1024(X)
 #define DFFT_F64_LIST_2048(X) X(2048, 1, F64_2048_v3) X(2048, 3, F64_2048_v3) X(2048, 7, F64_2048_v7) X(2048, 0, F64_2048) X(4096, 0, F64_4096) X(8192, 0, F64_8192) DFFT_F64_EXP_2048(X)
 
 // lengths with a packed real z pass / a Bluestein inner transform of their own configuration

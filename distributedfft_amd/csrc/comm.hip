@@ -6,7 +6,9 @@
 #include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <condition_variable>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -278,6 +280,210 @@ struct CallbackComm : dfft_comm {
         return r;
     }
 };
+
+// ------------------------------------------------------------------------------------------
+// Two-hop relay (see comm.hpp).  Per partner round k = 1 .. ngroup - 1 (rank `me` of a group sends to member me + k and
+// receives from member me - k):
+//   phase A  world all-to-all: part 0 of my message straight to the partner, part 2 + h to helper h (every rank outside the
+//            pair, ascending); I receive part 0 of my source's message in place and, as a helper of every other pair, one
+//            part each into the staging buffer
+//   phase B  world all-to-all: part 1 straight to the partner, every staged part on to its destination; I receive parts
+//            1 .. nranks - 1 of my source's message in place
+// ------------------------------------------------------------------------------------------
+void relay_part(size_t S, int nranks, int p, size_t *off, size_t *len)
+{
+    const size_t parts = (size_t)(nranks < 2 ? 2 : nranks);      // K + 2 with K = nranks - 2 helpers
+    size_t q = (S + parts - 1) / parts;
+    q = (q + 255) & ~(size_t)255;                                 // parts start on 256-byte boundaries
+    const size_t a = std::min(S, (size_t)p * q), b = std::min(S, (size_t)(p + 1) * q);
+    *off = a;
+    *len = b - a;
+}
+
+struct RelayMeta {
+    int R = 0;                        // rounds = group size - 1
+    std::vector<int> partner;         // [y * R + k - 1]: the rank y sends to in round k
+    std::vector<size_t> bytes;        // ... and the size of that message
+};
+struct RelayBuf { char *p = nullptr; size_t cap = 0; bool device = false; };
+struct RelayCache {
+    std::map<uint64_t, RelayMeta> meta;
+    std::map<std::pair<void *, int>, RelayBuf> staging;      // per (stream, channel): calls on one stream are ordered
+    RelayBuf msend, mrecv;
+};
+RelayCache *relay_cache_new() { return new RelayCache; }
+static void relay_buf_free(RelayBuf &b)
+{
+    if (!b.p) return;
+    if (b.device) (void)hipFree(b.p); else free(b.p);
+    b = RelayBuf();
+}
+void relay_cache_free(RelayCache *c)
+{
+    if (!c) return;
+    for (auto &kv : c->staging) relay_buf_free(kv.second);
+    relay_buf_free(c->msend);
+    relay_buf_free(c->mrecv);
+    delete c;
+}
+// is this a device pointer?  (the CPU tests drive the exchange with host tensors through the callback transport)
+static bool relay_on_device(const void *ptr)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, ptr) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeUnified || at.type == hipMemoryTypeManaged;
+}
+static int relay_reserve(RelayBuf &b, size_t bytes, bool device, hipStream_t stream)
+{
+    if (b.p && b.cap >= bytes && b.device == device) return 0;
+    if (b.p && b.device) HIP_TRY(hipStreamSynchronize(stream));      // earlier exchanges on this stream may still read it
+    relay_buf_free(b);
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    if (device) HIP_TRY(hipMalloc((void **)&b.p, bytes));
+    else if (!(b.p = (char *)malloc(bytes))) { set_error("relay: out of host memory"); return 1; }
+    b.cap = bytes;
+    b.device = device;
+    return 0;
+}
+
+static int relay_gather_meta(dfft_comm *comm, RelayCache *cache, RelayMeta &M, int myrank, const size_t *scount, const int *group,
+                             int ngroup, int me, bool device, hipStream_t stream, int channel)
+{
+    const int n = comm->nranks, R = ngroup - 1;
+    const size_t rec = (size_t)R * 2 * sizeof(uint64_t);
+    std::vector<uint64_t> mine((size_t)R * 2), all((size_t)n * R * 2);
+    for (int k = 1; k <= R; k++) {
+        const int ti = (me + k) % ngroup;
+        mine[2 * (k - 1)] = (uint64_t)group[ti];
+        mine[2 * (k - 1) + 1] = (uint64_t)scount[ti];
+    }
+    if (int r = relay_reserve(cache->msend, rec * n, device, stream)) return r;
+    if (int r = relay_reserve(cache->mrecv, rec * n, device, stream)) return r;
+    std::vector<uint64_t> rep((size_t)n * R * 2);
+    for (int y = 0; y < n; y++) memcpy(&rep[(size_t)y * R * 2], mine.data(), rec);
+    std::vector<size_t> cnt(n, rec), dsp(n);
+    std::vector<int> world(n);
+    for (int y = 0; y < n; y++) { dsp[y] = (size_t)y * rec; world[y] = y; }
+    if (device) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(cache->msend.p, rep.data(), rec * n, hipMemcpyHostToDevice));
+    } else memcpy(cache->msend.p, rep.data(), rec * n);
+    if (int r = comm->alltoallv(myrank, cache->msend.p, cnt.data(), dsp.data(), cache->mrecv.p, cnt.data(), dsp.data(), world.data(), n,
+                                myrank, stream, channel)) return r;
+    if (device) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(all.data(), cache->mrecv.p, rec * n, hipMemcpyDeviceToHost));
+    } else memcpy(all.data(), cache->mrecv.p, rec * n);
+    M.R = R;
+    M.partner.resize((size_t)n * R);
+    M.bytes.resize((size_t)n * R);
+    for (int y = 0; y < n; y++)
+        for (int k = 0; k < R; k++) {
+            const uint64_t t = all[((size_t)y * R + k) * 2];
+            if (t >= (uint64_t)n || (int)t == y) { set_error("relay: a rank reported an invalid partner (do all ranks run the same exchange?)"); return 1; }
+            M.partner[(size_t)y * R + k] = (int)t;
+            M.bytes[(size_t)y * R + k] = (size_t)all[((size_t)y * R + k) * 2 + 1];
+        }
+    // every rank must be the partner of exactly one rank per round (the groups partition the world)
+    for (int k = 0; k < R; k++) {
+        std::vector<int> seen(n, 0);
+        for (int y = 0; y < n; y++) seen[M.partner[(size_t)y * R + k]]++;
+        for (int y = 0; y < n; y++)
+            if (seen[y] != 1) { set_error("relay: the groups of this exchange do not partition the world"); return 1; }
+    }
+    return 0;
+}
+
+int relay_alltoallv(dfft_comm *comm, RelayCache *cache, uint64_t tag, int myrank, const void *send, const size_t *scount,
+                    const size_t *sdispl, void *recv, const size_t *rcount, const size_t *rdispl, const int *group, int ngroup,
+                    int me, hipStream_t stream, int channel)
+{
+    const int n = comm->nranks, R = ngroup - 1;
+    const bool device = relay_on_device(send);
+    const char *sb = static_cast<const char *>(send);
+    char *rb = static_cast<char *>(recv);
+    auto it = cache->meta.find(tag);
+    if (it == cache->meta.end()) {
+        RelayMeta M;
+        if (int r = relay_gather_meta(comm, cache, M, myrank, scount, group, ngroup, me, device, stream, channel)) return r;
+        it = cache->meta.emplace(tag, std::move(M)).first;
+    }
+    const RelayMeta &M = it->second;
+    if (M.R != R) { set_error("relay: exchange table changed under its tag"); return 1; }
+    // self block: a local copy, as in every transport
+    if (rcount[me]) {
+        if (device) HIP_TRY(hipMemcpyAsync(rb + rdispl[me], sb + sdispl[me], rcount[me], hipMemcpyDeviceToDevice, stream));
+        else memcpy(rb + rdispl[me], sb + sdispl[me], rcount[me]);
+    }
+    std::vector<int> world(n), src(n);
+    for (int y = 0; y < n; y++) world[y] = y;
+    std::vector<size_t> sc(n), sd(n), rc(n), rd(n), stoff(n), stlen(n);
+    auto helper_index = [](int h, int a, int b) { return h - (a < h) - (b < h); };      // position of h among the ranks outside {a, b}
+    for (int k = 1; k <= R; k++) {
+        const int ti = (me + k) % ngroup, si = (me - k + ngroup) % ngroup;
+        const int t = group[ti], s = group[si];
+        const size_t St = scount[ti], Ss = rcount[si];
+        if (M.partner[(size_t)myrank * R + k - 1] != t || M.partner[(size_t)s * R + k - 1] != myrank || M.bytes[(size_t)s * R + k - 1] != Ss) {
+            set_error("relay: the gathered tables do not match this call");
+            return 1;
+        }
+        for (int y = 0; y < n; y++) src[M.partner[(size_t)y * R + k - 1]] = y;
+        // staging: one part from every rank outside {me, s}
+        size_t need = 0;
+        for (int y = 0; y < n; y++) {
+            stoff[y] = stlen[y] = 0;
+            if (y == myrank || y == s) continue;
+            size_t off, len;
+            relay_part(M.bytes[(size_t)y * R + k - 1], n, 2 + helper_index(myrank, y, M.partner[(size_t)y * R + k - 1]), &off, &len);
+            stoff[y] = need;
+            stlen[y] = len;
+            need += (len + 255) & ~(size_t)255;
+        }
+        RelayBuf &st = cache->staging[std::make_pair((void *)stream, channel)];
+        if (int r = relay_reserve(st, need ? need : 256, device, stream)) return r;
+        // ---- phase A ----
+        const char *sbaseA = sb;
+        char *rbaseA = rb < st.p ? rb : st.p;
+        for (int x = 0; x < n; x++) {
+            sc[x] = sd[x] = rc[x] = rd[x] = 0;
+            if (x == myrank) continue;
+            size_t off, len;
+            relay_part(St, n, x == t ? 0 : 2 + helper_index(x, myrank, t), &off, &len);
+            sc[x] = len;
+            sd[x] = sdispl[ti] + off;
+            if (x == s) {
+                relay_part(Ss, n, 0, &off, &len);
+                rc[x] = len;
+                rd[x] = (size_t)((rb + rdispl[si] + off) - rbaseA);
+            } else {
+                rc[x] = stlen[x];
+                rd[x] = (size_t)((st.p + stoff[x]) - rbaseA);
+            }
+        }
+        if (int r = comm->alltoallv(myrank, sbaseA, sc.data(), sd.data(), rbaseA, rc.data(), rd.data(), world.data(), n, myrank, stream, channel)) return r;
+        // ---- phase B ----
+        const char *sbaseB = sb < st.p ? sb : st.p;
+        for (int x = 0; x < n; x++) {
+            sc[x] = sd[x] = rc[x] = rd[x] = 0;
+            if (x == myrank) continue;
+            size_t off, len;
+            if (x == t) {
+                relay_part(St, n, 1, &off, &len);
+                sc[x] = len;
+                sd[x] = (size_t)((sb + sdispl[ti] + off) - sbaseB);
+            } else {
+                const int y = src[x];      // the rank whose message to x I hold a part of (y != me: only t has me as its source)
+                sc[x] = stlen[y];
+                sd[x] = (size_t)((st.p + stoff[y]) - sbaseB);
+            }
+            relay_part(Ss, n, x == s ? 1 : 2 + helper_index(x, s, myrank), &off, &len);
+            rc[x] = len;
+            rd[x] = rdispl[si] + off;
+        }
+        if (int r = comm->alltoallv(myrank, sbaseB, sc.data(), sd.data(), rb, rc.data(), rd.data(), world.data(), n, myrank, stream, channel)) return r;
+    }
+    return 0;
+}
 
 dfft_comm *make_local_world(int nranks) { return new LocalWorld(nranks); }
 dfft_comm *make_callback_comm(int nranks, int rank, void *fn, void *user)

@@ -306,7 +306,6 @@ struct Options {
     int uniform_tables = 1;  // sides whose segments all start at multiples of 16 points: table entries through wave-uniform
                              // (scalar) loads, PassArgs::luni / suni (0: per-lane vector loads, for A/B runs)
     int shift = -1;          // row-aligned tile windows of odd-pitch point-major stores: -1 auto (fp64), 0 off, 2 always
-    int shift_load = 0;      // 1: row-aligned tile windows for odd-pitch point-major LOADS (the inverse x pass of an R2C plan, fp64)
     int debug = 0;           // PassArgs::debug of every launch (measurement only; results are wrong when set)
     int real_variant = 0;    // A/B configurations of the real z passes (DFFT_EXPERIMENTS builds)
     int single_order = -1;   // single-rank complex plans: 1 = pass order z, x, y with padded private layouts, 0 = z, y, x,
@@ -352,6 +351,7 @@ struct dfft_plan {
     // exchange tables in bytes (row comm = 1, column comm = 2) and member lists
     std::vector<size_t> sc1, sd1, rc1, rd1, sc2, sd2, rc2, rd2;
     std::vector<int> group1, group2;
+    dfft::RelayCache *relay = nullptr;      // two-hop relay of the group exchanges (dfft_comm_set_option "relay"): gathered world tables, staging
     int vfwd[3] = {0, 0, 0}, vinv[3] = {0, 0, 0};   // kernel variant per pass: [0]=z [1]=y [2]=x
     Options opt;
     Pipeline pl;
@@ -401,18 +401,6 @@ static void set_shift(const dfft_plan *p, PassArgs &X)
     if (p->prec != DFFT_F64 && p->opt.shift != 2) return;
     if (X.AS_out % TL == 0 || X.KS_out % TL != 0 || X.LB < TL) return;
     X.shift = 1;
-    X.nb += 1;
-    X.ntiles = X.na * X.nb;
-}
-
-// the mirror image for the inverse x pass, which LOADS the point-major API layout: windows aligned to the cache lines of each
-// input row; row0 = first row of the launch (a pipeline chunk starts at row k0 of the caller's block)
-static void set_shift_load(const dfft_plan *p, PassArgs &X, size_t row0)
-{
-    const uint32_t TL = (uint32_t)p->TL;
-    if (!p->opt.shift_load || p->ax[2].bluestein || p->ax[2].two) return;
-    if (X.AS_in % TL == 0 || X.KS_in % TL != 0 || X.LB < TL || (row0 * X.AS_in) % TL != 0) return;
-    X.shift = 2;
     X.nb += 1;
     X.ntiles = X.na * X.nb;
 }
@@ -514,13 +502,15 @@ static int build_pipeline(dfft_plan *p, Pipeline &pl)
             L.args.KS_in = (uint64_t)yo * zs;
             L.args.AS_in = zs;
             // aligned pitch: step along ky between neighbouring workgroups (DRAM/TLB spread);
-            // odd pitch (R2C): neighbouring z' tiles on one XCD so the shared lines are read once
+            // odd pitch (R2C): neighbouring z' tiles on one XCD so the shared lines are read once.
+            // (Row-aligned LOAD windows -- the mirror image of set_shift -- were measured in round 4 and rejected: the loads become
+            // whole cache lines, but every 128-byte run of the private layout is then written in two pieces by two workgroups:
+            // 3.63 -> 5.88 ms at 1024^3 on 513-wide rows, 0.80 -> 1.03 ms on rank 0 of 2 x 4, profiles/r4_shift_load_rejected.txt)
             L.args.xcd_swizzle = 1;
             L.args.a_fastest = zs % TL == 0 ? 1 : 0;
             L.in_off = e * k0[c] * zs;
             for (int q = 0; q < P1; q++) seg_push(L.sseg, p->xstart[q], p->xs[q], S2i + p->xstart[q] * zs * kl[c]);
             L.args.LA = (uint32_t)kl[c];
-            set_shift_load(p, L.args, k0[c]);
         }
         {   // exchange 2 backwards
             A2A &T = pl.i2[c];
@@ -916,13 +906,24 @@ static int launch_real(dfft_plan *p, const Launch &L, int mode, const char *in, 
 }
 
 static int exchange_tables(dfft_plan *p, int which, const A2A &T, bool forward, const char *send, char *recv,
-                           hipStream_t stream)
+                           hipStream_t stream, uint64_t tag = 0)
 {
     const bool first = which == 1;
     const std::vector<int> &grp = first ? p->group1 : p->group2;
     const int me = first ? p->pj : p->pi;
     if (!p->comm) return fail(ERR_STATE, "exchange without a communicator");
     const int channel = (which == 2 && p->pl.comm_stream2 && stream == p->pl.comm_stream2) ? 1 : 0;
+    // Two-hop relay (comm.hpp): a group that is a strict subset of the world leaves most xGMI links idle -- the column groups of
+    // a 2 x 4 grid drive one link of seven.  Option "relay" of the communicator: bit 0 = exchange 2, bit 1 = exchange 1.
+    if ((p->comm->relay & (first ? 2 : 1)) && grp.size() > 1 && (int)grp.size() < p->comm->nranks) {
+        if (!p->relay) p->relay = relay_cache_new();
+        if (!tag) tag = (uint64_t)(uintptr_t)&T;      // the pipeline's tables live as long as the plan's initialisation
+        const int r = forward ? relay_alltoallv(p->comm, p->relay, tag, p->rank, send, T.sc.data(), T.sd.data(), recv, T.rc.data(), T.rd.data(),
+                                                grp.data(), (int)grp.size(), me, stream, channel)
+                              : relay_alltoallv(p->comm, p->relay, tag, p->rank, send, T.rc.data(), T.rd.data(), recv, T.sc.data(), T.sd.data(),
+                                                grp.data(), (int)grp.size(), me, stream, channel);
+        return r ? fail(r, "relay exchange failed: " + g_error) : 0;
+    }
     // the inverse all-to-all swaps the send and receive tables (mpicufft_pencil_opt1.cpp:829-830)
     if (forward)
         return p->comm->alltoallv(p->rank, send, T.sc.data(), T.sd.data(), recv, T.rc.data(), T.rd.data(), grp.data(),
@@ -936,7 +937,9 @@ static int exchange(dfft_plan *p, int which, bool forward, const void *send, voi
     A2A T;
     T.sc = which == 1 ? p->sc1 : p->sc2; T.sd = which == 1 ? p->sd1 : p->sd2;
     T.rc = which == 1 ? p->rc1 : p->rc2; T.rd = which == 1 ? p->rd1 : p->rd2;
-    return exchange_tables(p, which, T, forward, static_cast<const char *>(send), static_cast<char *>(recv), p->stream);
+    // (the table is a temporary: name it by what it is -- exchange and direction)
+    return exchange_tables(p, which, T, forward, static_cast<const char *>(send), static_cast<char *>(recv), p->stream,
+                           16 + 2 * (uint64_t)which + (forward ? 1 : 0));
 }
 
 
@@ -1474,6 +1477,31 @@ static int dev_alloc(size_t bytes, size_t chunk_mib, void **out)
     return 0;
 }
 
+// The default backing of library-owned device memory (work areas, dfft_malloc(DFFT_CHUNK_DEFAULT)): the virtual-memory API with
+// 1 GiB physical chunks.  Buffers backed this way are systematically better targets for the passes that scatter 128-byte runs
+// than hipMalloc buffers (1024^3 fp64 C2C on one GPU, fresh processes: hipMalloc 37.3-37.5 ms per forward + inverse, 1 GiB chunks
+// 34.9 / 35.3, 2 MiB 35.0 / 35.4, 256 MiB 34.7 / 36.8, 64 MiB 36.7 / 35.0; the 10-second search of dfft_tune_placement 34.1;
+// profiles/r4_fixed_recipes.txt).  The chunk size matters little; 1 GiB means the fewest mappings.  Falls back to smaller chunks
+// (fragmented memory) and finally to hipMalloc, so it never fails where hipMalloc would succeed.  DFFT_DEFAULT_CHUNK_MIB overrides
+// (0 = plain hipMalloc, what rounds 1-3 used for work areas).
+static size_t default_chunk_mib()
+{
+    static const size_t v = [] {
+        const char *e = getenv("DFFT_DEFAULT_CHUNK_MIB");
+        return e ? (size_t)atol(e) : (size_t)1024;
+    }();
+    return v;
+}
+static int dev_alloc_default(size_t bytes, void **out)
+{
+    if (bytes < ((size_t)32 << 20)) return dev_alloc(bytes, 0, out);      // small buffers live in the caches: nothing to place
+    for (size_t c = default_chunk_mib(); c >= 2; c /= 8) {
+        if (dev_alloc(bytes, c, out) == 0) return 0;
+        (void)hipGetLastError();
+    }
+    return dev_alloc(bytes, 0, out);
+}
+
 static int check_ready(dfft_plan *p)
 {
     if (!p) return fail(ERR_ARG, "null plan");
@@ -1529,6 +1557,11 @@ int dfft_comm_info(const dfft_comm *comm, int *nranks, int *transport_nranks)
 int dfft_comm_set_option(dfft_comm *comm, const char *key, long value)
 {
     if (!comm || !key) return fail(ERR_ARG, "null communicator or key");
+    if (std::string(key) == "relay") {      // handled above the transports (comm.hpp): every transport can relay
+        if (value < 0 || value > 3) return fail(ERR_ARG, "relay: 0 off, 1 = exchange 2 (column groups), 2 = exchange 1 (row groups), 3 = both");
+        comm->relay = (int)value;
+        return 0;
+    }
     const int r = comm->set_option(key, value);
     if (r == 1 && g_error.empty()) set_error(std::string("this transport has no option ") + key);
     return r;
@@ -1571,7 +1604,6 @@ static int *option_slot(Options &o, const std::string &k)
     if (k == "point_tables") return &o.tables;
     if (k == "uniform_tables") return &o.uniform_tables;
     if (k == "shift") return &o.shift;
-    if (k == "shift_load") return &o.shift_load;
     if (k == "debug_skip") return &o.debug;
     if (k == "real_variant") return &o.real_variant;
     if (k == "single_order") return &o.single_order;
@@ -1608,6 +1640,7 @@ int dfft_plan_destroy(dfft_plan *p)
     if (!p) return 0;
     graphs_clear(p);
     if (p->work_owned && p->work_d) (void)dev_free(p->work_d);
+    relay_cache_free(p->relay);
     for (auto &a : p->ax) axis_free(a);
     for (void *t : {p->tw_zr, p->tables_d}) if (t) (void)hipFree(t);
     for (auto &t : p->spans) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
@@ -1624,6 +1657,8 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
     if (!p) return fail(ERR_ARG, "null plan");
     p->initialized = false;      // a failed (re-)initialisation must not leave a half-updated plan executable
     graphs_clear(p);
+    relay_cache_free(p->relay);      // gathered per exchange table: the tables are about to change
+    p->relay = nullptr;
     if (!Nx || !Ny || !Nz) return fail(ERR_ARG, "GlobalSize not initialized!");
     if (P1 < 1 || P2 < 1 || P1 * P2 != p->nranks) return fail(ERR_ARG, "Invalid Input Partition!");
     const bool zyx_kind = p->kind == DFFT_SLAB_Z_THEN_YX || p->kind == DFFT_SLAB_Z_THEN_YX_OPT1;
@@ -1757,6 +1792,9 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
             // two workgroups per CU) is 15 % faster there, 3.66 vs 4.26 ms at 1024^3 (profiles/r3_strided_read_odd_pitch.txt)
             const size_t zs_local = p->zs.empty() ? p->Nzc : p->zs[p->zyx ? (size_t)p->rank % p->zs.size() : (size_t)p->pj % p->zs.size()];
             if (has64(p->ax[2], ROLE_STRIDED_READ) && zs_local % (size_t)p->TL == 0) p->vinv[2] = ROLE_STRIDED_READ;
+            // ... and without a second exchange (P1 = 1) its persistent form with stores and loads fused (8.27 -> 7.64 ms at 1024^3,
+            // profiles/r4_persist3.txt); launches that do not have its pair of address forms run ROLE_STRIDED_READ by themselves
+            if (p->vinv[2] == ROLE_STRIDED_READ && p->P1 == 1 && has64(p->ax[2], ROLE_STRIDED_READ_FUSED)) p->vinv[2] = ROLE_STRIDED_READ_FUSED;
             // complex z passes have natural lines on one side and long-run stores
             const int zrole = has64(p->ax[0], ROLE_LINES) ? ROLE_LINES : has64(p->ax[0], ROLE_STREAM) ? ROLE_STREAM : ROLE_DEFAULT;
             if (p->c2c) p->vfwd[0] = p->vinv[0] = zrole;
@@ -1896,7 +1934,7 @@ int dfft_set_work_area(dfft_plan *p, void *device, void *host)
     if (device) {
         p->work_d = device;   // caller keeps ownership (:333-342)
     } else {
-        TRY(dev_alloc(p->worksize_d, 0, &p->work_d));
+        TRY(dev_alloc_default(p->worksize_d, &p->work_d));      // (the virtual-memory backing: see default_chunk_mib)
         p->work_owned = true;
     }
     return 0;
@@ -2178,8 +2216,11 @@ int dfft_fft1d_batched_ex(int precision, size_t N, size_t batch, void *out, cons
     static thread_local Axis ax;
     static thread_local int axP = -1;
     static thread_local int axB = 0;
-    static thread_local void *lvw = nullptr;       // scratch of two-level lines, grown on demand
-    static thread_local size_t lvw_bytes = 0;
+    // scratch of two-level lines, grown on demand, one per stream: two calls of one thread on different streams must not share it
+    // (growing it frees the old one with hipFree, which waits for every launch still using it)
+    static thread_local std::map<void *, std::pair<void *, size_t>> lvw_of;
+    void *&lvw = lvw_of[hip_stream].first;
+    size_t &lvw_bytes = lvw_of[hip_stream].second;
     // variant -1: the Bluestein kernel even where a native configuration exists; -2: two levels wherever the length splits
     const int force = variant == -2 ? 2 : variant < 0 ? 1 : 0;
     if (variant > 15) return fail(ERR_ARG, "variant must be -2 (two-level), -1 (Bluestein) or 0..15");
@@ -2262,6 +2303,7 @@ int dfft_axis_plan_info(int precision, size_t N, int two_level, size_t info[8])
 int dfft_malloc(size_t bytes, size_t chunk_mib, void **ptr)
 {
     if (!ptr) return fail(ERR_ARG, "null pointer");
+    if (chunk_mib == DFFT_CHUNK_DEFAULT) return dev_alloc_default(bytes, ptr);
     return dev_alloc(bytes, chunk_mib, ptr);
 }
 int dfft_free(void *ptr) { return dev_free(ptr); }
@@ -2383,7 +2425,14 @@ static int tune_variants(dfft_plan *p, const void *in, void *o, void *b, float &
         return !a.bluestein && (p->prec == DFFT_F64 ? pass_info_f64((int)a.N, v, &pi) : pass_info_f32((int)a.N, v, &pi));
     };
     auto tunable = [&](int k) { return usable(k) && p->opt.variant[k] < 0 && !p->ax[axis_of(k)].bluestein && !(p->c2c == false && axis_of(k) == 0); };
+    // only the role variants that the parity suite runs on every pass and address form (tests/test_gpu_variants.py); an A/B build
+    // (-DDFFT_EXPERIMENTS) carries further configuration numbers that are measured by hand, never picked here
+    auto validated = [&](int v) {
+        if (p->prec == DFFT_F64) return (v >= 0 && v <= 3) || v == 7 || v == 8;
+        return v == 0 || (v >= 4 && v <= 6) || v == 9;
+    };
     for (int v = 0; v < 16; v++) {
+        if (!validated(v)) continue;
         // does any axis length of the plan have this variant?  (global lengths: the same answer on every rank)
         bool any = false;
         for (int k = 0; k < 3; k++) any = any || exists(k, v);
@@ -2429,7 +2478,7 @@ static int tune_variants(dfft_plan *p, const void *in, void *o, void *b, float &
 }
 
 // physical chunk sizes (MiB) tried in turn; 0 = plain hipMalloc
-static const size_t kPlacementRecipes[] = {0, 64, 1024, 2, 256, 16, 512, 128};
+static const size_t kPlacementRecipes[] = {1024, 64, 2, 256, 0, 16, 512, 128};      // ([0] is never used: the first candidate is the default recipe)
 
 int dfft_tune_variants(dfft_plan *p, const void *in, void *out, void *back, float *report_ms, int max_report, int *n_report)
 {
@@ -2454,6 +2503,11 @@ int dfft_tune_placement(dfft_plan *p, const void *in, int tries, void **out, voi
     TRY(check_ready(p));
     if (!in || !out) return fail(ERR_ARG, "null buffer");
     if (tries < 1) tries = 1;
+    // COLLECTIVE on a multi-rank plan: every trial executes the plan, exchanges included.  How many candidates fit depends on the
+    // rank's own buffer sizes and free memory, so a search there could run a different number of trials on different ranks and
+    // strand the peers in an exchange.  Multi-rank plans therefore get NO candidate search: out / back come from the default
+    // recipe (like the work area) and only the variant trials run, whose count depends on the global grid alone.
+    if (p->nranks > 1) tries = 1;
     size_t isz[3];
     TRY(dfft_get_in_size(p, isz));
     const size_t in_bytes = isz[0] * isz[1] * isz[2] * (p->c2c ? p->esz : p->esz / 2);
@@ -2469,8 +2523,9 @@ int dfft_tune_placement(dfft_plan *p, const void *in, int tries, void **out, voi
     };
     const size_t nrec = sizeof(kPlacementRecipes) / sizeof(kPlacementRecipes[0]);
     void *o = nullptr, *b = nullptr;
-    int rc = dev_alloc(out_bytes, kPlacementRecipes[0], &o);
-    if (rc == 0 && back) rc = dev_alloc(in_bytes, kPlacementRecipes[0], &b);
+    // first candidate of every buffer: the default recipe (what a caller gets from dfft_malloc(DFFT_CHUNK_DEFAULT) without a search)
+    int rc = dev_alloc_default(out_bytes, &o);
+    if (rc == 0 && back) rc = dev_alloc_default(in_bytes, &b);
     float best = 0;
     if (rc == 0) rc = placement_measure(p, in, o, b, 2, &best);
     note(best);

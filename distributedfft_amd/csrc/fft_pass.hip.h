@@ -87,8 +87,6 @@ struct PassArgs {
     int32_t addr64;        // 1: this pass keeps the per-point 64-bit vector addresses (dfft_tune_variants measured them faster here)
     int32_t shift;         // 1: STORE_KMAJOR with an odd row pitch: tile windows follow the cache lines of each
                            //    output row (nb counts one extra tile per row); fft_pass_kernel only
-                           // 2: the same for LOAD_KMAJOR: windows follow the cache lines of each INPUT row (AS_in), the
-                           //    stores then go to the two tiles of the private layout a window straddles
     uint32_t LA;           // STORE_TILED_SAME: extent of the a axis
     uint32_t T2shift;      // STORE_TILED_TRANSPOSE: log2 of the consumer's tile size
     uint64_t KS_in;        // LOAD_KMAJOR point stride
@@ -381,11 +379,13 @@ struct PassCfg {
 };
 
 // A configuration compiled for ONE pair of address forms.  The kernel is an "uber-kernel": load_tile / store_tile branch (uniformly,
-// at run time) over every address form, which costs nothing in a straight-line kernel but makes the persistent forms spill -- every
-// branch the transformed registers flow through multiplies their live ranges (PERSIST = 3 with all forms: 684 B of scratch at 32 fp64
-// points per thread; with one form on each side: 247 VGPRs, no scratch).  kFIX = 1: point-major load with a scalar base (the strided
-// read of the API layout) and same-tile store through wave-uniform tables -- the inverse x pass of a multi-rank plan.  fix_ok() is the
-// launcher's test that a launch has exactly these forms; every other launch goes to Generic.
+// at run time) over every address form, which costs nothing in a straight-line kernel but makes the persistent form spill -- every
+// branch the transformed registers flow through multiplies their live ranges (PERSIST with all forms: 684 B of scratch at 32 fp64
+// points per thread; with one form on each side: 249 VGPRs, no scratch; profiles/r3_persist3_resources.txt).  kFIX = 1: point-major
+// load with a scalar base (the strided read of the API layout) and same-tile store into ONE block -- the inverse x pass of a plan
+// without a second exchange (P1 = 1).  fix_ok() is the launcher's test that a launch has exactly these forms; every other launch
+// goes to Generic.  (The sibling for the table store of P1 > 1 plans was measured in round 4 and dropped: no gain,
+// profiles/r4_persist3.txt.)
 template <typename Base, typename GenericCfg, int FIX> struct FixForms : Base {
     using Generic = GenericCfg;
     static constexpr int kFIX = FIX;
@@ -394,13 +394,7 @@ template <typename Cfg> inline bool fix_ok(const PassArgs &A)
 {
     if constexpr (Cfg::kFIX == 1) {
         using C = typename Cfg::C;
-        const uint64_t sk = A.SK ? A.SK : (uint64_t)A.LB * A.LA;
-        (void)sk;
-        return A.load_kind == LOAD_KMAJOR && A.store_kind == STORE_TILED_SAME && Cfg::UNI_STORE_SAME && A.stab && A.suni && !A.shift &&
-               ((uint64_t)(Cfg::NT - 1) * A.KS_in + (uint64_t)A.na * A.AS_in + A.LB + Cfg::kTL) * sizeof(C) < (1ull << 32);
-    } else if constexpr (Cfg::kFIX == 2) {      // ... -> same-tile store into ONE block, scalar base (one rank, slab plans: no exchange 2)
-        using C = typename Cfg::C;
-        return A.load_kind == LOAD_KMAJOR && A.store_kind == STORE_TILED_SAME && !A.stab && A.snseg == 1 && !A.shift &&
+        return A.load_kind == LOAD_KMAJOR && A.store_kind == STORE_TILED_SAME && !A.stab && A.snseg == 1 && !A.shift && !A.addr64 && !(A.debug & 2) &&
                ((uint64_t)(Cfg::NT - 1) * A.KS_in + (uint64_t)A.na * A.AS_in + A.LB + Cfg::kTL) * sizeof(C) < (1ull << 32);
     } else return true;
 }
@@ -723,7 +717,7 @@ template <typename Cfg> __device__ __forceinline__ TilePos<Cfg::kTL> tile_pos(co
     P.a = !ok ? 0 : (A.a_fastest ? w % A.na : w / A.nb);
     P.b = !ok ? 0 : (A.a_fastest ? w / A.na : w % A.nb);
     if (A.shift) {
-        const uint32_t s = (uint32_t)((uint64_t)P.a * (A.shift == 2 ? A.AS_in : A.AS_out)) & (uint32_t)(TL - 1);
+        const uint32_t s = (uint32_t)((uint64_t)P.a * A.AS_out) & (uint32_t)(TL - 1);
         const int ei = (int)(P.b * TL + P.l) - (int)s;
         ok = ok && ei >= 0 && (uint32_t)ei < A.LB;
         P.e = ok ? (uint32_t)ei : 0;
@@ -769,7 +763,7 @@ __device__ __forceinline__ void load_tile(const PassArgs &A, const typename Cfg:
     constexpr int N = Cfg::kN, TL = Cfg::kTL, NT = Cfg::NT;
     const uint32_t a = P.a, b = P.b, tw = P.tw;
     const int l = P.l;
-    if constexpr (Cfg::kFIX == 1 || Cfg::kFIX == 2) {          // LOAD_KMAJOR, scalar base (fix_ok has checked the range)
+    if constexpr (Cfg::kFIX == 1) {          // LOAD_KMAJOR, scalar base (fix_ok has checked the range)
         if (P.ok) {
             const uint32_t lane = (uint32_t)(((uint64_t)t * A.KS_in + (uint64_t)a * A.AS_in + P.e) * sizeof(C));
             const char *ub = reinterpret_cast<const char *>(in);
@@ -873,22 +867,7 @@ __device__ __forceinline__ void store_tile(const PassArgs &A, typename Cfg::C *_
     if (!P.ok) return;
     const uint32_t a2 = P.a, b2 = P.b, tws = P.tw, e2 = P.e;
     const int l2 = P.l;
-    if constexpr (Cfg::kFIX == 1) {          // STORE_TILED_SAME through wave-uniform tables (the branch below, alone)
-        const int t0 = __builtin_amdgcn_readfirstlane(t2);
-        const uint32_t dt = (uint32_t)(t2 - t0);
-        const SegEntry *tab = A.stab + t0;
-        const uint64_t sk = A.SK ? A.SK : (uint64_t)A.LB * A.LA;
-        C *pl = out + ((uint64_t)b2 * (A.SB ? A.SB : (uint64_t)TL * A.LA) + (uint64_t)a2 * tws + l2 + (uint64_t)dt * sk);
-        static_for<C0, C1>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            constexpr int k0 = NT * (c % S) + brev(c / S, RL) * (N / RL);
-            const SegEntry e = seg_entry_uniform(tab + k0);
-            stream_store<Cfg>(pl + e.base, v[c]);
-        });
-        (void)e2;
-        return;
-    }
-    if constexpr (Cfg::kFIX == 2) {          // STORE_TILED_SAME into one block: the lane's part once (tiles may differ from lane to lane:
+    if constexpr (Cfg::kFIX == 1) {          // STORE_TILED_SAME into one block: the lane's part once (tiles may differ from lane to lane:
         // two tiles per workgroup), the point's k0 rows as a scalar offset
         const uint64_t sk = A.SK ? A.SK : (uint64_t)A.LB * A.LA, sb = A.SB ? A.SB : (uint64_t)TL * A.LA;
         C *pl = out + (A.sseg->base[0] - (uint64_t)A.sseg->start[0] * sk + (uint64_t)b2 * sb + (uint64_t)a2 * tws + l2 + (uint64_t)t2 * sk);
@@ -1056,37 +1035,17 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
         if (!(A.debug & 1)) transform<Cfg>(v, lds, W, t, lw, t2, lw2);
         static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].y *= sgn; });
         store_tile<Cfg>(A, out, tile_pos<Cfg>(A, blk, lw2), t2, v);
-    } else if constexpr (Cfg::kPERSIST == 1) {
-        // Persistent, software-pipelined form for configurations that leave room for only ONE workgroup on a CU (a tile of
-        // 16 lines x 1024 fp64 points is the LDS plane of a CU): the grid is one workgroup per CU, each walks the tiles
-        // blockIdx.x, blockIdx.x + gridDim.x, ... and issues the global loads of its NEXT tile into a second register set
-        // before it transforms the current one, so that the memory system works during the butterflies, LDS exchanges and
-        // barriers (two tiles in flight per CU, like two resident workgroups, inside the 512 registers a lane has at two
-        // waves per SIMD).  The virtual workgroup index keeps the XCD of the hardware workgroup (gridDim.x % 8 == 0).
-        const uint32_t nwg = (A.ntiles + Cfg::kG - 1) / Cfg::kG * Cfg::kSUB;
-        uint32_t vid = blockIdx.x;
-        C vn[E];
-        load_tile<Cfg>(A, in, tile_pos<Cfg>(A, logical_block<(Cfg::kSUB > 1)>(A, vid, nwg), lw), t, vn);
-        for (;;) {
-            C v[E];
-            static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = vn[c]; v[c].y *= sgn; });
-            const uint32_t cur = logical_block<(Cfg::kSUB > 1)>(A, vid, nwg);
-            vid += gridDim.x;
-            const bool more = vid < nwg;
-            if (more) load_tile<Cfg>(A, in, tile_pos<Cfg>(A, logical_block<(Cfg::kSUB > 1)>(A, vid, nwg), lw), t, vn);
-            if (!(A.debug & 1)) transform<Cfg>(v, lds, W, t, lw, t2, lw2);
-            static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].y *= sgn; });
-            store_tile<Cfg>(A, out, tile_pos<Cfg>(A, cur, lw2), t2, v);
-            if (!more) break;
-            if constexpr (Cfg::NPASS > 1) __syncthreads();      // the next tile's first scatter reuses the LDS plane
-        }
-    } else if constexpr (Cfg::kPERSIST == 3) {
-        // PERSIST == 3 (round 3, prepared on the CPU, NOT yet measured): the same walk with the STORES of a tile fused with the LOADS
-        // of the next one, register by register.  A register that has been handed to a store is free, so the next tile's load can go
-        // into the very same register: no second register set (the reason PERSIST 1 / 2 spilled), and while the loads of tile i + 1
-        // are in flight the stores of tile i drain -- a one-workgroup-per-CU configuration then pays max(load, store) + compute per
-        // tile instead of load + compute + store.  The chunks of CH registers bound the code size (each chunk carries the uniform
-        // address-form branches of store_tile and load_tile once).
+    } else {
+        // PERSIST: persistent workgroups with the STORES of a tile fused with the LOADS of the next one, register by register, for
+        // configurations that leave room for only ONE workgroup on a CU (a tile of 16 lines x 1024 fp64 points is the LDS plane of a
+        // CU): the grid is one workgroup per CU, each walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ...  A register that has
+        // been handed to a store is free (gfx9 stores read their data at issue), so the next tile's load goes into the very same
+        // register: no second register set -- prefetching the next tile into one was measured in round 3 and spilled (13.3 - 16.2 ms
+        // against 7.68, profiles/r3_strided_read_variants.txt) -- and while the loads of tile i + 1 are in flight the stores of tile i
+        // drain: max(load, store) + compute per tile instead of load + compute + store.  Measured (profiles/r4_persist3.txt): the
+        // strided read of the API layout at 1024^3 fp64 on one rank 8.27 -> 7.64 ms; no gain on the per-GPU plans of 8 ranks (x^-1 is
+        // bound by its access pattern there, not by the phases of a tile).  The chunks of CH registers bound the code size.  The
+        // virtual workgroup index keeps the XCD of the hardware workgroup (gridDim.x % 8 == 0).
         const uint32_t nwg = (A.ntiles + Cfg::kG - 1) / Cfg::kG * Cfg::kSUB;
         uint32_t vid = blockIdx.x;
         C v[E];
@@ -1108,37 +1067,6 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
             });
             if (!more) break;
             if constexpr (Cfg::NPASS > 1) __syncthreads();      // the next tile's first scatter reuses the LDS plane
-        }
-    } else {
-        // PERSIST == 2: the same walk with HALF of the next tile prefetched during the transform, for configurations whose
-        // points fill half of the registers of a lane (32 fp64 points at two waves per SIMD: 128 of 256 registers).  The
-        // other half is requested between the two halves of the current tile's stores, into the registers the first half
-        // of the stores has just freed, so that the memory system always has at least half a tile of reads outstanding.
-        constexpr int H = E / 2;
-        const uint32_t nwg = (A.ntiles + Cfg::kG - 1) / Cfg::kG * Cfg::kSUB;
-        uint32_t vid = blockIdx.x;
-        C va[H], vb[H];
-        {
-            const TilePos<Cfg::kTL> P0 = tile_pos<Cfg>(A, logical_block<(Cfg::kSUB > 1)>(A, vid, nwg), lw);
-            load_tile<Cfg, 0, H>(A, in, P0, t, va);
-            load_tile<Cfg, H, E>(A, in, P0, t, vb - H);
-        }
-        for (;;) {
-            C v[E];
-            static_for<0, H>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c] = va[c]; v[c].y *= sgn; v[c + H] = vb[c]; v[c + H].y *= sgn; });
-            const uint32_t cur = logical_block<(Cfg::kSUB > 1)>(A, vid, nwg);
-            vid += gridDim.x;
-            const bool more = vid < nwg;
-            const TilePos<Cfg::kTL> Pn = tile_pos<Cfg>(A, logical_block<(Cfg::kSUB > 1)>(A, more ? vid : cur, nwg), lw);
-            if (more) load_tile<Cfg, 0, H>(A, in, Pn, t, va);
-            if (!(A.debug & 1)) transform<Cfg>(v, lds, W, t, lw, t2, lw2);
-            static_for<0, E>([&](auto cc) { constexpr int c = decltype(cc)::value; v[c].y *= sgn; });
-            const TilePos<Cfg::kTL> Ps = tile_pos<Cfg>(A, cur, lw2);
-            store_tile<Cfg, 0, H>(A, out, Ps, t2, v);
-            if (more) load_tile<Cfg, H, E>(A, in, Pn, t, vb - H);
-            store_tile<Cfg, H, E>(A, out, Ps, t2, v);
-            if (!more) break;
-            if constexpr (Cfg::NPASS > 1) __syncthreads();
         }
     }
 }

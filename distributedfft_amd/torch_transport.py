@@ -40,9 +40,12 @@ class TorchComm:
         for j in range(P2):
             ranks = [i * P2 + j for i in range(P1)]
             self.groups[tuple(ranks)] = dist.new_group(ranks) if len(ranks) > 1 else None
+        # the whole world: the two-hop relay (option "relay") runs world-wide all-to-alls; None = the default group
+        self.groups.setdefault(tuple(range(world)), None)
         self.buffers = []
         self.comm = api.Comm.callback(world, rank, self._alltoallv)
         self.calls = 0
+        self.p2p_calls = 0
 
     def register(self, tensor):
         """make a tensor's storage known to the pointer -> tensor lookup"""
@@ -53,19 +56,46 @@ class TorchComm:
             base = t.data_ptr()
             if base <= ptr and ptr + nbytes <= base + t.numel():
                 return t[ptr - base: ptr - base + nbytes]
-        raise RuntimeError(f"exchange buffer {ptr:#x}+{nbytes} is not registered with the torch transport")
+        # memory the library owns (the relay's staging and table buffers): wrap the raw pointer
+        if self.buffers and self.buffers[0].is_cuda:
+            return torch.as_tensor(api.DeviceBuffer(ptr, nbytes, owned=False), device="cuda")
+        import ctypes
+        import numpy as np
+        return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(ptr)))
+
+    def _p2p(self, send, sc, sd, recv, rc, rd, group, me, pg):
+        """peer blocks that are not laid out back to back (the relay's pieces): one send / receive per peer"""
+        ops = []
+        for q, peer in enumerate(group):
+            if q == me:
+                if rc[q]:
+                    self._slice(recv + rd[q], rc[q]).copy_(self._slice(send + sd[q], sc[q]))
+                continue
+            if sc[q]:
+                ops.append(self.dist.P2POp(self.dist.isend, self._slice(send + sd[q], sc[q]), peer, group=pg))
+            if rc[q]:
+                ops.append(self.dist.P2POp(self.dist.irecv, self._slice(recv + rd[q], rc[q]), peer, group=pg))
+        if ops:
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
+        self.p2p_calls += 1
 
     def _alltoallv(self, send, sc, sd, recv, rc, rd, group, me, stream):
-        for q in range(1, len(group)):   # peer blocks are laid out back to back in rank order
-            assert sd[q] == sd[q - 1] + sc[q - 1] and rd[q] == rd[q - 1] + rc[q - 1]
-        s = self._slice(send + sd[0], sum(sc)).view(torch.int64)
-        r = self._slice(recv + rd[0], sum(rc)).view(torch.int64)
+        packed = all(sd[q] == sd[q - 1] + sc[q - 1] and rd[q] == rd[q - 1] + rc[q - 1] for q in range(1, len(group)))
+        packed = packed and all(c % 8 == 0 for c in sc + rc) and sum(sc) > 0 and sum(rc) > 0
+        if packed:      # peer blocks back to back in rank order: one all_to_all_single
+            s = self._slice(send + sd[0], sum(sc)).view(torch.int64)
+            r = self._slice(recv + rd[0], sum(rc)).view(torch.int64)
+        on_device = bool(self.buffers and self.buffers[0].is_cuda)
 
         def run():
-            self.dist.all_to_all_single(r, s, output_split_sizes=[c // 8 for c in rc],
-                                        input_split_sizes=[c // 8 for c in sc], group=self.groups[tuple(group)])
+            if packed:
+                self.dist.all_to_all_single(r, s, output_split_sizes=[c // 8 for c in rc],
+                                            input_split_sizes=[c // 8 for c in sc], group=self.groups[tuple(group)])
+            else:
+                self._p2p(send, sc, sd, recv, rc, rd, group, me, self.groups[tuple(group)])
 
-        if s.is_cuda:
+        if on_device:
             # the library hands over the HIP stream this exchange is ordered on (its communication
             # stream); torch collectives order themselves against torch's *current* stream
             with torch.cuda.stream(torch.cuda.ExternalStream(stream or 0)):

@@ -96,7 +96,15 @@ int dfft_comm_info(const dfft_comm *comm, int *nranks, int *transport_nranks);
  * the same point): duplicate the communicator (ncclCommSplit) for the second exchange of pencil plans, so that the row-
  * and the column-group exchange -- which use disjoint xGMI links -- may be on the wire at the same time; without it one
  * ncclComm serialises them.  Replaces nothing in the reference (its two MPI sub-communicators are independent by
- * construction, src/pencil/mpicufft_pencil_opt1.cpp:103-104).  Returns 0, or nonzero for an unknown key / a failure. */
+ * construction, src/pencil/mpicufft_pencil_opt1.cpp:103-104).
+ * "relay" = 0..3 (every transport; a flag, not collective by itself, but every rank must set the same value before the next
+ * exec): two-hop relay of the group exchanges.  bit 0 = exchange 2 (column groups), bit 1 = exchange 1 (row groups).  xGMI is
+ * point to point, so the column groups of a 2 x 4 pencil grid move half of the volume over ONE of a GPU's seven links; with the
+ * relay a message is cut into nranks parts, two travel directly and each of the others through one of the ranks outside the
+ * pair, as two world-wide all-to-alls (all links equally loaded in both; 1 GiB: 7.0 -> 1.75 ms at 153 GB/s per link).  The bytes
+ * land exactly where the direct exchange puts them.  The reference's answer to its slow exchanges was per-peer overlap
+ * (src/pencil/mpicufft_pencil_opt1.cpp:1116-1275); this is the xGMI analogue.  Default off.
+ * Returns 0, or nonzero for an unknown key / a failure. */
 int dfft_comm_set_option(dfft_comm *comm, const char *key, long value);
 /* destroy the plans that use a communicator before the communicator itself */
 int dfft_comm_destroy(dfft_comm *comm);
@@ -280,7 +288,14 @@ int dfft_axis_plan_info(int precision, size_t N, int two_level, size_t info[8]);
  * The passes that write 128-byte runs (y, x) run 5-10 % faster or slower depending on the PHYSICAL backing of the
  * buffer they scatter to -- per buffer, for the life of the allocation (profiles/r3_placement.txt).
  * dfft_malloc: chunk_mib = 0 is hipMalloc; otherwise one virtual range backed by physical allocations of chunk_mib MiB
- * each (HIP virtual-memory API).  Free with dfft_free (which also takes pointers it did not allocate: hipFree). */
+ * each (HIP virtual-memory API).  chunk_mib = DFFT_CHUNK_DEFAULT: the library's default backing -- 1 GiB chunks, smaller
+ * ones and finally hipMalloc if that fails -- which is also what the library uses for a work area it owns
+ * (dfft_init(allocate = 1), dfft_set_work_area(plan, NULL, NULL)).  A caller that allocates `out` (and the inverse's output)
+ * this way gets, without any search, within 1-4 % of what dfft_tune_placement finds in ten seconds; plain hipMalloc buffers
+ * are ~10 % slower on the scatter passes (profiles/r4_fixed_recipes.txt).  Environment DFFT_DEFAULT_CHUNK_MIB overrides the
+ * default (0 = hipMalloc).  Free with dfft_free (which also takes pointers it did not allocate: hipFree; it synchronises the
+ * device first, like hipFree). */
+#define DFFT_CHUNK_DEFAULT ((size_t)-1)
 int dfft_malloc(size_t bytes, size_t chunk_mib, void **ptr);
 int dfft_free(void *ptr);
 /* Tries up to `tries` backings for the plan's own work area (only when the library owns it), for a new output buffer
@@ -288,8 +303,10 @@ int dfft_free(void *ptr);
  * transform's output), one buffer at a time, and keeps for each the backing on which the plan's own FFT passes
  * (forward in -> out, inverse out -> back; exchanges not counted) run fastest.  `in` must hold a valid input block; it
  * is only read.  Afterwards the y / x passes try their streaming (nontemporal) kernel configuration on the chosen buffers and
- * keep it where it measures faster.  *out / *back are freed with dfft_free.  On a multi-rank plan the call is collective (it
- * executes the plan about 3 * tries + 30 times).  report_ms (optional): the measured pass time of every trial in order, *n_report
+ * keep it where it measures faster.  *out / *back are freed with dfft_free.  On a multi-rank plan the call is collective and
+ * does NOT search (how many candidates fit is a per-rank matter: ranks running different numbers of trials would strand each
+ * other in an exchange): out / back come from the default backing and only the configuration trials run, whose number depends
+ * on the global grid alone.  report_ms (optional): the measured pass time of every trial in order, *n_report
  * entries. */
 int dfft_tune_placement(dfft_plan *plan, const void *in, int tries, void **out, void **back, float *report_ms,
                         int max_report, int *n_report);

@@ -22,6 +22,7 @@
 
 #include <hip/hip_runtime_api.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include "dfft_c.h"
 #include "timer_amd.hpp"
@@ -189,8 +190,10 @@ public:
         startTimer(global_size, partition);
         check(dfft_init(plan_, global_size->Nx, global_size->Ny, global_size->Nz, (int)partition->P1,
                         (int)partition->P2, /*c2c=*/0, allocate));
-        check(dfft_enable_phase_timing(plan_, 1));
-        timer->stop_store("init");
+        if (timer) {
+            check(dfft_enable_phase_timing(plan_, 1));
+            timer->stop_store("init");
+        }
     }
     // complex-to-complex plan (extension): same layouts with Nz_out = Nz
     void initFFT_C2C(GlobalSize *g, Partition *p, bool allocate = true)
@@ -198,8 +201,10 @@ public:
         if (!plan_) return;
         startTimer(g, p);
         check(dfft_init(plan_, g->Nx, g->Ny, g->Nz, (int)p->P1, (int)p->P2, 1, allocate));
-        check(dfft_enable_phase_timing(plan_, 1));
-        timer->stop_store("init");
+        if (timer) {
+            check(dfft_enable_phase_timing(plan_, 1));
+            timer->stop_store("init");
+        }
     }
     virtual void setWorkArea(void *device = nullptr, void *host = nullptr) { if (plan_) check(dfft_set_work_area(plan_, device, host)); }
     virtual void execR2C(void *out, const void *in) { if (plan_) timed(DFFT_FORWARD, [&] { return dfft_exec_r2c(plan_, out, in); }); }
@@ -240,7 +245,19 @@ protected:
         const bool zyx = kind_ == DFFT_SLAB_Z_THEN_YX || kind_ == DFFT_SLAB_Z_THEN_YX_OPT1, yzx = kind_ == DFFT_SLAB_Y_THEN_ZX;
         const int opt = (kind_ == DFFT_PENCIL_OPT1 || kind_ == DFFT_SLAB_OPT1 || kind_ == DFFT_SLAB_Z_THEN_YX_OPT1) ? 1 : 0;
         const std::string sub = pencil ? "/pencil" : zyx ? "/slab_z_then_yx" : yzx ? "/slab_y_then_zx" : "/slab_default";
-        mkdir((config.benchmark_dir + sub).c_str(), 0777);
+        // The section timer costs every exec an event pair per pass and, after the warm-up rounds, an MPI_Gatherv plus a file
+        // append (the reference's hidden collective, src/pencil/mpicufft_pencil_opt1.cpp:1515-1518).  It only runs when its CSV can
+        // be written: rank 0 (the gathering rank) tests the directory, everybody follows its verdict.
+        delete timer;
+        timer = nullptr;
+        int usable = 0;
+        if (pidx == 0 && !config.benchmark_dir.empty()) {
+            (void)mkdir(config.benchmark_dir.c_str(), 0777);
+            (void)mkdir((config.benchmark_dir + sub).c_str(), 0777);
+            usable = access((config.benchmark_dir + sub).c_str(), W_OK | X_OK) == 0;
+        }
+        MPI_Bcast(&usable, 1, MPI_INT, 0, world_);
+        if (!usable) return;
         std::string f = config.benchmark_dir + sub + "/test_" + std::to_string(opt) + "_" + std::to_string((int)config.comm_method) + "_" +
                         std::to_string((int)config.send_method);
         if (pencil) f += "_" + std::to_string((int)config.comm_method2) + "_" + std::to_string((int)config.send_method2);
@@ -270,21 +287,22 @@ protected:
             d.push_back("1D FFT X-Direction");
         }
         d.push_back("Run complete");
-        delete timer;
         timer = new Timer(world_, 0, pcnt, pidx, d, f);
         timer->start();
     }
     // runs one exec, then stores the sections it went through (cumulative milliseconds like the reference's stop points; the
     // library's device events per phase instead of MPI_Wtime() after host-side synchronisations) and appends a block to the CSV
     // when the warm-up rounds are used up (src/pencil/mpicufft_pencil_opt1.cpp:1515-1518)
-    template <typename F> void timed(int direction, F &&exec)
+    // partial = true (exec*(out, in, d) with d < 3): fewer phases come back than the class's section list assumes, so only the
+    // total ("Run complete") is recorded
+    template <typename F> void timed(int direction, F &&exec, bool partial = false)
     {
         if (!timer) { check(exec()); return; }
         timer->start();
         check(exec());
         timer->stop("Run complete");
         float ph[5] = {0, 0, 0, 0, 0};
-        const int n = dfft_get_phase_times(plan_, ph, 5);
+        const int n = partial ? 0 : dfft_get_phase_times(plan_, ph, 5);
         const bool pencil = kind_ == DFFT_PENCIL || kind_ == DFFT_PENCIL_OPT1;
         const bool zyx = kind_ == DFFT_SLAB_Z_THEN_YX || kind_ == DFFT_SLAB_Z_THEN_YX_OPT1, yzx = kind_ == DFFT_SLAB_Y_THEN_ZX;
         const char *done = config.comm_method == Peer2Peer ? "(Finished Receive)" : "(Finished All2All)";
@@ -386,11 +404,11 @@ public:
     // partial transforms execR2C/execC2R(out, in, d), include/mpicufft_pencil.hpp:101-111
     virtual void execR2C(void *out, const void *in, int d)
     {
-        if (this->plan_) this->timed(DFFT_FORWARD, [&] { return dfft_exec_dim(this->plan_, out, const_cast<void *>(in), DFFT_FORWARD, d); });
+        if (this->plan_) this->timed(DFFT_FORWARD, [&] { return dfft_exec_dim(this->plan_, out, const_cast<void *>(in), DFFT_FORWARD, d); }, d < 3);
     }
     virtual void execC2R(void *out, const void *in, int d)
     {
-        if (this->plan_) this->timed(DFFT_INVERSE, [&] { return dfft_exec_dim(this->plan_, out, const_cast<void *>(in), DFFT_INVERSE, d); });
+        if (this->plan_) this->timed(DFFT_INVERSE, [&] { return dfft_exec_dim(this->plan_, out, const_cast<void *>(in), DFFT_INVERSE, d); }, d < 3);
     }
     // include/mpicufft_pencil.hpp:112-116; tables as built in src/pencil/mpicufft_pencil_opt1.cpp:70-93
     void getPartitionDimensions(Partition_Dimensions &input_dim_, Partition_Dimensions &transposed_dim_, Partition_Dimensions &output_dim_)

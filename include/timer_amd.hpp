@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <fstream>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -66,7 +67,10 @@ protected:
     size_t index_of(const std::string &desc) const
     {
         const auto it = std::find(descs.begin(), descs.end(), desc);
-        return it == descs.end() ? 0 : (size_t)std::distance(descs.begin(), it);
+        // (the reference's stop_store on an unknown section writes through a default-constructed map slot; here it is an error
+        // instead of a silent overwrite of section 0, "init")
+        if (it == descs.end()) throw std::runtime_error("Timer: unknown section \"" + desc + "\"");
+        return (size_t)std::distance(descs.begin(), it);
     }
     MPI_Comm comm;
     int p_gather;

@@ -89,6 +89,9 @@ def main():
     if len(sys.argv) > 4:
         return sequence_main(sys.argv[4], rank, world, shape)
     tc = TorchComm(dist, rank, world, P1, P2)
+    relay = int(os.environ.get("DFFT_TEST_RELAY", "0"))
+    if relay:       # two-hop relay of the group exchanges (include/dfft_c.h: dfft_comm_set_option "relay")
+        tc.comm.setOption("relay", relay)
     plan = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), tc, precision="double", rank=rank)
     plan.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(P1, P2), allocate=False, c2c=True)
     assert plan.getRank() == rank and plan.getWorldSize() == world
@@ -148,8 +151,17 @@ def main():
     want = np.fft.fftn(g)[:, ost[1]:ost[1] + yo, ost[2]:ost[2] + zs]
     err = np.max(np.abs(got - want)) / np.max(np.abs(want))
     assert err < 1e-12, err
-    nexch = (P1 > 1) + 2 * (P2 > 1)
-    assert tc.calls == nexch, (tc.calls, nexch)
+    # a relayed exchange (group = a strict subset of the world) is one table gather at its first use plus two world-wide
+    # all-to-alls per partner, whose pieces are not back to back (the transport's per-peer path)
+    def ncalls(bit, ng):
+        if ng <= 1:
+            return 0, 0
+        if relay & bit and ng < world:
+            return 1 + 2 * (ng - 1), 2 * (ng - 1)
+        return 1, 0
+    c2, p2 = ncalls(1, P1)
+    c1, p1 = ncalls(2, P2)
+    assert tc.calls == c2 + 2 * c1 and tc.p2p_calls == p2 + 2 * p1, (tc.calls, tc.p2p_calls, c2, c1, p2, p1)
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank} ok err={err:.2e}")

@@ -21,12 +21,26 @@ def free_port():
                                              (3, 2, "16x16x16", ""), (3, 1, "16x16x8", ""),
                                              (2, 1, "16x8x8", "zyx"), (3, 1, "16x6x10", "zyx"), (2, 1, "8x8x16", "yzx"), (3, 1, "10x16x6", "yzx")])
 def test_gloo_exchange_path(P1, P2, shape, seq):
+    run_world(P1, P2, shape, seq)
+
+
+@pytest.mark.parametrize("relay", [1, 2, 3])
+@pytest.mark.parametrize("P1,P2,shape", [(2, 2, "16x16x8"), (2, 3, "12x18x16"), (3, 2, "18x16x10"), (2, 2, "10x6x14")])
+def test_gloo_relayed_exchange_path(P1, P2, shape, relay):
+    """the two-hop relay (dfft_comm_set_option "relay": bit 0 = exchange 2, bit 1 = exchange 1) on the torch transport over gloo:
+    every group exchange becomes world-wide all-to-alls of message parts; the blocks must arrive exactly where the direct
+    exchange puts them (the worker checks the transform, the mirror property of the inverse exchange and the call counts).
+    Uneven splits (10 = 5 + 5 rows of 6 / 14 columns, 18 = 6 + 6 + 6 ...), groups of 2 and 3, worlds of 4 and 6."""
+    run_world(P1, P2, shape, "", {"DFFT_TEST_RELAY": str(relay)})
+
+
+def run_world(P1, P2, shape, seq, extra_env=None):
     world = P1 * P2
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="1")
+                   OMP_NUM_THREADS="1", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_gloo_worker.py"), str(P1), str(P2), shape] + ([seq] if seq else []),
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []

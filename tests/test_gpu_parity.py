@@ -79,11 +79,13 @@ def test_golden_fixture_single_rank():
     assert rel(got, d["c2c_8x8x8"]) < 1e-11
 
 
-def run_distributed(shape, P1, P2, prec, seed=7, chunks=None, options=None):
+def run_distributed(shape, P1, P2, prec, seed=7, chunks=None, options=None, comm_options=None):
     """P1*P2 virtual ranks on one GPU (one host thread per rank, like MPI ranks sharing a
     device: tests/src/pencil/random_dist_3D.cu:175-177)."""
     P = P1 * P2
     world = dfft.Comm.local(P)
+    for k, v in (comm_options or {}).items():
+        world.setOption(k, v)
     esz = 16 if prec == "double" else 8
     plans, ins, outs, backs = [], [], [], []
     for r in range(P):
@@ -145,9 +147,11 @@ RDT = {"double": torch.float64, "float": torch.float32}
 NPR = {"double": np.float64, "float": np.float32}
 
 
-def run_distributed_real(shape, P1, P2, prec, field=None, seed=13, modify=None, options=None):
+def run_distributed_real(shape, P1, P2, prec, field=None, seed=13, modify=None, options=None, comm_options=None):
     P = P1 * P2
     world = dfft.Comm.local(P) if P > 1 else None
+    for k, v in (comm_options or {}).items():
+        world.setOption(k, v)
     esz = 16 if prec == "double" else 8
     plans, ins, outs, backs = [], [], [], []
     for r in range(P):

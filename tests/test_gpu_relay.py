@@ -1,0 +1,65 @@
+"""Two-hop relay of the group exchanges (include/dfft_c.h: dfft_comm_set_option "relay"; csrc/comm.hip relay_alltoallv) on
+virtual ranks of one GPU: every message is cut into nranks parts, two travel directly and the others through the ranks outside
+the pair, as two world-wide all-to-alls per partner.  The bytes must land exactly where the direct exchange puts them, so the
+spectrum and the round trip are BIT-identical to the direct run -- on even and uneven splits, pipeline depths 1-4, groups of
+2, 3 and 4, C2C and R2C.  The reference's counterpart is its per-peer overlap (src/pencil/mpicufft_pencil_opt1.cpp:1116-1275);
+the multi-process form of the same layer runs over gloo in tests/test_cpu_multiprocess.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import distributedfft_amd as dfft  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+from test_gpu_parity import NPDT, TOL_FWD, TOL_RT, rel, run_distributed, run_distributed_real  # noqa: E402
+
+CASES = [((128, 64, 32), 2, 4), ((66, 50, 38), 2, 4), ((64, 64, 64), 3, 2), ((48, 40, 56), 4, 2), ((40, 36, 30), 2, 3)]
+
+
+@pytest.mark.parametrize("relay", [1, 2, 3])
+@pytest.mark.parametrize("chunks", [1, 2, 3, 4])
+@pytest.mark.parametrize("shape,P1,P2", CASES)
+def test_relayed_exchange_is_bit_identical_to_the_direct_one(shape, P1, P2, chunks, relay):
+    prec = "double"
+    plans, ins, spec_d, backs_d = run_distributed(shape, P1, P2, prec, chunks=chunks)
+    _, _, spec_r, backs_r = run_distributed(shape, P1, P2, prec, chunks=chunks, comm_options={"relay": relay})
+    g = orc.fill_block(shape, (0, 0, 0), shape, 2, seed=7).astype(NPDT[prec]).astype(np.complex128)
+    want = orc.fft3d_c2c(g, -1)
+    scale = np.max(np.abs(want))
+    for r, pl in enumerate(plans):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        assert np.array_equal(spec_d[r], spec_r[r]), (r, "spectrum differs from the direct exchange")
+        assert np.array_equal(backs_d[r], backs_r[r]), (r, "round trip differs from the direct exchange")
+        assert np.max(np.abs(spec_r[r] - want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]])) / scale < TOL_FWD[prec]
+        assert rel(backs_r[r] / float(np.prod(shape)), ins[r]) < TOL_RT[prec]
+
+
+@pytest.mark.parametrize("prec", ["double", "float"])
+@pytest.mark.parametrize("shape,P1,P2", [((32, 32, 64), 2, 4), ((24, 40, 50), 2, 2)])
+def test_relayed_r2c_c2r(shape, P1, P2, prec):
+    """the reference's own API (execR2C / execC2R) with the uneven Nz/2 + 1 split: 33 = 9 + 8 + 8 + 8"""
+    plans, ins, spec_d, backs_d = run_distributed_real(shape, P1, P2, prec)
+    _, _, spec_r, backs_r = run_distributed_real(shape, P1, P2, prec, comm_options={"relay": 3})
+    for r in range(len(plans)):
+        assert np.array_equal(spec_d[r], spec_r[r]) and np.array_equal(backs_d[r], backs_r[r])
+        assert rel(backs_r[r] / float(np.prod(shape)), ins[r]) < TOL_RT[prec]
+
+
+def test_relay_option_values():
+    world = dfft.Comm.local(4)
+    for v in (0, 1, 2, 3):
+        world.setOption("relay", v)
+    with pytest.raises(dfft.DfftError, match="relay"):
+        world.setOption("relay", 4)
+
+
+def test_relay_leaves_whole_world_groups_alone():
+    """a slab plan's single exchange spans the whole world: there is nobody to relay through, the direct path runs"""
+    shape = (64, 32, 16)
+    plans, ins, spec_d, backs_d = run_distributed(shape, 4, 1, "double")
+    _, _, spec_r, backs_r = run_distributed(shape, 4, 1, "double", comm_options={"relay": 3})
+    for r in range(4):
+        assert np.array_equal(spec_d[r], spec_r[r]) and np.array_equal(backs_d[r], backs_r[r])

@@ -143,3 +143,31 @@ def test_c1_128_cube_round_trip():
     assert np.max(np.abs(X - want)) / np.max(np.abs(want)) < 1e-12
     back = orc.fft3d_c2c(X, +1) / float(n) ** 3
     assert np.max(np.abs(back - g)) / np.max(np.abs(g)) < 1e-12
+
+
+@pytest.mark.parametrize("shape,P1,P2", [((32, 32, 32), 2, 2), ((18, 20, 14), 3, 2), ((16, 24, 10), 1, 4), ((20, 12, 16), 4, 1)])
+def test_mpi_form_of_the_pencil_path_matches_the_oracle(shape, P1, P2):
+    """oracle/mpi_pencil.c (one MPI process per rank: MPI_Comm_split + MPI_Alltoallv, what bench.py's cpu_baseline leg times) against
+    the single transform of the same global array: an index-weighted checksum of every rank's spectrum block and the round trip.
+    Uneven splits (18 = 6+6+6 rows over 3, 20 = 10+10 columns, 14 z planes over 2 ...), slab shapes (P2 = 1, P1 = 1)."""
+    import json
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    launcher = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if not os.path.exists(launcher) or not os.path.exists("/opt/conda/lib/libmpi.so.12"):
+        pytest.skip("no MPICH in this image")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "liboracle.so", "mpi_pencil"])
+    out = subprocess.run([launcher, "-n", str(P1 * P2), os.path.join(root, "oracle", "mpi_pencil"), str(shape[0]), str(P1), str(P2), "1",
+                          str(shape[1]), str(shape[2])], capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert out.returncode == 0, out.stdout + out.stderr
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["ranks"] == P1 * P2 and r["round_trip_rel_linf"] < 1e-12
+    g = orc.fill_block(shape, (0, 0, 0), shape, 2, seed=20260921)
+    X = np.fft.fftn(g)
+    idx = np.arange(X.size, dtype=np.int64).reshape(shape)          # global linear index (x*Ny + y)*Nz + z
+    w = 1.0 + (idx % 1021) / 1021.0
+    want = [float(np.sum(w * X.real)), float(np.sum(w * X.imag)), float(np.sum(np.abs(X)))]
+    scale = want[2]
+    for got, ref in zip(r["checksum"], want):
+        assert abs(got - ref) / scale < 1e-12, (r["checksum"], want)

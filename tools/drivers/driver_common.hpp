@@ -27,6 +27,11 @@
 
 #define HIP_CALL(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("Error %d at %s:%d\n", (int)e_, __FILE__, __LINE__); MPI_Abort(MPI_COMM_WORLD, 1); } } while (0)
 
+// `out` (and the inverse's output) come from the library's allocator: same ownership as the reference's cudaMalloc'd buffers
+// (tests/src/pencil/random_dist_3D.cu:197-205: the caller allocates and frees), on the backing the scatter passes run ~7 %
+// faster on (include/dfft_c.h: dfft_malloc(DFFT_CHUNK_DEFAULT); DFFT_DEFAULT_CHUNK_MIB=0 makes it hipMalloc again)
+#define DFFT_CALL(x) do { int r_ = (x); if (r_ != 0) { printf("Error %d (%s) at %s:%d\n", r_, dfft_last_error(), __FILE__, __LINE__); MPI_Abort(MPI_COMM_WORLD, 1); } } while (0)
+
 namespace driver {
 
 inline std::string getValueOfParam(int argc, char *argv[], const std::string &longdesc, const std::string &shortdesc)
@@ -166,7 +171,7 @@ template <typename T> int runTimed(const PlanOps<T> &ops, const Common &c, int r
     T *in_d = nullptr;
     void *out_d = nullptr;
     HIP_CALL(hipMalloc(&in_d, ops.in_elems() * sizeof(T)));
-    HIP_CALL(hipMalloc(&out_d, ops.domain_bytes));
+    DFFT_CALL(dfft_malloc(ops.domain_bytes, DFFT_CHUNK_DEFAULT, &out_d));
     for (int i = 0; i < c.iterations; i++) {
         if (!inverse) {
             randomFill(in_d, ops.in_elems(), 1000003ull * (rank + 1) + i);
@@ -176,7 +181,7 @@ template <typename T> int runTimed(const PlanOps<T> &ops, const Common &c, int r
         MPI_Barrier(MPI_COMM_WORLD);
         if (!inverse) ops.forward(out_d, in_d); else ops.inverse(in_d, out_d);
     }
-    HIP_CALL(hipFree(in_d)); HIP_CALL(hipFree(out_d));
+    HIP_CALL(hipFree(in_d)); DFFT_CALL(dfft_free(out_d));
     return 0;
 }
 
@@ -188,8 +193,8 @@ template <typename T> int runRoundTrip(const PlanOps<T> &ops, const Common &c, i
     T *in_d = nullptr, *inv_d = nullptr;
     void *out_d = nullptr;
     HIP_CALL(hipMalloc(&in_d, n * sizeof(T)));
-    HIP_CALL(hipMalloc(&inv_d, n * sizeof(T)));
-    HIP_CALL(hipMalloc(&out_d, ops.domain_bytes));
+    DFFT_CALL(dfft_malloc(n * sizeof(T), DFFT_CHUNK_DEFAULT, (void **)&inv_d));
+    DFFT_CALL(dfft_malloc(ops.domain_bytes, DFFT_CHUNK_DEFAULT, &out_d));
     // an unnormalised forward + inverse pair multiplies by the transformed extents: Nz, Ny*Nz or Nx*Ny*Nz (--fft-dim 1, 2, 3)
     const double N3 = c.fft_dim == 1 ? (double)c.Nz : c.fft_dim == 2 ? (double)c.Ny * c.Nz : (double)c.Nx * c.Ny * c.Nz;
     std::vector<T> h(n);
@@ -206,7 +211,7 @@ template <typename T> int runRoundTrip(const PlanOps<T> &ops, const Common &c, i
         printResult(rank, sum * N3, mx * N3, (double)c.Nx * c.Ny * c.Nz);
         MPI_Barrier(MPI_COMM_WORLD);
     }
-    HIP_CALL(hipFree(in_d)); HIP_CALL(hipFree(inv_d)); HIP_CALL(hipFree(out_d));
+    HIP_CALL(hipFree(in_d)); DFFT_CALL(dfft_free(inv_d)); DFFT_CALL(dfft_free(out_d));
     return 0;
 }
 
@@ -220,8 +225,8 @@ template <typename T> int runLaplacian(const PlanOps<T> &ops, const Common &c, i
     T *in_d = nullptr, *inv_d = nullptr;
     void *out_d = nullptr;
     HIP_CALL(hipMalloc(&in_d, n * sizeof(T)));
-    HIP_CALL(hipMalloc(&inv_d, n * sizeof(T)));
-    HIP_CALL(hipMalloc(&out_d, ops.domain_bytes));
+    DFFT_CALL(dfft_malloc(n * sizeof(T), DFFT_CHUNK_DEFAULT, (void **)&inv_d));
+    DFFT_CALL(dfft_malloc(ops.domain_bytes, DFFT_CHUNK_DEFAULT, &out_d));
     const double Nx = (double)c.Nx, Ny = (double)c.Ny, Nz = (double)c.Nz, root = std::sqrt(Nx * Ny * Nz);
     std::vector<T> in_h(n), der_h(n);
     for (size_t x = 0; x < ops.isz[0]; x++)
@@ -256,7 +261,7 @@ template <typename T> int runLaplacian(const PlanOps<T> &ops, const Common &c, i
         printResult(rank, sum, mx, Nx * Ny * Nz);
         MPI_Barrier(MPI_COMM_WORLD);
     }
-    HIP_CALL(hipFree(in_d)); HIP_CALL(hipFree(inv_d)); HIP_CALL(hipFree(out_d));
+    HIP_CALL(hipFree(in_d)); DFFT_CALL(dfft_free(inv_d)); DFFT_CALL(dfft_free(out_d));
     return 0;
 }
 
@@ -279,7 +284,7 @@ int runCoordinated(const std::function<PlanOps<T>(MPI_Comm, int)> &make, const C
         T *in_d = nullptr;
         void *out_d = nullptr;
         HIP_CALL(hipMalloc(&in_d, n * sizeof(T)));
-        HIP_CALL(hipMalloc(&out_d, full.domain_bytes));
+        DFFT_CALL(dfft_malloc(full.domain_bytes, DFFT_CHUNK_DEFAULT, &out_d));
         std::vector<T> in_h(n), blk;
         std::vector<Cx> want(no), got;
         for (int i = 0; i < c.iterations; i++) {
@@ -312,7 +317,7 @@ int runCoordinated(const std::function<PlanOps<T>(MPI_Comm, int)> &make, const C
             printf("\nResults: %f\n", sum);
             MPI_Barrier(MPI_COMM_WORLD);
         }
-        HIP_CALL(hipFree(in_d)); HIP_CALL(hipFree(out_d));
+        HIP_CALL(hipFree(in_d)); DFFT_CALL(dfft_free(out_d));
         return 0;
     }
     PlanOps<T> ops = make(MPI_COMM_WORLD, workers);
@@ -322,7 +327,7 @@ int runCoordinated(const std::function<PlanOps<T>(MPI_Comm, int)> &make, const C
     T *in_d = nullptr;
     void *out_d = nullptr;
     HIP_CALL(hipMalloc(&in_d, ops.in_elems() * sizeof(T)));
-    HIP_CALL(hipMalloc(&out_d, ops.domain_bytes));
+    DFFT_CALL(dfft_malloc(ops.domain_bytes, DFFT_CHUNK_DEFAULT, &out_d));
     std::vector<T> in_h(ops.in_elems());
     std::vector<Cx> out_h(ops.out_elems());
     for (int i = 0; i < c.iterations; i++) {
@@ -334,7 +339,7 @@ int runCoordinated(const std::function<PlanOps<T>(MPI_Comm, int)> &make, const C
         MPI_Send(out_h.data(), (int)(out_h.size() * sizeof(Cx)), MPI_BYTE, workers, 2, MPI_COMM_WORLD);
         MPI_Barrier(MPI_COMM_WORLD);
     }
-    HIP_CALL(hipFree(in_d)); HIP_CALL(hipFree(out_d));
+    HIP_CALL(hipFree(in_d)); DFFT_CALL(dfft_free(out_d));
     return 0;
 }
 
