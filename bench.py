@@ -184,7 +184,7 @@ def cpu_baseline(n_req):
                 "numpy_check": {"grid": f"{m}^3", "numpy_fftn_ms": round(t_np * 1e3, 1), "oracle_ms": round(t_or * 1e3, 1), "max_rel_dev": dev},
                 "sample": f"{n}^3 fp64 complex, pencil {mpi['P1']}x{mpi['P2']} over {mpi['cores']} MPI ranks (mpiexec -n {mpi['cores']} oracle/mpi_pencil: "
                           f"z-FFT, MPI_Alltoallv in the row communicator, y-FFT, MPI_Alltoallv in the column communicator, x-FFT and the mirror), "
-                          f"1 warm-up + {mpi['iters']} timed forward and inverse transforms; host has {os.cpu_count()} cores; next to it the "
+                          f"1 warm-up + {mpi['iters']} timed forward and inverse transforms; host has {os.cpu_count()} cores, {mpi['usable_cores']} usable by this job; next to it the "
                           f"single-process OpenMP oracle on {orc.num_threads()} threads ({omp['forward_ms']} / {omp['inverse_ms']} ms)"}
     return {"value": round(2 * fl * iters / (tf + tb) / 1e9, 3), "unit": "GFLOP/s", "cores": orc.num_threads(),
             "kind": "port", "mpi": mpi,
@@ -206,7 +206,12 @@ def cpu_baseline_mpi(n):
     launcher = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
     if not os.path.exists(exe) or not os.path.exists(launcher):
         return {"error": "oracle/mpi_pencil or mpiexec not available (make -C oracle mpi_pencil)"}
-    cores = os.cpu_count() or 1
+    # the cores this process may run on (the GPU boxes hand a 256-core host's job 128 of them: busy-polling MPI ranks beyond that
+    # oversubscribe the cores and never finish)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
     R = 1
     while R * 2 <= min(cores, 256):
         R *= 2
@@ -219,7 +224,7 @@ def cpu_baseline_mpi(n):
         env.pop(k, None)
     t0 = time.perf_counter()
     try:
-        out = subprocess.run([launcher, "-n", str(R), exe, str(n), str(P1), str(P2), "2"], capture_output=True, text=True, timeout=240, env=env)
+        out = subprocess.run([launcher, "-n", str(R), exe, str(n), str(P1), str(P2), "2"], capture_output=True, text=True, timeout=150, env=env)
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
         if out.returncode != 0 or not line:
             return {"error": (out.stderr or out.stdout)[-300:], "ranks": R}
@@ -229,7 +234,7 @@ def cpu_baseline_mpi(n):
     fl = flops_per_direction(n)
     return {"value": round(2 * fl / ((r["forward_ms"] + r["inverse_ms"]) * 1e-3) / 1e9, 3), "unit": "GFLOP/s", "cores": R, "P1": P1, "P2": P2,
             "forward_ms": round(r["forward_ms"], 1), "inverse_ms": round(r["inverse_ms"], 1), "iters": r["iters"],
-            "round_trip_rel_linf": r["round_trip_rel_linf"], "wall_s": round(time.perf_counter() - t0, 1)}
+            "round_trip_rel_linf": r["round_trip_rel_linf"], "wall_s": round(time.perf_counter() - t0, 1), "usable_cores": cores}
 
 
 def dry_run():

@@ -52,21 +52,29 @@ using F32_2048_v9 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3>;
 // inverse y pass (transposed-tile stores in whole lines instead of 32-byte pieces): 4.42 vs 4.30 ms at 1024 points, 10.55 vs 10.35 at 2048
 using F32_1024_v10 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 2>;
 using F32_2048_v10 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 2>;
-// Round 4, under test (A/B builds): getting the tiled 2048-point passes to TWO workgroups per CU.  16 lines x 2048 points are 256 KiB,
-// half of a CU's register file, so whole tiles mean one workgroup per CU and load -> compute -> store in sequence.
-//   12 / 13 = sub-tile workgroups of 8 lines (PassCfg::SUB = 2: 64-byte runs on the tiled sides, two workgroups per CU), line-fastest
-//             mapping, 64 points per thread, without / with nontemporal hints (variant 5 is the same with the point-fastest store
-//             mapping: the tuner already picks it for the inverse y pass of C5, 5.59 -> 4.77 ms)
-//   14 / 15 = sub-tile workgroups of 8 lines with 32 points per thread: 512 threads, <= 128 VGPRs, 66 KiB of LDS -> two workgroups =
-//             32 waves per CU, three radix passes
+// Round 4: the tiled 2048-point passes on TWO workgroups per CU.  16 lines x 2048 points are 256 KiB, half of a CU's register file, so
+// whole tiles mean one workgroup per CU and load -> compute -> store in sequence.  Measured on rank 0 of the 2 x 4 plan at 2048^3
+// (profiles/r4_f32_2048_tiled_candidates.txt), every configuration as a transform and as a copy with the same access pattern:
+//   14 / 15 = sub-tile workgroups of 8 lines (PassCfg::SUB = 2) with 32 points per thread: 512 threads, <= 128 VGPRs, 66 KiB of LDS ->
+//             two workgroups = 32 waves per CU, three radix passes, without / with nontemporal hints.  SHIPPED as tuner candidates
+//             (dfft_tune_variants): the inverse y pass 4.80 (variant 5) -> 4.49 ms with 15, 3 % above its own copy (4.37)
+//   12 / 13 = the same sub-tiles with 64 points per thread (two waves per SIMD): 4.84-5.08 ms there, no better than 5; A/B builds only
+// What the copies say: the floor of these passes is their access pattern, not the phases of a tile -- y 3.43 ms, x 3.27, x^-1 4.25,
+// y^-1 4.16 as pure copies (4.0-5.2 TB/s) against 3.87 / 3.61 / 4.59 / 4.49 as transforms.
 using F32_2048_v12 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 0, 2>;
 using F32_2048_v13 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3, 0, 2>;
 using F32_2048_v14 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 0, 2>;
 using F32_2048_v15 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3, 0, 2>;
+//   1 / 3 = natural-line LOAD (the role of 4) with 32 points per thread on sub-tile workgroups: point-fastest mapping, with / without hints
+//   2 / 7 = natural-line STORE (the role of 5) likewise: line-fastest first pass, point-fastest afterwards, without / with hints
+using F32_2048_v1 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3, 1, 2>;
+using F32_2048_v3 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 1, 2>;
+using F32_2048_v2 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 2, 2>;
+using F32_2048_v7 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3, 2, 2>;
 #ifdef DFFT_EXPERIMENTS
 #define DFFT_F32_EXP_SMALL(X)
 #define DFFT_F32_EXP_1024(X) X(1024, 10, F32_1024_v10)
-#define DFFT_F32_EXP_2048(X) X(2048, 10, F32_2048_v10) X(2048, 12, F32_2048_v12) X(2048, 13, F32_2048_v13) X(2048, 14, F32_2048_v14) X(2048, 15, F32_2048_v15)
+#define DFFT_F32_EXP_2048(X) X(2048, 10, F32_2048_v10) X(2048, 12, F32_2048_v12) X(2048, 13, F32_2048_v13) X(2048, 1, F32_2048_v1) X(2048, 3, F32_2048_v3) X(2048, 2, F32_2048_v2) X(2048, 7, F32_2048_v7)
 #else
 #define DFFT_F32_EXP_SMALL(X)
 #define DFFT_F32_EXP_1024(X)
@@ -74,7 +82,7 @@ using F32_2048_v15 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3, 0, 2>
 #endif
 #define DFFT_F32_LIST_SMALL(X) X(512, 6, F32_512_v6) X(512, 9, F32_512_v9) X(512, 4, F32_512_v4) X(512, 5, F32_512_v5) X(2, 0, F32_2) X(4, 0, F32_4) X(8, 0, F32_8) X(16, 0, F32_16) X(32, 0, F32_32) X(64, 0, F32_64) X(128, 0, F32_128) X(256, 0, F32_256) X(512, 0, F32_512) DFFT_F32_EXP_SMALL(X)
 #define DFFT_F32_LIST_1024(X) X(1024, 4, F32_1024_v4) X(1024, 5, F32_1024_v5) X(1024, 6, F32_1024_v6) X(1024, 9, F32_1024_v9) X(1024, 0, F32_1024) DFFT_F32_EXP_1024(X)
-#define DFFT_F32_LIST_2048(X) X(2048, 4, F32_2048_v4) X(2048, 5, F32_2048_v5) X(2048, 6, F32_2048_v6) X(2048, 9, F32_2048_v9) X(2048, 0, F32_2048) X(4096, 0, F32_4096) X(8192, 0, F32_8192) DFFT_F32_EXP_2048(X)
+#define DFFT_F32_LIST_2048(X) X(2048, 4, F32_2048_v4) X(2048, 5, F32_2048_v5) X(2048, 6, F32_2048_v6) X(2048, 9, F32_2048_v9) X(2048, 14, F32_2048_v14) X(2048, 15, F32_2048_v15) X(2048, 0, F32_2048) X(4096, 0, F32_4096) X(8192, 0, F32_8192) DFFT_F32_EXP_2048(X)
 
 // lengths with a packed real z pass / a Bluestein inner transform of their own configuration
 // real-transform z passes (variant 0 configurations only); M = Nz/2

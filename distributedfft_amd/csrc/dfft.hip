@@ -2429,7 +2429,7 @@ static int tune_variants(dfft_plan *p, const void *in, void *o, void *b, float &
     // (-DDFFT_EXPERIMENTS) carries further configuration numbers that are measured by hand, never picked here
     auto validated = [&](int v) {
         if (p->prec == DFFT_F64) return (v >= 0 && v <= 3) || v == 7 || v == 8;
-        return v == 0 || (v >= 4 && v <= 6) || v == 9;
+        return v == 0 || (v >= 4 && v <= 6) || v == 9 || v == 14 || v == 15;
     };
     for (int v = 0; v < 16; v++) {
         if (!validated(v)) continue;
@@ -2539,8 +2539,8 @@ int dfft_tune_placement(dfft_plan *p, const void *in, int tries, void **out, voi
         std::vector<void *> cands;
         for (int t = 1; t < tries; t++) {
             void *cand = nullptr;
-            const size_t rec_chunk = kPlacementRecipes[(size_t)t % nrec] << 20;
-            if (rec_chunk > bytes) continue;      // a chunk larger than the buffer: dev_alloc would clamp it to one chunk, which the smaller recipes already cover
+            // (dev_alloc clamps a chunk larger than the buffer to the buffer's own size: still another physical allocation to try)
+            const size_t rec_chunk = std::min(kPlacementRecipes[(size_t)t % nrec] << 20, (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1));
             const size_t rounded = rec_chunk ? (bytes + rec_chunk - 1) / rec_chunk * rec_chunk : bytes;
             if (!room_for(rounded) || dev_alloc(bytes, kPlacementRecipes[(size_t)t % nrec], &cand) != 0) break;      // out of memory: fewer candidates
             cands.push_back(cand);
