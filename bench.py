@@ -134,6 +134,9 @@ def cpu_baseline(n_req):
 
     from oracle import oracle as orc
     L = orc.lib()
+    usable = orc.usable_cores()
+    if usable < orc.num_threads():
+        orc.set_num_threads(usable)      # one thread per CPU the cgroup grants, not per core of the host
     try:
         import psutil
         avail = psutil.virtual_memory().available
@@ -193,25 +196,24 @@ def cpu_baseline(n_req):
             "numpy_check": {"grid": f"{m}^3", "numpy_fftn_ms": round(t_np * 1e3, 1), "oracle_ms": round(t_or * 1e3, 1),
                             "max_rel_dev": dev},
             "sample": f"{n}^3 fp64 complex, 1 warm-up + {iters} timed forward and inverse transforms ({tf + tb:.1f} s), "
-                      f"oracle/dfft_oracle.c with {orc.num_threads()} OpenMP threads, host has {os.cpu_count()} cores"}
+                      f"oracle/dfft_oracle.c with {orc.num_threads()} OpenMP threads, host has {os.cpu_count()} cores of which the job's cgroup grants {usable}"}
 
 
 def cpu_baseline_mpi(n):
     """The restated reference path as ONE MPI PROCESS PER RANK on this host's cores (oracle/mpi_pencil.c: the opt1 pencil chain with
     MPI_Comm_split + MPI_Alltoallv, src/pencil/mpicufft_pencil_opt1.cpp:103-104, 1422-1600): R = the largest power of two <= cores
-    (at most 256), P1 x P2 as square as possible, 1 warm-up + 2 timed forward and inverse transforms of the n^3 fp64 complex grid."""
+    (at most 256; "cores" = what the cgroup grants), P1 x P2 as square as possible, 1 warm-up + 1 timed forward and inverse transform of
+    the n^3 fp64 complex grid."""
     import shutil
     import subprocess
     exe = os.path.join(ROOT, "oracle", "mpi_pencil")
     launcher = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
     if not os.path.exists(exe) or not os.path.exists(launcher):
         return {"error": "oracle/mpi_pencil or mpiexec not available (make -C oracle mpi_pencil)"}
-    # the cores this process may run on (the GPU boxes hand a 256-core host's job 128 of them: busy-polling MPI ranks beyond that
-    # oversubscribe the cores and never finish)
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    # the CPUs this job may use: affinity capped by the cgroup quota (the GPU boxes: 256 cores, cpu.max = 16 CPUs; busy-polling MPI
+    # ranks beyond the quota only slow each other down -- 1024^3 forward: 11.1 s on 64 ranks, 16.0 s on 128, profiles/r4_mpi_probe.txt)
+    from oracle import oracle as orc
+    cores = orc.usable_cores()
     R = 1
     while R * 2 <= min(cores, 256):
         R *= 2
@@ -224,7 +226,7 @@ def cpu_baseline_mpi(n):
         env.pop(k, None)
     t0 = time.perf_counter()
     try:
-        out = subprocess.run([launcher, "-n", str(R), exe, str(n), str(P1), str(P2), "2"], capture_output=True, text=True, timeout=150, env=env)
+        out = subprocess.run([launcher, "-n", str(R), exe, str(n), str(P1), str(P2), "1"], capture_output=True, text=True, timeout=200, env=env)
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
         if out.returncode != 0 or not line:
             return {"error": (out.stderr or out.stdout)[-300:], "ranks": R}

@@ -199,6 +199,13 @@ class Comm:
         """transport knobs (include/dfft_c.h: dfft_comm_set_option); 'dup_channel' = 1 is collective over all ranks"""
         check(lib().dfft_comm_set_option(self._h, key.encode(), int(value)))
 
+    def alltoallv(self, myrank, send, scounts, sdispls, recv, rcounts, rdispls, group, me, stream=None):
+        """the transport's all-to-all-v by itself (dfft_comm_alltoallv): byte counts / displacements, stream-ordered"""
+        n = len(group)
+        arr = lambda v: (C.c_size_t * n)(*[int(x) for x in v])      # noqa: E731
+        check(lib().dfft_comm_alltoallv(self._h, int(myrank), _ptr(send), arr(scounts), arr(sdispls), _ptr(recv), arr(rcounts), arr(rdispls),
+                                        (C.c_int * n)(*[int(g) for g in group]), n, int(me), C.c_void_p(stream or 0)))
+
     def destroy(self):
         if self._h:
             lib().dfft_comm_destroy(self._h)

@@ -30,7 +30,10 @@ using F32_512_v5 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1, 0, 2>;
 // per thread (radix 64.32, a single LDS exchange) on sub-tile workgroups of 8 lines (PassCfg::SUB = 2: 256 threads,
 // 66 KiB LDS, two per CU): 36.2 -> 30.4 ms per pass at 2048^3.  The tiled passes (6) keep whole tiles (a sub-tile's
 // 64-byte runs cost more than its occupancy gives) with the same two-pass chain on 512 threads.
-using F32_2048_v4 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3, 1, 2>;
+// (round 4: the natural-line LOAD runs 32 points per thread -- 512 threads, <= 128 VGPRs, two workgroups = 32 waves per CU, three radix
+// passes -- instead of 64: rank 0 of 2 x 4 at 2048^3 3.61 -> 3.09 ms, its copy 3.00; 2048^3 on one GPU 31.7 -> 27.9 ms per z pass;
+// the natural-line STORE keeps 64 points: 3.11 vs 3.15 ms; profiles/r4_f32_2048_natural_candidates.txt, r4_f32_2048_single_gpu_candidates.txt)
+using F32_2048_v4 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3, 1, 2>;
 using F32_2048_v5 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 2, 2>;
 using F32_2048_v6 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1>;
 // 4096 and 8192 points: sub-tile workgroups of 4 / 2 lines (see kernels_f64.hip), 512 threads, 64 KiB of LDS
@@ -65,16 +68,10 @@ using F32_2048_v12 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 0, 2
 using F32_2048_v13 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3, 0, 2>;
 using F32_2048_v14 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 0, 2>;
 using F32_2048_v15 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3, 0, 2>;
-//   1 / 3 = natural-line LOAD (the role of 4) with 32 points per thread on sub-tile workgroups: point-fastest mapping, with / without hints
-//   2 / 7 = natural-line STORE (the role of 5) likewise: line-fastest first pass, point-fastest afterwards, without / with hints
-using F32_2048_v1 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3, 1, 2>;
-using F32_2048_v3 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 1, 2>;
-using F32_2048_v2 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 2, 2>;
-using F32_2048_v7 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3, 2, 2>;
 #ifdef DFFT_EXPERIMENTS
 #define DFFT_F32_EXP_SMALL(X)
 #define DFFT_F32_EXP_1024(X) X(1024, 10, F32_1024_v10)
-#define DFFT_F32_EXP_2048(X) X(2048, 10, F32_2048_v10) X(2048, 12, F32_2048_v12) X(2048, 13, F32_2048_v13) X(2048, 1, F32_2048_v1) X(2048, 3, F32_2048_v3) X(2048, 2, F32_2048_v2) X(2048, 7, F32_2048_v7)
+#define DFFT_F32_EXP_2048(X) X(2048, 10, F32_2048_v10) X(2048, 12, F32_2048_v12) X(2048, 13, F32_2048_v13)
 #else
 #define DFFT_F32_EXP_SMALL(X)
 #define DFFT_F32_EXP_1024(X)

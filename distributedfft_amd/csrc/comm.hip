@@ -164,6 +164,8 @@ struct RcclComm : dfft_comm {
     void *comm = nullptr;
     void *comm2 = nullptr;     // duplicate communicator (ncclCommSplit, colour 0) for channel 1
     int rank = 0;
+    bool self_send = false;    // testing: the self block goes through ncclSend / ncclRecv to the own rank instead of a device copy
+                               // (lets a 1-GPU box hand caller buffers -- virtual-memory ranges included -- to RCCL)
     int fixed_rank() const override { return rank; }
     // one ncclComm serialises its operations: only a duplicated communicator allows overlap
     bool concurrent_channels() const override { return comm2 != nullptr; }
@@ -185,6 +187,7 @@ struct RcclComm : dfft_comm {
     // serialises them.
     int set_option(const char *key, long value) override
     {
+        if (std::string(key ? key : "") == "self_send") { self_send = value != 0; return 0; }
         if (std::string(key ? key : "") != "dup_channel") return 1;
         RcclApi *R = rccl();
         if (!R || !comm) { set_error("librccl not available"); return 1; }
@@ -209,9 +212,14 @@ struct RcclComm : dfft_comm {
         void *use = (channel == 1 && comm2) ? comm2 : comm;
         // self block: plain device copy, never goes through RCCL
         // (the reference skips self in its send tables, src/pencil/mpicufft_pencil.cpp:282-289)
-        if (rcount[me])
+        if (rcount[me] && !self_send)
             HIP_TRY(hipMemcpyAsync(r + rdispl[me], s + sdispl[me], rcount[me], hipMemcpyDeviceToDevice, stream));
         NCCL_TRY(R->GroupStart());
+        if (rcount[me] && self_send) {
+            int e1 = R->Send(s + sdispl[me], scount[me], 0, group[me], use, stream);
+            int e2 = e1 ? 0 : R->Recv(r + rdispl[me], rcount[me], 0, group[me], use, stream);
+            if (e1 || e2) { (void)R->GroupEnd(); set_error("ncclSend/ncclRecv to self failed"); return 1000 + (e1 ? e1 : e2); }
+        }
         // a failing call inside the group must not leave the group open: remember the first error, stop
         // queueing, always close the group
         int err = 0;

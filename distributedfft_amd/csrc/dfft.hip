@@ -1478,10 +1478,12 @@ static int dev_alloc(size_t bytes, size_t chunk_mib, void **out)
 }
 
 // The default backing of library-owned device memory (work areas, dfft_malloc(DFFT_CHUNK_DEFAULT)): the virtual-memory API with
-// 1 GiB physical chunks.  Buffers backed this way are systematically better targets for the passes that scatter 128-byte runs
-// than hipMalloc buffers (1024^3 fp64 C2C on one GPU, fresh processes: hipMalloc 37.3-37.5 ms per forward + inverse, 1 GiB chunks
-// 34.9 / 35.3, 2 MiB 35.0 / 35.4, 256 MiB 34.7 / 36.8, 64 MiB 36.7 / 35.0; the 10-second search of dfft_tune_placement 34.1;
-// profiles/r4_fixed_recipes.txt).  The chunk size matters little; 1 GiB means the fewest mappings.  Falls back to smaller chunks
+// 1 GiB physical chunks.  Buffers backed this way are on average better targets for the passes that scatter 128-byte runs than
+// hipMalloc buffers (1024^3 fp64 C2C on one GPU, fresh processes: hipMalloc 36.9-37.5 ms per forward + inverse in every one;
+// 1 GiB chunks 34.9 / 35.3 / 35.0 / 35.6 but 37.2 right after 64 GiB buffers were freed; 2 MiB 35.0-36.0; 16, 64, 256 MiB and
+// shuffled mapping orders the same 34.2-36.8 scatter; the search of dfft_tune_placement 33.6-34.4; profiles/r4_fixed_recipes.txt,
+// r4_placement_shuffle.txt).  Neither the chunk size nor the order the chunks are mapped in controls which case one gets -- it is
+// the physical pages -- so the recipe is the one with the fewest mappings, and the search stays the way to a guaranteed result.  Falls back to smaller chunks
 // (fragmented memory) and finally to hipMalloc, so it never fails where hipMalloc would succeed.  DFFT_DEFAULT_CHUNK_MIB overrides
 // (0 = plain hipMalloc, what rounds 1-3 used for work areas).
 static size_t default_chunk_mib()
@@ -1565,6 +1567,14 @@ int dfft_comm_set_option(dfft_comm *comm, const char *key, long value)
     const int r = comm->set_option(key, value);
     if (r == 1 && g_error.empty()) set_error(std::string("this transport has no option ") + key);
     return r;
+}
+int dfft_comm_alltoallv(dfft_comm *comm, int myrank, const void *send, const size_t *scounts, const size_t *sdispls, void *recv,
+                        const size_t *rcounts, const size_t *rdispls, const int *group, int ngroup, int me, void *hip_stream)
+{
+    if (!comm || !send || !recv || !scounts || !sdispls || !rcounts || !rdispls || !group) return fail(ERR_ARG, "null argument");
+    if (ngroup < 1 || me < 0 || me >= ngroup) return fail(ERR_ARG, "bad group");
+    const int r = comm->alltoallv(myrank, send, scounts, sdispls, recv, rcounts, rdispls, group, ngroup, me, (hipStream_t)hip_stream, 0);
+    return r ? fail(r, "all-to-all failed: " + g_error) : 0;
 }
 int dfft_comm_destroy(dfft_comm *comm)
 {

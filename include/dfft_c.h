@@ -97,6 +97,8 @@ int dfft_comm_info(const dfft_comm *comm, int *nranks, int *transport_nranks);
  * and the column-group exchange -- which use disjoint xGMI links -- may be on the wire at the same time; without it one
  * ncclComm serialises them.  Replaces nothing in the reference (its two MPI sub-communicators are independent by
  * construction, src/pencil/mpicufft_pencil_opt1.cpp:103-104).
+ * "self_send" = 1 (RCCL transport, testing): a rank's own block goes through ncclSend / ncclRecv to itself instead of a device
+ * copy, so that a single-GPU box can hand caller buffers (virtual-memory ranges from dfft_malloc included) to RCCL.
  * "relay" = 0..3 (every transport; a flag, not collective by itself, but every rank must set the same value before the next
  * exec): two-hop relay of the group exchanges.  bit 0 = exchange 2 (column groups), bit 1 = exchange 1 (row groups).  xGMI is
  * point to point, so the column groups of a 2 x 4 pencil grid move half of the volume over ONE of a GPU's seven links; with the
@@ -106,6 +108,12 @@ int dfft_comm_info(const dfft_comm *comm, int *nranks, int *transport_nranks);
  * (src/pencil/mpicufft_pencil_opt1.cpp:1116-1275); this is the xGMI analogue.  Default off.
  * Returns 0, or nonzero for an unknown key / a failure. */
 int dfft_comm_set_option(dfft_comm *comm, const char *key, long value);
+/* The transport's all-to-all-v on its own -- what a plan calls for its exchanges (counts / displacements in bytes, `group` =
+ * ranks of the communicator taking part, `me` = the caller's index in it; hip_stream may be NULL).  Stream-ordered: returns
+ * when the exchange is enqueued.  For callers that move their own blocks with the library's transports, and for tests of a
+ * transport by itself (the reference's counterpart is a bare MPI_Alltoallv, src/pencil/mpicufft_pencil_opt1.cpp:784-785). */
+int dfft_comm_alltoallv(dfft_comm *comm, int myrank, const void *send, const size_t *scounts, const size_t *sdispls, void *recv,
+                        const size_t *rcounts, const size_t *rdispls, const int *group, int ngroup, int me, void *hip_stream);
 /* destroy the plans that use a communicator before the communicator itself */
 int dfft_comm_destroy(dfft_comm *comm);
 
@@ -290,9 +298,12 @@ int dfft_axis_plan_info(int precision, size_t N, int two_level, size_t info[8]);
  * dfft_malloc: chunk_mib = 0 is hipMalloc; otherwise one virtual range backed by physical allocations of chunk_mib MiB
  * each (HIP virtual-memory API).  chunk_mib = DFFT_CHUNK_DEFAULT: the library's default backing -- 1 GiB chunks, smaller
  * ones and finally hipMalloc if that fails -- which is also what the library uses for a work area it owns
- * (dfft_init(allocate = 1), dfft_set_work_area(plan, NULL, NULL)).  A caller that allocates `out` (and the inverse's output)
- * this way gets, without any search, within 1-4 % of what dfft_tune_placement finds in ten seconds; plain hipMalloc buffers
- * are ~10 % slower on the scatter passes (profiles/r4_fixed_recipes.txt).  Environment DFFT_DEFAULT_CHUNK_MIB overrides the
+ * (dfft_init(allocate = 1), dfft_set_work_area(plan, NULL, NULL)).  What a caller gets by allocating `out` (and the inverse's
+ * output) this way, measured over 30 fresh processes at 1024^3 fp64 (profiles/r4_fixed_recipes.txt, r4_placement_shuffle.txt):
+ * 34.2 - 36.0 ms per forward + inverse in most of them, 37 ms -- as slow as hipMalloc buffers, which are 36.9 - 37.5 always --
+ * in some (right after very large buffers were freed); dfft_tune_placement's search finds 33.6 - 34.4 reliably.  The backing
+ * improves the average, only the search guarantees the result: which physical pages a buffer gets is what matters, and no
+ * recipe (chunk size, shuffled mapping order) was found that controls it.  Environment DFFT_DEFAULT_CHUNK_MIB overrides the
  * default (0 = hipMalloc).  Free with dfft_free (which also takes pointers it did not allocate: hipFree; it synchronises the
  * device first, like hipFree). */
 #define DFFT_CHUNK_DEFAULT ((size_t)-1)

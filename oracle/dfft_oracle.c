@@ -578,6 +578,16 @@ void orc_derivative_coefficients(cplx *out, size_t Nx, size_t Ny, size_t Nz, siz
     }
 }
 
+/* (bench.py's cpu_baseline leg: a job whose cgroup grants fewer CPUs than the host has cores should not run 128 threads on 16) */
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -51,8 +51,35 @@ def lib():
         L.orc_fill_block.argtypes = [vp, sz, sz, sz, sz, sz, sz, sz, sz, i32, u64]
         L.orc_derivative_coefficients.argtypes = [vp, sz, sz, sz, sz, sz, sz, sz, i32]
         L.orc_num_threads.restype = i32
+        L.orc_set_num_threads.argtypes = [i32]
         _lib = L
     return _lib
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
+
+
+def usable_cores():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup's CPU quota (the GPU boxes show 256 cores and an
+    affinity of 256, but cpu.max grants 16: 128 OpenMP threads or MPI ranks then share 16 cores' worth of time)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def _p(a):

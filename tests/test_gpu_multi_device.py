@@ -72,3 +72,28 @@ def test_worker_runs_with_one_rank(kind, transport):
     assert "MULTI_DEVICE_OK" in out.stdout
     if transport == "rccl":
         assert "rccl_nranks=1" in out.stdout
+
+
+def test_rccl_takes_virtual_memory_ranges_world_size_one():
+    """buffers from the library's default backing (dfft_malloc(DFFT_CHUNK_DEFAULT): HIP virtual-memory ranges of several physical
+    chunks) handed to RCCL itself: a communicator of one rank whose own block travels through ncclSend / ncclRecv to itself
+    (transport option self_send) instead of a device copy.  This is what the exchange buffers of an N > 1 run are once the default
+    backing is on everywhere; the real thing needs two GPUs (the needs_two cases above)."""
+    import distributedfft_amd as dfft
+    comm = dfft.Comm.rccl(dfft.Comm.rccl_unique_id(), 1, 0)
+    assert comm.info() == (1, 1)
+    comm.setOption("self_send", 1)
+    n = 192 << 20                                   # 192 MiB: above the 32 MiB threshold of the default backing, three 64 MiB pieces
+    a = dfft.DeviceBuffer.alloc(n, chunk_mib=64)
+    b = dfft.DeviceBuffer.alloc(n)
+    ta, tb = a.tensor(torch.int64), b.tensor(torch.int64)
+    ta.copy_(torch.arange(n // 8, device="cuda", dtype=torch.int64))
+    tb.zero_()
+    torch.cuda.synchronize()
+    # two pieces with a gap, as an exchange of a segmented buffer has them
+    comm.alltoallv(0, a, [n // 2], [n // 4], b, [n // 2], [n // 8], [0], 0)
+    torch.cuda.synchronize()
+    lo, cnt = n // 8 // 8, n // 2 // 8
+    assert torch.equal(tb[lo:lo + cnt], ta[n // 4 // 8:n // 4 // 8 + cnt])
+    assert int(tb[:lo].abs().sum()) == 0 and int(tb[lo + cnt:].abs().sum()) == 0
+    comm.destroy()
