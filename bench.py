@@ -717,9 +717,11 @@ def main():
         sha = hashlib.sha256(open(so, "rb").read()).hexdigest()
         roofline["library_sha256"] = sha
         # newest committed PMC run of the headline kernel (tools/pmc_traffic.sh + tools/pmc_traffic.py)
-        pmc = [f for f in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")
-               if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
-        pm = json.load(open(os.path.join(ROOT, "profiles", pmc)))
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True)
+        loaded = [(os.path.basename(f), json.load(open(f))) for f in cands]
+        match = [x for x in loaded if x[1].get("library_sha256") == sha]
+        pmc, pm = (match or loaded)[0]      # the profile of THIS library if there is one, else the newest (reported as stale)
         if ngpus == 1 and N == 1024 and prec == "double" and pm.get("hbm_bytes_per_launch"):
             roofline["traffic_source"] = f"profiles/{pmc} (a committed rocprofv3 PMC run, not this run)"
             if pm.get("library_sha256") == sha:

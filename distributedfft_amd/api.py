@@ -456,14 +456,15 @@ def fft1d_batched(out, in_, N, batch, direction=FORWARD, precision="double", str
 
 
 def axis_plan_info(N, precision="double", two_level=0):
-    """how an axis of N points is transformed: {"kind": "native" | "bluestein" | "two_level", "M": inner length,
+    """how an axis of N points is transformed: {"kind": "native" | "bluestein" | "two_level" | "long_bluestein", "M": inner length,
     "levels": [(N1, M1, bluestein1), (N2, M2, bluestein2)]}; None if the length has no plan"""
     prec = {"double": 1, "float": 0}[precision]
     info = (C.c_size_t * 8)()
     if lib().dfft_axis_plan_info(prec, N, int(two_level), info) != 0:
         return None
-    kind = ("native", "bluestein", "two_level")[info[0]]
-    levels = [(info[2], info[3], bool(info[4])), (info[5], info[6], bool(info[7]))] if info[0] == 2 else []
+    kind = ("native", "bluestein", "two_level", "long_bluestein")[info[0]]
+    # long_bluestein: Bluestein's algorithm on M padded points, whose M-point transforms run in the two levels listed
+    levels = [(info[2], info[3], bool(info[4])), (info[5], info[6], bool(info[7]))] if info[0] >= 2 else []
     return {"kind": kind, "M": info[1], "levels": levels}
 
 

@@ -111,6 +111,10 @@ struct Axis {
     // two-level line (fft_pass.hip.h, "Two-level lines"): lv[0] transforms N1 = lv[0].N points, lv[1] N2 = lv[1].N; a level is
     // the plain power-of-two chain (bluestein == false, M == N) or Bluestein on an arbitrary factor
     bool two = false;
+    // long Bluestein line (a length that neither fits one launch nor splits into two such factors: a prime above 4096, twice such a
+    // prime ...): Bluestein's algorithm whose M-point transforms are two-level lines; lv[0] is that two-level plan of M, chirp / bhat as
+    // for the one-launch form.  Four launches of the generic kernel (launch_long_bluestein).
+    bool longb = false;
     std::vector<Axis> lv;
     void *twN = nullptr;   // exp(-2 pi i j / N), N entries: twiddles between the levels
 };
@@ -202,6 +206,21 @@ static bool axis_plan_two_level(int prec, size_t N, Axis &a)
     return true;
 }
 
+// Long Bluestein plan: any length up to 2^23 whose padded length M = next_pow2(2N - 1) <= 2^24 runs as a two-level line
+static bool axis_plan_long(int prec, size_t N, Axis &a)
+{
+    a = Axis();
+    a.N = N;
+    if (N < 2) return false;
+    const size_t M = next_pow2(2 * N - 1);
+    if (M > ((size_t)1 << 24)) return false;
+    Axis inner;
+    if (!axis_plan_two_level(prec, M, inner)) return false;
+    a.longb = true; a.bluestein = true; a.two = false; a.M = M;
+    a.lv.assign(1, inner);
+    return true;
+}
+
 // decide how an axis of length N is transformed; returns false if unsupported.  two_level: 0 = only lengths with no other
 // plan, 1 = wherever a split exists (tests, A/B runs)
 static bool axis_plan(int prec, size_t N, Axis &a, bool mixed = true, int two_level = 0)
@@ -212,7 +231,7 @@ static bool axis_plan(int prec, size_t N, Axis &a, bool mixed = true, int two_le
     // native chain: powers of two 2..8192 and the mixed-radix lengths of kernels_mixed.inc (2^a 3^b 5^c 7^d <= 2048)
     if ((is_pow2(N) || mixed) && N <= 8192 && pass_info(prec, (int)N, &pi)) { a.bluestein = false; a.M = N; return true; }
     const size_t M = next_pow2(2 * N - 1);
-    if (N < 2 || M > 8192 || !pass_info(prec, (int)M, &pi)) return axis_plan_two_level(prec, N, a);
+    if (N < 2 || M > 8192 || !pass_info(prec, (int)M, &pi)) return axis_plan_two_level(prec, N, a) || axis_plan_long(prec, N, a);
     a.bluestein = true; a.M = M;
     return true;
 }
@@ -225,7 +244,7 @@ static bool axis_plan_bluestein(int prec, size_t N, Axis &a, int two_level = 0)
     a.N = N;
     if (two_level == 1 && axis_plan_two_level(prec, N, a)) return true;
     const size_t M = next_pow2(2 * N - 1);
-    if (N < 2 || M > 8192 || !pass_info(prec, (int)M, &pi)) return axis_plan_two_level(prec, N, a);
+    if (N < 2 || M > 8192 || !pass_info(prec, (int)M, &pi)) return axis_plan_two_level(prec, N, a) || axis_plan_long(prec, N, a);
     a.bluestein = true; a.M = M;
     return true;
 }
@@ -238,7 +257,8 @@ static int axis_upload(int prec, Axis &a)
         if (!a.twN) TRY(make_twiddles(prec, a.N, &a.twN));
         return 0;
     }
-    if (!a.tw) TRY(make_twiddles(prec, a.M, &a.tw));
+    if (a.longb) TRY(axis_upload(prec, a.lv[0]));
+    else if (!a.tw) TRY(make_twiddles(prec, a.M, &a.tw));
     if (a.bluestein && !a.chirp) {
         const size_t N = a.N, M = a.M;
         std::vector<std::complex<long double>> ch(N), b(M, std::complex<long double>(0, 0));
@@ -850,6 +870,64 @@ static int launch_two_level(int prec, const Axis &ax, PassArgs A, int real_mode,
 // bytes of scratch a two-level launch needs
 static size_t two_level_bytes(const PassArgs &A, int TL, size_t N, size_t esz) { return (size_t)A.ntiles * (size_t)TL * N * esz; }
 
+// Long Bluestein pass (fft_pass.hip.h, PassArgs::lb): X = ch * IFFT_M(FFT_M(x * ch, zero-padded) * bhat), the two M-point transforms
+// as two-level lines.  Launch 1 reads the pass's own load form (chirp and padding on the fly), launch 4 writes its own store form
+// (chirp on the fly), so unpack / pack / transposes stay fused as for every other pass; between them the line lives in a scratch of
+// natural M-point lines (S2) and the two-level scratch (S1).  The inverse M-point transform is the forward one between re <-> im
+// swaps; an inverse PASS swaps at its own two ends (PassArgs::swap of launches 1 and 4) like every inverse pass.
+//   1  level 1, pass's load form -> S1   lb = 1: x[n] * ch[n], 0 beyond the line          2  level 2, S1 -> S2 natural, * bhat, swapped
+//   3  level 1, S2 natural -> S1                                                           4  level 2, S1 -> pass's store form: swap, * ch
+static size_t long_bytes(const PassArgs &A, int TL, size_t M, size_t esz) { return 2 * (size_t)A.ntiles * (size_t)TL * M * esz; }
+static int launch_long_bluestein(int prec, const Axis &ax, const PassArgs &P, int real_mode, size_t NK, void *scratch, int TL, hipStream_t s)
+{
+    const Axis &in = ax.lv[0];      // the two-level plan of M
+    const uint32_t M = (uint32_t)ax.M, N1 = (uint32_t)in.lv[0].N, N2 = (uint32_t)in.lv[1].N;
+    const size_t esz = prec == DFFT_F64 ? 16 : 8;
+    char *S1 = static_cast<char *>(scratch), *S2 = S1 + (size_t)P.ntiles * (size_t)TL * M * esz;
+    auto level = [&](PassArgs B, int lv, bool qm) {
+        B.lvN = M; B.lvNK = M; B.lvtw = in.twN; B.lvw = S1; B.lv = lv; B.lvQ = (uint32_t)in.lv[2 - lv].N; B.lvqm = qm ? 1 : 0;
+        const int r = launch_generic(prec, in.lv[lv - 1], B, s);
+        return r == 0 ? 0 : fail(r == -1 ? ERR_UNSUPPORTED : r, "long Bluestein launch failed for length " + std::to_string(ax.N));
+    };
+    auto layout = [&](PassArgs &B, bool q1, bool q2) {      // as launch_two_level
+        if (!q1 && !q2) { B.lvlay = 0; B.lvs1 = N2 * (uint32_t)TL; B.lvs2 = (uint32_t)TL; }
+        else if (q1) { B.lvlay = 1; B.lvs1 = N2; B.lvs2 = 1; }
+        else { B.lvlay = 1; B.lvs1 = 1; B.lvs2 = N1; }
+    };
+    // natural M-point lines in S2 for the same tiles
+    auto natural_side = [&](PassArgs &B, bool store) {
+        if (store) { B.store_kind = STORE_LINES; B.out = S2; B.KS_out = 0; B.AS_out = 0; B.stab = nullptr; B.sseg = nullptr; B.snseg = 0; B.suni = 0; B.shift = 0; }
+        else { B.load_kind = LOAD_LINES; B.in = S2; B.KS_in = 0; B.AS_in = 0; B.ltab = nullptr; B.lseg = nullptr; B.lnseg = 0; B.luni = 0; }
+    };
+    const bool qin = P.load_kind == LOAD_LINES, qout = P.store_kind == STORE_LINES;      // (as launch_two_level decides)
+    {   // forward M-point transform: pass's load form -> S2
+        PassArgs A = P;
+        A.shift = 0;
+        natural_side(A, true);
+        layout(A, qin, true);
+        PassArgs L1 = A;
+        L1.lb = 1; L1.lbL = (uint32_t)ax.N; L1.lbK = (uint32_t)NK; L1.lbtab = ax.chirp; L1.real_mode = real_mode;      // (swap: the pass's)
+        TRY(level(L1, 1, qin));
+        PassArgs L2 = A;
+        L2.lb = 2; L2.lbL = M; L2.lbK = M; L2.lbtab = ax.bhat; L2.real_mode = 0; L2.swap = 1;
+        TRY(level(L2, 2, true));
+    }
+    {   // inverse M-point transform: S2 -> pass's store form
+        PassArgs A = P;
+        natural_side(A, false);
+        layout(A, true, qout);
+        PassArgs L3 = A;
+        L3.lb = 0; L3.real_mode = 0; L3.swap = 0; L3.shift = 0;
+        natural_side(L3, true);      // (its store side is the scratch S1: unused, but must not carry the pass's tables)
+        L3.out = nullptr;
+        TRY(level(L3, 1, true));
+        PassArgs L4 = A;
+        L4.lb = 6; L4.lbL = (uint32_t)ax.N; L4.lbK = (uint32_t)NK; L4.lbtab = ax.chirp; L4.real_mode = real_mode;      // (swap: the pass's)
+        TRY(level(L4, 2, qout));
+    }
+    return 0;
+}
+
 // complex axis pass on axis `axis` (0 = z, 1 = y, 2 = x)
 static int launch(dfft_plan *p, const Launch &L, int variant, int axis, const char *in, char *out, bool real_lines = false)
 {
@@ -866,6 +944,10 @@ static int launch(dfft_plan *p, const Launch &L, int variant, int axis, const ch
         return 0;
     }
     if (!ax.bluestein) return launch_pass(p->prec, (int)ax.N, variant, A, p->stream);
+    if (ax.longb) {
+        if (long_bytes(A, p->TL, ax.M, p->esz) > p->lv_bytes) return fail(ERR_STATE, "long Bluestein pass: scratch region too small");
+        return launch_long_bluestein(p->prec, ax, A, real_lines ? 1 : 0, real_lines ? ax.N / 2 + 1 : ax.N, static_cast<char *>(p->work_d) + p->lv_off, p->TL, p->stream);
+    }
     if (ax.two) {
         if (two_level_bytes(A, p->TL, ax.N, p->esz) > p->lv_bytes) return fail(ERR_STATE, "two-level pass: scratch region too small");
         return launch_two_level(p->prec, ax, A, real_lines ? 1 : 0, real_lines ? ax.N / 2 + 1 : ax.N, static_cast<char *>(p->work_d) + p->lv_off, p->TL, p->stream);
@@ -893,6 +975,9 @@ static int launch_real(dfft_plan *p, const Launch &L, int mode, const char *in, 
                                 : launch_real_f32(M, mode, p->opt.real_variant, A, p->stream);
     } else if (!ax.bluestein) {
         return fail(ERR_UNSUPPORTED, "real z pass without a native or Bluestein plan");      // (dfft_init rules this out)
+    } else if (ax.longb) {
+        if (long_bytes(A, p->TL, ax.M, p->esz) > p->lv_bytes) return fail(ERR_STATE, "long Bluestein pass: scratch region too small");
+        return launch_long_bluestein(p->prec, ax, A, mode, p->Nzc, static_cast<char *>(p->work_d) + p->lv_off, p->TL, p->stream);
     } else if (ax.two) {
         if (two_level_bytes(A, p->TL, ax.N, p->esz) > p->lv_bytes) return fail(ERR_STATE, "two-level pass: scratch region too small");
         return launch_two_level(p->prec, ax, A, mode, p->Nzc, static_cast<char *>(p->work_d) + p->lv_off, p->TL, p->stream);
@@ -1699,8 +1784,8 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         const bool zreal_generic = !yzx && !c2c && !zr_native;
         const bool zok = zreal_generic ? axis_plan_bluestein(p->prec, Nz, az, tl) : axis_plan(p->prec, zlen, az, mixed, tl);
         if (!zok || !yok || !axis_plan(p->prec, Nx, axx, mixed, tl))
-            return fail(ERR_UNSUPPORTED, "unsupported axis length (any length up to 4096, powers of two up to 8192, and beyond that every length "
-                                         "N1*N2 <= 2^24 whose factors are each such a length: not a prime above 4096)");
+            return fail(ERR_UNSUPPORTED, "unsupported axis length (every length from 2 to 2^23 has a plan; beyond that only lengths N1*N2 <= 2^24 whose "
+                                         "factors are each a power of two up to 8192 or any length up to 4096)");
         for (auto &a : p->ax) axis_free(a);
         p->ax[0] = az; p->ax[1] = ay; p->ax[2] = axx;
         p->zreal_native = zr_native;
@@ -1777,6 +1862,7 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         size_t lvb = 0;
         auto need = [&](const Launch &L, int axis) {
             if (p->ax[axis].two) lvb = std::max(lvb, two_level_bytes(L.args, p->TL, p->ax[axis].N, p->esz));
+            if (p->ax[axis].longb) lvb = std::max(lvb, long_bytes(L.args, p->TL, p->ax[axis].M, p->esz));
         };
         for (auto &L : pl.fz) need(L, 0); for (auto &L : pl.iz) need(L, 0);
         for (auto &L : pl.fy) need(L, 1); for (auto &L : pl.iy) need(L, 1); for (auto &L : pl.py2) need(L, 1); for (auto &L : pl.qy2) need(L, 1);
@@ -2257,7 +2343,7 @@ int dfft_fft1d_batched_ex(int precision, size_t N, size_t batch, void *out, cons
     const bool has = !ax.bluestein && variant ? (precision == DFFT_F64 ? pass_info_f64((int)ax.M, variant, &pi) : pass_info_f32((int)ax.M, variant, &pi)) : false;
     if (!has) {
         variant = 0;
-        if (!pass_info(precision, ax.two ? 2 : (int)ax.M, &pi)) return fail(ERR_UNSUPPORTED, "unsupported line length");      // (two levels: any configuration gives TL)
+        if (!pass_info(precision, ax.two || ax.longb ? 2 : (int)ax.M, &pi)) return fail(ERR_UNSUPPORTED, "unsupported line length");      // (two levels: any configuration gives TL)
     }
     PassArgs A;
     memset(&A, 0, sizeof(A));
@@ -2265,13 +2351,14 @@ int dfft_fft1d_batched_ex(int precision, size_t N, size_t batch, void *out, cons
     A.na = 1; A.LB = (uint32_t)batch; A.nb = ((uint32_t)batch + pi.TL - 1) / pi.TL; A.ntiles = A.nb;
     A.load_kind = LOAD_LINES; A.store_kind = STORE_LINES; A.swap = direction == DFFT_INVERSE;
     if (!ax.bluestein) return launch_pass(precision, (int)N, variant, A, (hipStream_t)hip_stream);
-    if (ax.two) {
-        const size_t need = two_level_bytes(A, pi.TL, N, precision == DFFT_F64 ? 16 : 8);
+    if (ax.two || ax.longb) {
+        const size_t need = ax.longb ? long_bytes(A, pi.TL, ax.M, precision == DFFT_F64 ? 16 : 8) : two_level_bytes(A, pi.TL, N, precision == DFFT_F64 ? 16 : 8);
         if (need > lvw_bytes) {
             if (lvw) { (void)hipFree(lvw); lvw = nullptr; lvw_bytes = 0; }      // (hipFree waits for the launches that still use it)
             HIP_TRY(hipMalloc(&lvw, need));
             lvw_bytes = need;
         }
+        if (ax.longb) return launch_long_bluestein(precision, ax, A, 0, N, lvw, pi.TL, (hipStream_t)hip_stream);
         return launch_two_level(precision, ax, A, 0, N, lvw, pi.TL, (hipStream_t)hip_stream);
     }
     A.NK = (uint32_t)N;
@@ -2290,7 +2377,7 @@ int dfft_kernel_info(int precision, size_t N, int *threads, int *lds_bytes, int 
 {
     PassInfo pi;
     Axis a;
-    if (!axis_plan(precision, N, a) || !pass_info(precision, (int)(a.two ? a.lv[1].M : a.M), &pi)) return ERR_UNSUPPORTED;      // two levels: the second level's kernel
+    if (!axis_plan(precision, N, a) || !pass_info(precision, (int)(a.longb ? a.lv[0].lv[1].M : a.two ? a.lv[1].M : a.M), &pi)) return ERR_UNSUPPORTED;      // two levels: the second level's kernel
     if (threads) *threads = pi.threads;
     if (lds_bytes) *lds_bytes = pi.lds_bytes;
     if (points_per_thread) *points_per_thread = pi.E;
@@ -2304,8 +2391,9 @@ int dfft_axis_plan_info(int precision, size_t N, int two_level, size_t info[8])
     Axis a;
     if (!axis_plan(precision, N, a, true, two_level)) return ERR_UNSUPPORTED;
     for (int k = 0; k < 8; k++) info[k] = 0;
-    info[0] = a.two ? 2 : a.bluestein ? 1 : 0;
+    info[0] = a.longb ? 3 : a.two ? 2 : a.bluestein ? 1 : 0;
     info[1] = a.M;
+    if (a.longb) a = Axis(a.lv[0]);      // the levels of the padded length
     for (size_t k = 0; k < a.lv.size(); k++) { info[2 + 3 * k] = a.lv[k].N; info[3 + 3 * k] = a.lv[k].M; info[4 + 3 * k] = a.lv[k].bluestein; }
     return 0;
 }

@@ -112,6 +112,14 @@ struct PassArgs {
     int32_t lvqm;          // this level's lanes run over neighbouring sub-lines of one line (its outer side has natural lines)
     int32_t lvlay;         // scratch layout: 0 tiled ((w*N1 + i1)*N2 + i2)*TL + l, 1 per line: line*lvN + i1*lvs1 + i2*lvs2
     uint32_t lvs1, lvs2;
+    // long Bluestein lines (a length beyond the one-launch kernel that does not split either, e.g. a prime above 4096): Bluestein's
+    // algorithm with M-point transforms that are two-level lines themselves -- four launches, whose outer sides carry the chirp steps.
+    // bit 0 (a first-level launch): the points a sub-line fetches are those of a line of lbL points (lbK on the spectral side of a real
+    // transform), multiplied by lbtab[point] and zero beyond lbL; bit 1 (a second-level launch): output k is multiplied by lbtab[k];
+    // bit 2 (second level): re <-> im are swapped before that product (the inverse M-point transform by the swap trick)
+    int32_t lb;
+    uint32_t lbL, lbK;
+    const void *lbtab;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1661,7 +1669,10 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_bluestein_kernel(const PassA
     }
     const uint32_t NL = A.NL;
     // the line as the pass's address forms see it: its length, its points on the spectral side of a real transform
-    const uint32_t NF = lv ? A.lvN : NL, NKF = lv ? A.lvNK : A.NK;
+    // (a long-Bluestein launch: the pass's own line has lbL / lbK points, the two-level line around it lvN)
+    const uint32_t NS = lv ? A.lvN : NL;                                      // points of the line in the scratch between the levels
+    const uint32_t NF = A.lb ? A.lbL : NS, NKF = A.lb ? A.lbK : (lv ? A.lvNK : A.NK);
+    const C *__restrict__ LBT = reinterpret_cast<const C *>(A.lbtab);
     const bool plain = A.plain != 0;
     const C *__restrict__ in = reinterpret_cast<const C *>(A.in);
     const R *__restrict__ rin = reinterpret_cast<const R *>(A.in);
@@ -1695,6 +1706,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_bluestein_kernel(const PassA
         load_all([&](uint32_t n) {
             const uint32_t nf = lv ? n * Q + q : n;
             C x; x.x = 0; x.y = 0;
+            if ((A.lb & 1) && nf >= NF) return x;      // zero padding of a long-Bluestein line
             if (A.real_mode == 1) {            // real input line
                 x.x = rin[offset_of(nf, NF)];
             } else if (A.real_mode == 2) {     // Hermitian half in, rebuild the full spectrum
@@ -1709,13 +1721,18 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_bluestein_kernel(const PassA
                 x = in[offset_of(nf, NF)];
             }
             if (A.swap) { R tmp = x.x; x.x = x.y; x.y = tmp; }
+            if (A.lb & 1) {                    // long Bluestein: times the chirp of the LINE's point
+                const C ch = LBT[nf];
+                C r; r.x = x.x * ch.x - x.y * ch.y; r.y = x.x * ch.y + x.y * ch.x;
+                x = r;
+            }
             return x;
         });
     };
     const uint64_t rowline = (uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + tc.l;
     // scratch element (i1, i2) of this thread's line: tiled (lvlay 0, both levels with lanes over the lines of a tile) at
     // ((w*N1 + i1)*N2 + i2)*TL + l, else in the line's own N points at i1*lvs1 + i2*lvs2
-    const uint64_t sbase = A.lvlay == 0 ? (uint64_t)w * NF * TL + (uint32_t)l : rowline * NF;
+    const uint64_t sbase = A.lvlay == 0 ? (uint64_t)w * NS * TL + (uint32_t)l : rowline * NS;
     if (lv == 2) {                                       // second level: sub-line q = i1 of the scratch
         const C *__restrict__ ws = reinterpret_cast<const C *>(A.lvw) + sbase + (uint64_t)q * A.lvs1;
         const uint64_t s2 = A.lvs2;
@@ -1788,6 +1805,12 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_bluestein_kernel(const PassA
         store_all(lv ? NL : kend, [&](uint32_t k, C r) {
             const uint32_t kf = lv ? q + Q * k : k;
             if (lv && kf >= kend) return;
+            if (A.lb & 4) { R tmp = r.x; r.x = r.y; r.y = tmp; }
+            if (A.lb & 2) {
+                const C m = LBT[kf];
+                C y; y.x = r.x * m.x - r.y * m.y; y.y = r.x * m.y + r.y * m.x;
+                r = y;
+            }
             if (A.swap) { R tmp = r.x; r.x = r.y; r.y = tmp; }
             if (A.real_mode == 2) rout[offset_of(kf)] = r.x;
             else out[offset_of(kf)] = r;

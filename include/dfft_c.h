@@ -132,7 +132,8 @@ int dfft_plan_destroy(dfft_plan *plan);
  * plan) and the lengths 2^a 3^b 5^c 7^d <= 2048 listed in csrc/kernels_mixed.inc (native chain), any other length
  * up to 4096 (Bluestein), and beyond that every length N1*N2 <= 2^24 whose factors are each such a length (two-level
  * lines: two launches per pass and a scratch region in the work area, dfft_axis_plan_info shows the split); a length
- * that does not split that way (e.g. a prime factor above 4096) is ERR_UNSUPPORTED.  c2c = 0: R2C/C2R plan (Nz_out = Nz/2+1,
+ * that does not split that way (a prime above 4096, twice such a prime ...) runs Bluestein's algorithm over a two-level padded
+ * length (four launches), so every length from 2 to 2^23 has a plan; beyond 2^24 points per line: ERR_UNSUPPORTED.  c2c = 0: R2C/C2R plan (Nz_out = Nz/2+1,
  * include/params.hpp:30); c2c = 1: complex plan (Nz_out = Nz). */
 int dfft_init(dfft_plan *plan, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int c2c, int allocate);
 /* setWorkArea(void *device, void *host)   mpicufft_pencil_opt1.cpp:329-387.  NULL device =
@@ -286,9 +287,11 @@ const char *dfft_version(void);
 int dfft_kernel_info(int precision, size_t N, int *threads, int *lds_bytes, int *points_per_thread,
                      int *lines_per_workgroup);
 /* how an axis of N points is transformed (the plan cufftMakePlanMany64 hides, mpicufft_pencil_opt1.cpp:165-197): returns 0 and fills
- * info[0] = 0 native chain / 1 Bluestein / 2 two levels (N = N1*N2 over two launches), info[1] = inner power-of-two length (0 for
- * two levels), and for two levels info[2..4] = {N1, its inner length, 1 if Bluestein} and info[5..7] likewise for N2.
- * two_level = 1: two levels wherever N splits (the plan option of the same name).  ERR_UNSUPPORTED: no plan (a prime above 4096 ...). */
+ * info[0] = 0 native chain / 1 Bluestein / 2 two levels (N = N1*N2 over two launches) / 3 long Bluestein (a length that neither fits
+ * one launch nor splits, e.g. a prime above 4096: Bluestein's algorithm on info[1] padded points whose transforms are two-level lines;
+ * four launches), info[1] = inner power-of-two length (0 for two levels), and for two levels / long Bluestein info[2..4] = {N1, its
+ * inner length, 1 if Bluestein} and info[5..7] likewise for N2 (the levels of the padded length in the long form).
+ * two_level = 1: two levels wherever N splits (the plan option of the same name).  ERR_UNSUPPORTED: no plan (beyond 2^23 points). */
 int dfft_axis_plan_info(int precision, size_t N, int two_level, size_t info[8]);
 
 /* ---- placement-aware device memory (no counterpart in the reference, whose buffers are plain cudaMalloc,

@@ -54,14 +54,18 @@ def test_kernel_table():
         # every other length runs through Bluestein on the next power of two >= 2N-1 (N <= 4096)
         assert dfft.kernel_info(3, prec)["points_per_thread"] == 8 and dfft.kernel_info(1023, prec)["threads"] > 0
         assert dfft.kernel_info(1025, prec)["threads"] > 0 and dfft.kernel_info(4095, prec)["threads"] > 0
-        # beyond that: two-level lines N = N1*N2 (each factor within reach of the generic kernel); a prime above 4096 has no plan
+        # beyond that: two-level lines N = N1*N2 (each factor within reach of the generic kernel), and for what does not split -- a prime
+        # above 4096, twice such a prime -- Bluestein over a two-level padded length; nothing beyond 2^24 points
         assert dfft.kernel_info(16384, prec)["threads"] > 0 and dfft.kernel_info(5000, prec)["threads"] > 0
-        assert dfft.kernel_info(4099, prec) is None and dfft.kernel_info(2 * 4099, prec) is None
+        assert dfft.kernel_info(4099, prec)["threads"] > 0 and dfft.kernel_info(2 * 4099, prec)["threads"] > 0
+        assert dfft.axis_plan_info(4099, prec) == {"kind": "long_bluestein", "M": 16384, "levels": [(128, 128, False), (128, 128, False)]}
+        assert dfft.kernel_info((1 << 24) + 1, prec) is None
 
 
 def test_axis_plans_cover_every_length_the_factors_allow():
-    """dfft_axis_plan_info: native chain / Bluestein / two levels.  Every length up to 4096 has a plan, powers of two up to 8192
-    have the native one, and beyond that exactly the lengths N1*N2 whose factors are each within reach of the generic kernel
+    """dfft_axis_plan_info: native chain / Bluestein / two levels / long Bluestein.  Every length up to 4096 has a plan, powers of two
+    up to 8192 have the native one, beyond that the lengths N1*N2 whose factors are each within reach of the generic kernel run in two
+    levels and everything else up to 2^23 as Bluestein over a two-level padded length
     (the reference takes any length through cufftMakePlanMany64, mpicufft_pencil_opt1.cpp:165-197)."""
     def reach(f):      # one launch of the generic kernel: plain power of two <= 8192, or Bluestein with 2f-1 <= 8192
         return f >= 2 and ((f & (f - 1)) == 0 and f <= 8192 or 2 * f - 1 <= 8192)
@@ -73,13 +77,20 @@ def test_axis_plans_cover_every_length_the_factors_allow():
                                             4099, 2 * 4099, 4093 * 4093, 4096 * 4096, 4096 * 4096 + 2, 1 << 25]:
             info = dfft.axis_plan_info(n, prec)
             splits = [d for d in range(2, int(n ** 0.5) + 1) if n % d == 0 and reach(d) and reach(n // d)] if n <= 1 << 24 else []
-            assert (info is not None) == bool(splits), n
-            if info:
+            # what does not split -- a prime above 4096 (4099), twice one (8198), 4093 x 4093 ... -- runs Bluestein over a two-level
+            # padded length as long as that stays within 2^24 points
+            pad = 1 << (2 * n - 2).bit_length()
+            assert (info is not None) == (bool(splits) or pad <= 1 << 24), n
+            if info and splits:
                 assert info["kind"] == "two_level" and info["M"] == 0
                 (n1, m1, b1), (n2, m2, b2) = info["levels"]
                 assert n1 * n2 == n and reach(n1) and reach(n2)
                 for f, m, b in info["levels"]:
                     assert (m == f and f & (f - 1) == 0) if not b else (m & (m - 1) == 0 and m >= 2 * f - 1 and m < 2 * (2 * f - 1))
+            elif info:
+                assert info["kind"] == "long_bluestein" and info["M"] == pad
+                (n1, m1, b1), (n2, m2, b2) = info["levels"]
+                assert n1 * n2 == pad and not b1 and not b2 and m1 == n1 and m2 == n2 and max(n1, n2) <= 8192
         # the option / variant that forces two levels: every composite length splits, primes keep their plan
         for n in (4, 6, 15, 64, 1000, 1024, 1155, 4096):
             info = dfft.axis_plan_info(n, prec, two_level=1)
@@ -230,7 +241,7 @@ def test_init_errors():
     with pytest.raises(dfft.DfftError, match="Invalid Input Partition"):
         pl.initFFT(dfft.GlobalSize(16, 16, 16), dfft.Slab_Partition(2), allocate=False)
     with pytest.raises(dfft.DfftError, match="unsupported"):
-        pl.initFFT(dfft.GlobalSize(16, 16, 4099), dfft.Slab_Partition(1), allocate=False, c2c=True)      # a prime above 4096
+        pl.initFFT(dfft.GlobalSize(16, 16, (1 << 24) + 1), dfft.Slab_Partition(1), allocate=False, c2c=True)      # more than 2^24 points on a line
     world = dfft.Comm.local(4)
     ps = dfft.MPIcuFFT_Slab_Opt1(dfft.Configurations(), world, rank=0)
     with pytest.raises(dfft.DfftError, match="slab"):

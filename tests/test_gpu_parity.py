@@ -239,7 +239,7 @@ def test_error_behaviour():
     with pytest.raises(dfft.DfftError, match="C2C|R2C"):
         pl.execC2C(1, 1)
     with pytest.raises(dfft.DfftError, match="unsupported"):
-        pl.initFFT(dfft.GlobalSize(4099, 16, 16), dfft.Pencil_Partition(1, 1))      # a prime above 4096
+        pl.initFFT(dfft.GlobalSize((1 << 24) + 1, 16, 16), dfft.Pencil_Partition(1, 1), False)      # more than 2^24 points on a line
 
 
 @pytest.mark.parametrize("chunks", [1, 2, 3, 5, 8])

@@ -135,7 +135,7 @@ def test_tune_variants_is_collective_with_rank_dependent_roles():
     torch.cuda.synchronize()
     with ThreadPoolExecutor(P1 * P2) as ex:
         trials = list(ex.map(lambda r: plans[r].tuneVariants(ins[r], outs[r], backs[r]), range(P1 * P2)))
-    assert len({len(t) for t in trials}) == 1 and len(trials[0]) == 12      # as built + 4 order settings + chosen orders + configurations 0..3 + address forms + final, on every rank
+    assert len({len(t) for t in trials}) == 1 and len(trials[0]) == 13      # as built + 4 order settings + chosen orders + configurations 0..3 and 8 + address forms + final, on every rank
     with ThreadPoolExecutor(P1 * P2) as ex:
         list(ex.map(lambda r: plans[r].execR2C(outs[r], ins[r]), range(P1 * P2)))
     scale = np.max(np.abs(want))

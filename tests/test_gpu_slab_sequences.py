@@ -229,8 +229,8 @@ def test_y_then_zx_pipeline_depths_tables_and_errors(chunks):
     with pytest.raises(dfft.DfftError, match="forward only"):
         plans[0].execC2R(1, 1)
     one = dfft.MPIcuFFT_Slab_Y_Then_ZX(dfft.Configurations())
-    with pytest.raises(dfft.DfftError, match="unsupported axis length"):      # a prime above 4096: beyond the Bluestein kernel, no two-level split
-        one.initFFT(dfft.GlobalSize(16, 4099, 16), dfft.Slab_Partition(1), True)
+    with pytest.raises(dfft.DfftError, match="unsupported axis length"):      # beyond the 32-bit point indices of the generic kernel
+        one.initFFT(dfft.GlobalSize(16, (1 << 24) + 1, 16), dfft.Slab_Partition(1), False)
 
 
 @pytest.mark.parametrize("prec", ["double", "float"])

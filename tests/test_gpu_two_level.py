@@ -59,15 +59,58 @@ def test_fft1d_long_lines_vs_oracle(N, prec):
     fft1d_case(N, prec, 0, 11 if N < 50000 else 5)
 
 
-def test_unsupported_lengths_fail_loudly():
-    """a prime above 4096 has no plan, nor has twice such a prime (Bluestein would need more than 8192 points)"""
-    x = torch.zeros(4 * 8198, dtype=torch.complex128, device="cuda")
-    for N in (4099, 8198):
-        with pytest.raises(dfft.DfftError):
-            dfft.fft1d_batched(torch.zeros_like(x), x, N, 4, dfft.FORWARD, "double")
+LONG_BLUESTEIN = [4099, 8198, 5003, 10007, 12289, 2 * 3 * 4099, 65537]
+
+
+@pytest.mark.parametrize("prec", ["double", "float"])
+@pytest.mark.parametrize("N", LONG_BLUESTEIN)
+def test_fft1d_long_bluestein_lines_vs_oracle(N, prec):
+    """lengths that neither fit one launch nor split into two factors within its reach -- a prime above 4096 (4099, 5003, 10007,
+    12289, 65537), a small multiple of one (8198, 24594) -- run Bluestein's algorithm with M-point transforms that are two-level
+    lines themselves (four launches of the generic kernel, dfft.hip launch_long_bluestein).  The reference takes such sizes through
+    cuFFT like any other (mpicufft_pencil_opt1.cpp:165-197)."""
+    assert dfft.axis_plan_info(N, prec)["kind"] == "long_bluestein"
+    fft1d_case(N, prec, 0, 7 if N < 20000 else 3)
+
+
+def test_every_length_has_a_plan_and_absurd_ones_fail_loudly():
+    """every length from 2 to 2^23 has a plan now; beyond the 32-bit point indices of the kernel (2^24) there is none"""
+    for N in (2, 3, 4099, 8191 * 3, 99991, 1000003, (1 << 23) - 15):
+        assert dfft.axis_plan_info(N, "double") is not None
     plan = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), precision="double")
     with pytest.raises(dfft.DfftError, match="unsupported axis length"):
-        plan.initFFT(dfft.GlobalSize(4099, 4, 4), dfft.Pencil_Partition(1, 1), True, c2c=True)
+        plan.initFFT(dfft.GlobalSize((1 << 24) + 1, 4, 4), dfft.Pencil_Partition(1, 1), False, c2c=True)
+
+
+@pytest.mark.parametrize("prec", ["double", "float"])
+@pytest.mark.parametrize("c2c", [True, False])
+@pytest.mark.parametrize("shape", [(4099, 4, 6), (3, 4099, 8), (5, 4, 4099), (6, 5, 8198), (8198, 3, 10)])
+def test_single_rank_long_bluestein_axes_vs_oracle(shape, c2c, prec):
+    """a long-Bluestein axis in every position; R2C: real input lines of an odd (4099) and an even (8198) prime-ridden length"""
+    g, got, back = single(shape, prec, c2c)
+    want = orc.fft3d_c2c(g.astype(np.complex128), -1) if c2c else orc.fft3d_r2c(g.astype(np.float64))
+    assert rel(got, want) < (4e-11 if prec == "double" else 4e-4)
+    assert rel(back / g.size, g) < (2e-10 if prec == "double" else 1e-4)
+
+
+@pytest.mark.parametrize("c2c", [True, False])
+@pytest.mark.parametrize("shape,P1,P2,chunks", [((4099, 8, 12), 2, 2, 2), ((8, 4099, 6), 2, 2, 1), ((6, 8, 4099), 2, 3, 2), ((4099, 6, 8), 3, 1, 3)])
+def test_distributed_long_bluestein_axes_vs_oracle(shape, P1, P2, chunks, c2c):
+    """... distributed: the first and the last launch carry the pass's own (segmented, chunked) address forms"""
+    prec = "double"
+    if c2c:
+        plans, ins, spec, backs = run_distributed(shape, P1, P2, prec, chunks=chunks)
+        g = orc.fill_block(shape, (0, 0, 0), shape, 2, seed=7).astype(np.complex128)
+        want = orc.fft3d_c2c(g, -1)
+    else:
+        plans, ins, spec, backs = run_distributed_real(shape, P1, P2, prec)
+        g = orc.fill_block(shape, (0, 0, 0), shape, 1, seed=13).astype(np.float64)
+        want = orc.fft3d_r2c(g)
+    scale = np.max(np.abs(want))
+    for r, pl in enumerate(plans):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        assert np.max(np.abs(spec[r] - want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]])) / scale < 4e-11
+        assert rel(backs[r] / float(np.prod(shape)), ins[r]) < 2e-10
 
 
 def single(shape, prec, c2c, options=None, seed=5):
