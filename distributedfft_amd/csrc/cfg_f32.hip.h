@@ -68,16 +68,25 @@ using F32_2048_v12 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 0, 2
 using F32_2048_v13 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 3, 0, 2>;
 using F32_2048_v14 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 0, 2>;
 using F32_2048_v15 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3, 0, 2>;
-// under test (A/B): the transposed-tile store of the inverse y pass in whole 128-byte lines (point-fastest mapping after the first exchange)
-// at 32 points per thread -- whole tiles on 1024 threads (11 / 3: without / with hints) and sub-tiles of 8 lines (2 / 7)
+//   7 = transposed-tile store (the inverse y pass of a multi-rank plan): tiled load with the line-fastest mapping, then the point-fastest
+//       one, so that a wave stores whole 128-byte lines of the consumer's tiles instead of 32-byte pieces that four waves complete
+//       (a line-fastest fp32 wave is 16 lines x 4 points); 32 points per thread on sub-tile workgroups of 8 lines (two workgroups = 32
+//       waves per CU), nontemporal hints.  Rank 0 of 2 x 4 at 2048^3: 4.80 ms (variant 5, the tuner's former pick; 5.58 with 6) ->
+//       3.63 ms, as a copy 3.50; slab 8: 4.73 -> 3.87.  The same mapping on whole tiles at 64 points per thread (round 3, variant 10)
+//       had shown nothing: 5.38.  profiles/r4_f32_2048_inverse_y_whole_lines.txt
+using F32_2048_v7 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3, 2, 2>;
+// A/B only: the same without hints (2: 4.19 ms), on whole tiles with 1024 threads (11 / 3: 4.59 / 4.03), and the 1024-point siblings under test
+using F32_2048_v2 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 2, 2>;
 using F32_2048_v11 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 2>;
 using F32_2048_v3 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3, 2>;
-using F32_2048_v2 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 2, 2>;
-using F32_2048_v7 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3, 2, 2>;
+using F32_1024_v7 = PassCfg<float, 1024, 16, 16, 1, 16, 8, 8, 1, 1, 1, 3, 2, 2>;      // 64 threads per line x 8 lines
+using F32_1024_v11 = PassCfg<float, 1024, 32, 16, 1, 32, 8, 4, 1, 1, 1, 3, 2, 2>;     // 32 threads per line x 8 lines
+using F32_1024_v3 = PassCfg<float, 1024, 32, 16, 1, 32, 8, 4, 1, 1, 1, 3, 2>;         // whole tiles, 512 threads
+using F32_1024_v2 = PassCfg<float, 1024, 16, 16, 1, 16, 8, 8, 1, 1, 1, 3, 2>;         // whole tiles, 1024 threads
 #ifdef DFFT_EXPERIMENTS
 #define DFFT_F32_EXP_SMALL(X)
-#define DFFT_F32_EXP_1024(X) X(1024, 10, F32_1024_v10)
-#define DFFT_F32_EXP_2048(X) X(2048, 10, F32_2048_v10) X(2048, 12, F32_2048_v12) X(2048, 13, F32_2048_v13) X(2048, 11, F32_2048_v11) X(2048, 3, F32_2048_v3) X(2048, 2, F32_2048_v2) X(2048, 7, F32_2048_v7)
+#define DFFT_F32_EXP_1024(X) X(1024, 10, F32_1024_v10) X(1024, 7, F32_1024_v7) X(1024, 11, F32_1024_v11) X(1024, 3, F32_1024_v3) X(1024, 2, F32_1024_v2)
+#define DFFT_F32_EXP_2048(X) X(2048, 10, F32_2048_v10) X(2048, 12, F32_2048_v12) X(2048, 13, F32_2048_v13) X(2048, 11, F32_2048_v11) X(2048, 3, F32_2048_v3) X(2048, 2, F32_2048_v2)
 #else
 #define DFFT_F32_EXP_SMALL(X)
 #define DFFT_F32_EXP_1024(X)
@@ -85,7 +94,7 @@ using F32_2048_v7 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3, 2, 2>;
 #endif
 #define DFFT_F32_LIST_SMALL(X) X(512, 6, F32_512_v6) X(512, 9, F32_512_v9) X(512, 4, F32_512_v4) X(512, 5, F32_512_v5) X(2, 0, F32_2) X(4, 0, F32_4) X(8, 0, F32_8) X(16, 0, F32_16) X(32, 0, F32_32) X(64, 0, F32_64) X(128, 0, F32_128) X(256, 0, F32_256) X(512, 0, F32_512) DFFT_F32_EXP_SMALL(X)
 #define DFFT_F32_LIST_1024(X) X(1024, 4, F32_1024_v4) X(1024, 5, F32_1024_v5) X(1024, 6, F32_1024_v6) X(1024, 9, F32_1024_v9) X(1024, 0, F32_1024) DFFT_F32_EXP_1024(X)
-#define DFFT_F32_LIST_2048(X) X(2048, 4, F32_2048_v4) X(2048, 5, F32_2048_v5) X(2048, 6, F32_2048_v6) X(2048, 9, F32_2048_v9) X(2048, 14, F32_2048_v14) X(2048, 15, F32_2048_v15) X(2048, 0, F32_2048) X(4096, 0, F32_4096) X(8192, 0, F32_8192) DFFT_F32_EXP_2048(X)
+#define DFFT_F32_LIST_2048(X) X(2048, 4, F32_2048_v4) X(2048, 5, F32_2048_v5) X(2048, 6, F32_2048_v6) X(2048, 9, F32_2048_v9) X(2048, 7, F32_2048_v7) X(2048, 14, F32_2048_v14) X(2048, 15, F32_2048_v15) X(2048, 0, F32_2048) X(4096, 0, F32_4096) X(8192, 0, F32_8192) DFFT_F32_EXP_2048(X)
 
 // lengths with a packed real z pass / a Bluestein inner transform of their own configuration
 // real-transform z passes (variant 0 configurations only); M = Nz/2

@@ -1901,6 +1901,10 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
             if (p->c2c && has32(p->ax[0], ROLE_NATURAL_STORE)) p->vinv[0] = ROLE_NATURAL_STORE;
             for (int ax = 1; ax <= 2; ax++)
                 if (has32(p->ax[ax], ROLE_TILED)) p->vfwd[ax] = p->vinv[ax] = ROLE_TILED;
+            // the inverse y pass of a multi-rank plan stores transposed tiles: whole-line stores (ROLE_TRANSPOSED_STORE) where the length
+            // has such a configuration (2048 points: 4.80 -> 3.63 ms on rank 0 of 2 x 4 at 2048^3)
+            // (a single rank's complex inverse runs the forward launches: there vinv is not used)
+            if (has32(p->ax[1], ROLE_TRANSPOSED_STORE)) p->vinv[1] = ROLE_TRANSPOSED_STORE;
             // (The inverse y pass stores transposed tiles, which a line-fastest fp32 wave -- 16 lines x 4 points -- writes in 32-byte
             // pieces.  A point-fastest store mapping, PassCfg::MAP = 2, writes whole lines and was measured: 1024 points 4.42 vs 4.30 ms,
             // 2048 points 10.55 vs 10.35, no better -- L2 merges the pieces; profiles/r3_f32_inverse_y_point_fastest_store.txt.)
@@ -2527,7 +2531,7 @@ static int tune_variants(dfft_plan *p, const void *in, void *o, void *b, float &
     // (-DDFFT_EXPERIMENTS) carries further configuration numbers that are measured by hand, never picked here
     auto validated = [&](int v) {
         if (p->prec == DFFT_F64) return (v >= 0 && v <= 3) || v == 7 || v == 8;
-        return v == 0 || (v >= 4 && v <= 6) || v == 9 || v == 14 || v == 15;
+        return v == 0 || (v >= 4 && v <= 7) || v == 9 || v == 14 || v == 15;
     };
     for (int v = 0; v < 16; v++) {
         if (!validated(v)) continue;

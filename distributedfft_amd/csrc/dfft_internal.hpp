@@ -21,6 +21,7 @@ enum PassRole {
     ROLE_NATURAL_STORE = 5,    // fp32: natural lines out (point-fastest mapping after the first pass)
     ROLE_TILED = 6,            // fp32: tiled on both sides (two radix passes, one exchange)
     ROLE_LINES = 7,            // fp64: natural lines on one side where that differs from ROLE_STREAM (2048: sub-tiles)
+    ROLE_TRANSPOSED_STORE = 7, // fp32: tiled load, transposed-tile store in whole 128-byte lines (the inverse y pass of a multi-rank plan)
     ROLE_STRIDED_READ_FUSED = 8,   // fp64: ROLE_STRIDED_READ as persistent workgroups, stores fused with the next tile's loads (plans with P1 = 1)
     ROLE_TILED_STREAM = 9      // fp32: ROLE_TILED with nontemporal loads and stores (chosen by measurement only: dfft_tune_variants)
 };
