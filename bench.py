@@ -46,6 +46,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 XGMI_LINK_GBS = 153.0   # same guide: per link and direction
+RELAY_TIMEOUT_S = 180   # watchdog of the relayed leg at N > 1 (it has never run on more than one GPU)
 
 
 def parse():
@@ -566,6 +567,75 @@ def main():
         stub.destroy()
         return res
 
+    chunks_main = plan.getPipelineChunks()
+    flops_step = 2 * flops_per_direction(N)
+    ms_per_step = dt / args.steps * 1e3
+    value = flops_step * args.steps / dt / 1e9
+
+    # roofline of the dominant kernel: fft_pass_kernel.  One axis pass (one launch on a single
+    # GPU; `pipeline_chunks` launches when the pass is pipelined against an exchange) reads the
+    # local volume once and writes it once: algorithmic bytes = 2 * esz * N^3 / n_gpus
+    # (SURVEY.md 8d).  Duration = HIP events around the launches on the launch stream.
+    avg_ms = kern_ms / max(kern_launches, 1)
+    achieved = vol_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "dfft::fft_pass_kernel", "avg_launch_ms": round(avg_ms, 4),
+                "launches_timed": kern_launches, "alg_bytes_per_launch": vol_bytes,
+                "launches_per_pass": chunks_main if ngpus > 1 else 1}
+
+    # HBM bytes per launch: NOT measured by this run.  It is the figure of the committed PMC profile of this kernel
+    # on this workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 read correction applied)
+    # The committed figure is only carried if it was measured on THIS library: the profile records the sha256 of the libdfft_amd.so
+    # it ran; a different library loaded here means the figure is stale (traffic stays null, traffic_stale says why).
+    try:
+        import hashlib
+        so = os.path.join(ROOT, "distributedfft_amd", "libdfft_amd.so")
+        sha = hashlib.sha256(open(so, "rb").read()).hexdigest()
+        roofline["library_sha256"] = sha
+        # newest committed PMC run of the headline kernel (tools/pmc_traffic.sh + tools/pmc_traffic.py)
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True)
+        loaded = [(os.path.basename(f), json.load(open(f))) for f in cands]
+        match = [x for x in loaded if x[1].get("library_sha256") == sha]
+        pmc, pm = (match or loaded)[0]      # the profile of THIS library if there is one, else the newest (reported as stale)
+        if ngpus == 1 and N == 1024 and prec == "double" and pm.get("hbm_bytes_per_launch"):
+            roofline["traffic_source"] = f"profiles/{pmc} (a committed rocprofv3 PMC run, not this run)"
+            if pm.get("library_sha256") == sha:
+                roofline["traffic"] = pm["hbm_bytes_per_launch"]
+                roofline["traffic_static"] = True
+            else:
+                roofline["traffic_stale"] = True
+                roofline["traffic_stale_value"] = pm["hbm_bytes_per_launch"]
+                roofline["traffic_stale_why"] = ("the profile was measured on library sha256 %s, this run loaded %s" %
+                                                 (str(pm.get("library_sha256"))[:12], sha[:12]))
+    except Exception:   # noqa: BLE001
+        pass
+
+    rccl_nranks = comm.info()[1] if (comm is not None and hasattr(comm, "info")) else 0
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "3D FFT GFLOP/s (5N^3 log2 N^3 per direction), forward+inverse",
+            "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": ngpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64" if prec == "double" else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{N}^3 {'fp64' if prec == 'double' else 'fp32'} complex forward+inverse",
+                       "decomposition": "single GPU, three local axis passes" if ngpus == 1 else
+                       (f"slab P={P1}" if P2 == 1 else f"pencil {P1}x{P2}"),
+                       "transport": transport, "exchange_ms_per_step": round(exch_ms / args.steps, 3),
+                       "fft_ms_per_step": round(kern_ms / args.steps, 3),
+                       "pipeline_chunks": chunks_main,
+                       # what the transport itself says (ncclCommCount; 0 = the torch transport, ask torch.distributed)
+                       "rccl_nranks": rccl_nranks, "world_size": world, "devices_visible": ndev,
+                       "ranks_per_device": max(1, -(-world // ndev)),
+                       "per_pass": per_pass(phases, args.steps),
+                       "input_aliased_with_inverse_output": bool(aliased), "placement": placement, "variants": variants},
+            "round_trip_rel_linf": rt_err,
+            "roofline": roofline,
+        }
+
     # N = 1: the same plan on the buffers a caller gets from its own allocator (the reference's ownership contract as it stands:
     # cudaMalloc'd in / out, tests/src/pencil/random_dist_3D.cu:197-205) and a hipMalloc work area, no tuner of any kind
     plain_leg = None
@@ -594,6 +664,19 @@ def main():
     relay_leg = None
     want_relay = args.relay if args.relay >= 0 else 1
     if world > 1 and comm is not None and want_relay and (P1 < world and P1 > 1 or (want_relay & 2 and P2 < world and P2 > 1)):
+        # The relay has run on virtual ranks and over gloo only (no lease here has two GPUs).  A collective that hangs cannot be caught
+        # by an exception handler, so a watchdog guards this leg: if it does not finish in time, rank 0 prints the headline line as
+        # measured so far (config.relay says what happened) and every rank leaves; the headline never depends on this leg.
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["config"]["relay"] = {"error": "the relayed run did not finish within %d s: abandoned, the line holds the direct run only" % RELAY_TIMEOUT_S}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(RELAY_TIMEOUT_S, bail)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             comm.setOption("relay", want_relay)
             if aliased:
@@ -615,11 +698,11 @@ def main():
         except Exception as e:   # noqa: BLE001
             relay_leg = {"error": str(e)}
         finally:
+            watchdog.cancel()
             comm.setOption("relay", 0)
 
     # N = 1: the code path of the N > 1 runs on the same grid (mirrored inverse order, 8-chunk segment tables)
     multi_rank_path = None
-    chunks_main = plan.getPipelineChunks()
     free_b, _ = torch.cuda.mem_get_info()
     if ngpus == 1 and not args.no_multi_rank_path and free_b < plan.getWorkSizeDevice() + (2 << 30):
         del plan            # 2048^3 fp32: only one work area fits next to the grid
@@ -691,72 +774,7 @@ def main():
                "links_in_use": {"exchange 1": a2 - 1, "exchange 2": a1 - 1}}
         alt["overlap"] = overlap_report(alt["ms_per_step"], alt["fft_ms_per_step"], alt["exchange_ms_per_step"])
 
-    flops_step = 2 * flops_per_direction(N)
-    ms_per_step = dt / args.steps * 1e3
-    value = flops_step * args.steps / dt / 1e9
-
-    # roofline of the dominant kernel: fft_pass_kernel.  One axis pass (one launch on a single
-    # GPU; `pipeline_chunks` launches when the pass is pipelined against an exchange) reads the
-    # local volume once and writes it once: algorithmic bytes = 2 * esz * N^3 / n_gpus
-    # (SURVEY.md 8d).  Duration = HIP events around the launches on the launch stream.
-    avg_ms = kern_ms / max(kern_launches, 1)
-    achieved = vol_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "dfft::fft_pass_kernel", "avg_launch_ms": round(avg_ms, 4),
-                "launches_timed": kern_launches, "alg_bytes_per_launch": vol_bytes,
-                "launches_per_pass": chunks_main if ngpus > 1 else 1}
-
-    # HBM bytes per launch: NOT measured by this run.  It is the figure of the committed PMC profile of this kernel
-    # on this workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 read correction applied)
-    # The committed figure is only carried if it was measured on THIS library: the profile records the sha256 of the libdfft_amd.so
-    # it ran; a different library loaded here means the figure is stale (traffic stays null, traffic_stale says why).
-    try:
-        import hashlib
-        so = os.path.join(ROOT, "distributedfft_amd", "libdfft_amd.so")
-        sha = hashlib.sha256(open(so, "rb").read()).hexdigest()
-        roofline["library_sha256"] = sha
-        # newest committed PMC run of the headline kernel (tools/pmc_traffic.sh + tools/pmc_traffic.py)
-        import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True)
-        loaded = [(os.path.basename(f), json.load(open(f))) for f in cands]
-        match = [x for x in loaded if x[1].get("library_sha256") == sha]
-        pmc, pm = (match or loaded)[0]      # the profile of THIS library if there is one, else the newest (reported as stale)
-        if ngpus == 1 and N == 1024 and prec == "double" and pm.get("hbm_bytes_per_launch"):
-            roofline["traffic_source"] = f"profiles/{pmc} (a committed rocprofv3 PMC run, not this run)"
-            if pm.get("library_sha256") == sha:
-                roofline["traffic"] = pm["hbm_bytes_per_launch"]
-                roofline["traffic_static"] = True
-            else:
-                roofline["traffic_stale"] = True
-                roofline["traffic_stale_value"] = pm["hbm_bytes_per_launch"]
-                roofline["traffic_stale_why"] = ("the profile was measured on library sha256 %s, this run loaded %s" %
-                                                 (str(pm.get("library_sha256"))[:12], sha[:12]))
-    except Exception:   # noqa: BLE001
-        pass
-
-    rccl_nranks = comm.info()[1] if (comm is not None and hasattr(comm, "info")) else 0
     if rank == 0:
-        out = {
-            "metric": "3D FFT GFLOP/s (5N^3 log2 N^3 per direction), forward+inverse",
-            "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": ngpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64" if prec == "double" else "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{N}^3 {'fp64' if prec == 'double' else 'fp32'} complex forward+inverse",
-                       "decomposition": "single GPU, three local axis passes" if ngpus == 1 else
-                       (f"slab P={P1}" if P2 == 1 else f"pencil {P1}x{P2}"),
-                       "transport": transport, "exchange_ms_per_step": round(exch_ms / args.steps, 3),
-                       "fft_ms_per_step": round(kern_ms / args.steps, 3),
-                       "pipeline_chunks": chunks_main,
-                       # what the transport itself says (ncclCommCount; 0 = the torch transport, ask torch.distributed)
-                       "rccl_nranks": rccl_nranks, "world_size": world, "devices_visible": ndev,
-                       "ranks_per_device": max(1, -(-world // ndev)),
-                       "per_pass": per_pass(phases, args.steps),
-                       "input_aliased_with_inverse_output": bool(aliased), "placement": placement, "variants": variants},
-            "round_trip_rel_linf": rt_err,
-            "roofline": roofline,
-        }
         if plain_leg is not None:
             out["config"]["plain_buffers"] = plain_leg
             out["config"]["plain_buffers_ms_per_step"] = plain_leg["ms_per_step"]

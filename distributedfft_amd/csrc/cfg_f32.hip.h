@@ -79,21 +79,26 @@ using F32_2048_v7 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3, 2, 2>;
 using F32_2048_v2 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 2, 2>;
 using F32_2048_v11 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 2>;
 using F32_2048_v3 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3, 2>;
-using F32_1024_v7 = PassCfg<float, 1024, 16, 16, 1, 16, 8, 8, 1, 1, 1, 3, 2, 2>;      // 64 threads per line x 8 lines
-using F32_1024_v11 = PassCfg<float, 1024, 32, 16, 1, 32, 8, 4, 1, 1, 1, 3, 2, 2>;     // 32 threads per line x 8 lines
-using F32_1024_v3 = PassCfg<float, 1024, 32, 16, 1, 32, 8, 4, 1, 1, 1, 3, 2>;         // whole tiles, 512 threads
-using F32_1024_v2 = PassCfg<float, 1024, 16, 16, 1, 16, 8, 8, 1, 1, 1, 3, 2>;         // whole tiles, 1024 threads
+using F32_2048_v8 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3>;            // the default (whole tiles, 1024 threads) with hints
+// 1024 points, the same role (profiles/r4_f32_1024_inverse_y_whole_lines.txt): 7 = 16 points per thread on sub-tiles of 8 lines (512
+// threads): rank 0 of 2 x 4 at 1024^3 0.614 (variant 6) -> 0.502 ms, one rank with the mirrored inverse 3.95 -> 3.66; 3 = 32 points per
+// thread on whole tiles (512 threads): 0.518 / 3.11 -- a tuner candidate (it wins on the big single-rank grid).  SHIPPED: 7 by rule, 3
+// for dfft_tune_variants.  A/B only: 11 (32 points, sub-tiles: 0.524 / 3.62), 2 (16 points, whole tiles, 1024 threads: 0.622 / 4.01)
+using F32_1024_v7 = PassCfg<float, 1024, 16, 16, 1, 16, 8, 8, 1, 1, 1, 3, 2, 2>;
+using F32_1024_v3 = PassCfg<float, 1024, 32, 16, 1, 32, 8, 4, 1, 1, 1, 3, 2>;
+using F32_1024_v11 = PassCfg<float, 1024, 32, 16, 1, 32, 8, 4, 1, 1, 1, 3, 2, 2>;
+using F32_1024_v2 = PassCfg<float, 1024, 16, 16, 1, 16, 8, 8, 1, 1, 1, 3, 2>;
 #ifdef DFFT_EXPERIMENTS
 #define DFFT_F32_EXP_SMALL(X)
-#define DFFT_F32_EXP_1024(X) X(1024, 10, F32_1024_v10) X(1024, 7, F32_1024_v7) X(1024, 11, F32_1024_v11) X(1024, 3, F32_1024_v3) X(1024, 2, F32_1024_v2)
-#define DFFT_F32_EXP_2048(X) X(2048, 10, F32_2048_v10) X(2048, 12, F32_2048_v12) X(2048, 13, F32_2048_v13) X(2048, 11, F32_2048_v11) X(2048, 3, F32_2048_v3) X(2048, 2, F32_2048_v2)
+#define DFFT_F32_EXP_1024(X) X(1024, 10, F32_1024_v10) X(1024, 11, F32_1024_v11) X(1024, 2, F32_1024_v2)
+#define DFFT_F32_EXP_2048(X) X(2048, 10, F32_2048_v10) X(2048, 12, F32_2048_v12) X(2048, 13, F32_2048_v13) X(2048, 11, F32_2048_v11) X(2048, 3, F32_2048_v3) X(2048, 2, F32_2048_v2) X(2048, 8, F32_2048_v8)
 #else
 #define DFFT_F32_EXP_SMALL(X)
 #define DFFT_F32_EXP_1024(X)
 #define DFFT_F32_EXP_2048(X)
 #endif
 #define DFFT_F32_LIST_SMALL(X) X(512, 6, F32_512_v6) X(512, 9, F32_512_v9) X(512, 4, F32_512_v4) X(512, 5, F32_512_v5) X(2, 0, F32_2) X(4, 0, F32_4) X(8, 0, F32_8) X(16, 0, F32_16) X(32, 0, F32_32) X(64, 0, F32_64) X(128, 0, F32_128) X(256, 0, F32_256) X(512, 0, F32_512) DFFT_F32_EXP_SMALL(X)
-#define DFFT_F32_LIST_1024(X) X(1024, 4, F32_1024_v4) X(1024, 5, F32_1024_v5) X(1024, 6, F32_1024_v6) X(1024, 9, F32_1024_v9) X(1024, 0, F32_1024) DFFT_F32_EXP_1024(X)
+#define DFFT_F32_LIST_1024(X) X(1024, 4, F32_1024_v4) X(1024, 5, F32_1024_v5) X(1024, 6, F32_1024_v6) X(1024, 9, F32_1024_v9) X(1024, 7, F32_1024_v7) X(1024, 3, F32_1024_v3) X(1024, 0, F32_1024) DFFT_F32_EXP_1024(X)
 #define DFFT_F32_LIST_2048(X) X(2048, 4, F32_2048_v4) X(2048, 5, F32_2048_v5) X(2048, 6, F32_2048_v6) X(2048, 9, F32_2048_v9) X(2048, 7, F32_2048_v7) X(2048, 14, F32_2048_v14) X(2048, 15, F32_2048_v15) X(2048, 0, F32_2048) X(4096, 0, F32_4096) X(8192, 0, F32_8192) DFFT_F32_EXP_2048(X)
 
 // lengths with a packed real z pass / a Bluestein inner transform of their own configuration

@@ -2531,7 +2531,7 @@ static int tune_variants(dfft_plan *p, const void *in, void *o, void *b, float &
     // (-DDFFT_EXPERIMENTS) carries further configuration numbers that are measured by hand, never picked here
     auto validated = [&](int v) {
         if (p->prec == DFFT_F64) return (v >= 0 && v <= 3) || v == 7 || v == 8;
-        return v == 0 || (v >= 4 && v <= 7) || v == 9 || v == 14 || v == 15;
+        return v == 0 || (v >= 3 && v <= 7) || v == 9 || v == 14 || v == 15;
     };
     for (int v = 0; v < 16; v++) {
         if (!validated(v)) continue;

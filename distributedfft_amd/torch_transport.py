@@ -65,19 +65,29 @@ class TorchComm:
 
     def _p2p(self, send, sc, sd, recv, rc, rd, group, me, pg):
         """peer blocks that are not laid out back to back (the relay's pieces): one send / receive per peer"""
-        ops = []
+        ops, landed = [], []
+        # gloo moves device tensors in its collectives but not in point-to-point operations: stage those through the host
+        stage = bool(self.buffers and self.buffers[0].is_cuda) and self.dist.get_backend(pg) == "gloo"
         for q, peer in enumerate(group):
             if q == me:
                 if rc[q]:
                     self._slice(recv + rd[q], rc[q]).copy_(self._slice(send + sd[q], sc[q]))
                 continue
             if sc[q]:
-                ops.append(self.dist.P2POp(self.dist.isend, self._slice(send + sd[q], sc[q]), peer, group=pg))
+                t = self._slice(send + sd[q], sc[q])
+                ops.append(self.dist.P2POp(self.dist.isend, t.cpu() if stage else t, peer, group=pg))
             if rc[q]:
-                ops.append(self.dist.P2POp(self.dist.irecv, self._slice(recv + rd[q], rc[q]), peer, group=pg))
+                t = self._slice(recv + rd[q], rc[q])
+                if stage:
+                    h = torch.empty(rc[q], dtype=torch.uint8)
+                    landed.append((t, h))
+                    t = h
+                ops.append(self.dist.P2POp(self.dist.irecv, t, peer, group=pg))
         if ops:
             for req in self.dist.batch_isend_irecv(ops):
                 req.wait()
+        for t, h in landed:
+            t.copy_(h)
         self.p2p_calls += 1
 
     def _alltoallv(self, send, sc, sd, recv, rc, rd, group, me, stream):
