@@ -115,6 +115,13 @@ class TorchComm:
         self.calls += 1
 
     # duck-typing so a TorchComm can be passed wherever a Comm is expected
+    def setOption(self, key, value):
+        """transport knobs of the communicator underneath (e.g. 'relay', include/dfft_c.h: dfft_comm_set_option)"""
+        self.comm.setOption(key, value)
+
+    def info(self):
+        return self.comm.info()
+
     @property
     def _h(self):
         return self.comm._h

@@ -91,7 +91,7 @@ def main():
     tc = TorchComm(dist, rank, world, P1, P2)
     relay = int(os.environ.get("DFFT_TEST_RELAY", "0"))
     if relay:       # two-hop relay of the group exchanges (include/dfft_c.h: dfft_comm_set_option "relay")
-        tc.comm.setOption("relay", relay)
+        tc.setOption("relay", relay)
     plan = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), tc, precision="double", rank=rank)
     plan.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(P1, P2), allocate=False, c2c=True)
     assert plan.getRank() == rank and plan.getWorldSize() == world

@@ -418,6 +418,13 @@ def test_bench_multi_rank_line_is_self_documenting(nproc, want, alt):
     for m in per.values():
         assert abs(m["bytes_per_link"] - vol / m["group_ranks"]) < 1
     assert "hidden_frac" in line["overlap"] and line["overlap"]["step_ms"] == line["ms_per_step"]
+    if alt:      # pencil grids: the same plan with the two-hop relay on exchange 2, measured next to the direct run
+        rl = line["config"]["relay"]
+        assert "error" not in rl, rl
+        assert rl["relay"] == 1 and rl["round_trip_rel_linf"] < 1e-10 and rl["ms_per_step"] > 0
+        assert per["exchange 2"]["relay"]["links"] == nproc - 1 and per["exchange 2"]["relay"]["predicted_ms"] < per["exchange 2"]["predicted_ms"]
+    else:
+        assert "relay" not in line["config"]
 
 
 def test_bench_single_gpu_line_carries_the_8gpu_kernels():
