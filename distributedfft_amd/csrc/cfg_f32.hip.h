@@ -79,7 +79,9 @@ using F32_2048_v7 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3, 2, 2>;
 using F32_2048_v2 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 2, 2>;
 using F32_2048_v11 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 0, 2>;
 using F32_2048_v3 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3, 2>;
-using F32_2048_v8 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3>;            // the default (whole tiles, 1024 threads) with hints
+// (the default -- whole tiles, 32 points per thread, 1024 threads -- with hints: y 4.58, x 3.98, x^-1 4.58 ms against 3.93 / 4.03 / 4.55
+// for 9: nothing, profiles/r4_f32_2048_whole_tiles_32_hints.txt)
+using F32_2048_v8 = PassCfg<float, 2048, 32, 16, 1, 32, 8, 8, 1, 1, 1, 3>;
 // 1024 points, the same role (profiles/r4_f32_1024_inverse_y_whole_lines.txt): 7 = 16 points per thread on sub-tiles of 8 lines (512
 // threads): rank 0 of 2 x 4 at 1024^3 0.614 (variant 6) -> 0.502 ms, one rank with the mirrored inverse 3.95 -> 3.66; 3 = 32 points per
 // thread on whole tiles (512 threads): 0.518 / 3.11 -- a tuner candidate (it wins on the big single-rank grid).  SHIPPED: 7 by rule, 3

@@ -26,7 +26,7 @@ FORCED = [4, 6, 8, 9, 15, 16, 21, 64, 100, 121, 256, 1000, 1024, 1155, 2048, 300
 LONG = [4098, 5000, 6000, 9999, 10000, 12288, 16384, 20000, 65536, 3 * 4093, 100000, 131072]
 
 
-def fft1d_case(N, prec, variant, batch):
+def fft1d_case(N, prec, variant, batch, big_prime=False):
     rng = np.random.default_rng(N)
     x = (rng.uniform(0, 255, (batch, N)) + 1j * rng.uniform(0, 255, (batch, N))).astype(NPDT[prec])
     d_in = torch.from_numpy(x).cuda()
@@ -36,11 +36,13 @@ def fft1d_case(N, prec, variant, batch):
         torch.cuda.synchronize()
         dfft.fft1d_batched(d_out, d_in, N, batch, direction, prec, variant=variant)
         torch.cuda.synchronize()
-        want = orc.fft1d(x.astype(np.complex128), direction)
+        ref = np.fft.fft(x.astype(np.complex128), axis=-1) if direction == dfft.FORWARD else np.fft.ifft(x.astype(np.complex128), axis=-1) * N
+        if big_prime:      # the oracle transforms a prime length as an O(N^2) sum (65537 points: 25 s per case): pocketfft alone here
+            want = ref
+        else:
+            want = orc.fft1d(x.astype(np.complex128), direction)
+            assert rel(want, ref) < 1e-12      # independent cross-check of the oracle itself on these lengths
         assert rel(d_out.cpu().numpy(), want) < (2e-11 if prec == "double" else 2e-4) * grow
-        # independent cross-check of the oracle itself on these lengths
-        assert rel(want, np.fft.fft(x.astype(np.complex128), axis=-1) if direction == dfft.FORWARD
-                   else np.fft.ifft(x.astype(np.complex128), axis=-1) * N) < 1e-12
     assert np.array_equal(d_in.cpu().numpy(), x), "the pass must not modify its input"
 
 
@@ -70,7 +72,7 @@ def test_fft1d_long_bluestein_lines_vs_oracle(N, prec):
     lines themselves (four launches of the generic kernel, dfft.hip launch_long_bluestein).  The reference takes such sizes through
     cuFFT like any other (mpicufft_pencil_opt1.cpp:165-197)."""
     assert dfft.axis_plan_info(N, prec)["kind"] == "long_bluestein"
-    fft1d_case(N, prec, 0, 7 if N < 20000 else 3)
+    fft1d_case(N, prec, 0, 7 if N < 20000 else 3, big_prime=N > 20000)
 
 
 def test_every_length_has_a_plan_and_absurd_ones_fail_loudly():
