@@ -402,8 +402,10 @@ def test_bench_multi_rank_line_is_self_documenting(nproc, want, alt):
     """`bench.py --gpus N --backend gloo` with the N ranks sharing this GPU: the headline decomposition is the one
     BASELINE.json names, slab over all ranks is config.alt, and the line carries the xGMI model (bytes per link / 153 GB/s
     next to the measured exchange spans) and overlap.hidden_frac"""
-    line = _bench(["--gpus", str(nproc), "--backend", "gloo", "--size", "128", "--steps", "2", "--warmup", "1"], nproc=nproc,
-                  port=29671 + nproc)
+    # (4 ranks: the relayed run is made the headline whatever its time, to exercise that branch: on ranks that share one GPU over
+    # gloo it is never the faster one)
+    line = _bench(["--gpus", str(nproc), "--backend", "gloo", "--size", "128", "--steps", "2", "--warmup", "1"] + (["--prefer-relay"] if nproc == 4 else []),
+                  nproc=nproc, port=29671 + nproc)
     assert line["n_gpus"] == nproc and line["round_trip_rel_linf"] < 1e-10
     assert line["config"]["decomposition"] == want
     if alt:
@@ -421,7 +423,12 @@ def test_bench_multi_rank_line_is_self_documenting(nproc, want, alt):
     if alt:      # pencil grids: the same plan with the two-hop relay on exchange 2, measured next to the direct run
         rl = line["config"]["relay"]
         assert "error" not in rl, rl
-        assert rl["relay"] == 1 and rl["round_trip_rel_linf"] < 1e-10 and rl["ms_per_step"] > 0
+        assert rl["relay"] == 3 and rl["round_trip_rel_linf"] < 1e-10 and rl["ms_per_step"] > 0
+        if nproc == 4:
+            assert rl["headline"] and line["ms_per_step"] == rl["ms_per_step"] and "relay" in line["config"]["transport"]
+            assert line["config"]["direct"]["ms_per_step"] > 0 and line["config"]["direct"]["round_trip_rel_linf"] < 1e-10
+        elif not rl.get("headline"):
+            assert "direct" not in line["config"]
         assert per["exchange 2"]["relay"]["links"] == nproc - 1 and per["exchange 2"]["relay"]["predicted_ms"] < per["exchange 2"]["predicted_ms"]
     else:
         assert "relay" not in line["config"]
