@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -170,6 +171,9 @@ public:
                 staged_ = new DfftHostStagedMPI(world);
                 check(dfft_comm_create_callback(pcnt, pidx, &DfftHostStagedMPI::alltoallv, staged_, &comm_));
             }
+            // transport knob without a counterpart in Configurations: DFFT_RELAY = 1 | 2 | 3 routes the group exchanges of pencil
+            // grids through the two-hop relay (include/dfft_c.h: dfft_comm_set_option "relay"; every rank must see the same value)
+            if (const char *rl = getenv("DFFT_RELAY")) check(dfft_comm_set_option(comm_, "relay", atol(rl)));
         }
         dfft_config c{config.cuda_aware, config.warmup_rounds, (int)config.comm_method, (int)config.send_method,
                       (int)config.comm_method2, (int)config.send_method2};

@@ -55,6 +55,21 @@ def test_cpp_shim_mpi_ranks_sharing_the_gpu(tmp_path, P1, P2, mode):
 
 
 @needs_mpich
+@pytest.mark.parametrize("P1,P2,relay", [(2, 2, 3), (3, 2, 1), (2, 3, 3)])
+def test_cpp_shim_mpi_ranks_with_the_relay(tmp_path, P1, P2, relay):
+    """the same through the two-hop relay (DFFT_RELAY in the shim -> dfft_comm_set_option "relay"): the host-staged MPI transport
+    then runs world-wide all-to-alls of message parts; round trip and DC term as before"""
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not os.path.exists(mpiexec):
+        pytest.skip("no mpiexec")
+    exe, env = build(tmp_path, "shim_mpi_multirank.cpp")
+    out = subprocess.run([mpiexec, "-n", str(P1 * P2), str(exe), str(P1), str(P2)], env=dict(env, DFFT_RELAY=str(relay)), capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert f"ranks {P1 * P2} grid {P1}x{P2}" in out.stdout
+
+
+@needs_mpich
 @pytest.mark.parametrize("kind,opt,P1,P2,nranks,fft_ranks", [
     ("pencil", 1, 3, 2, 6, 6), ("pencil", 0, 2, 2, 4, 4), ("slab", 1, 5, 1, 5, 5), ("slab", 0, 2, 1, 2, 2),
     ("pencil", 1, 1, 1, 1, 1),
