@@ -143,6 +143,9 @@ static int dry_exchange(void *, const void *, const size_t *, const size_t *, vo
     return 0;
 }
 
+// --vmm-spread K (A/B, round 4): K times as many physical chunks are created as the buffer needs and every K-th is kept, the others
+// released -- whatever the allocator hands out in a row, the buffer's chunks are not physical neighbours
+static int g_vmm_spread = 1;
 static char *vmm_alloc(size_t bytes, size_t chunk, bool shuffle)
 {
     hipMemAllocationProp prop = {};
@@ -154,6 +157,14 @@ static char *vmm_alloc(size_t bytes, size_t chunk, bool shuffle)
     HIPCHK(hipMemAddressReserve(&va, bytes, chunk, nullptr, 0));
     const size_t n = bytes / chunk;
     std::vector<hipMemGenericAllocationHandle_t> h(n);
+    if (g_vmm_spread > 1) {
+        std::vector<hipMemGenericAllocationHandle_t> all(n * g_vmm_spread);
+        for (size_t i = 0; i < all.size(); i++) HIPCHK(hipMemCreate(&all[i], chunk, &prop, 0));
+        for (size_t i = 0; i < all.size(); i++) {
+            if (i % g_vmm_spread == 0) h[i / g_vmm_spread] = all[i];
+            else HIPCHK(hipMemRelease(all[i]));
+        }
+    } else
     for (size_t i = 0; i < n; i++) HIPCHK(hipMemCreate(&h[i], chunk, &prop, 0));
     std::vector<size_t> order(n);
     for (size_t i = 0; i < n; i++) order[i] = i;
@@ -198,6 +209,7 @@ static Args parse(int argc, char **argv)
         else if (k == "--perm") { a.slab = 1; a.perm = next(); }
         else if (k == "--vmm") a.vmm_mib = (size_t)atoll(next());
         else if (k == "--shuffle") a.shuffle = 1;
+        else if (k == "--vmm-spread") g_vmm_spread = atoi(next());
         else if (k == "--ranks") { if (sscanf(next(), "%dx%d", &a.P1, &a.P2) != 2) { fprintf(stderr, "--ranks P1xP2\n"); exit(1); } }
         else if (k == "--rank") a.rank = atoi(next());
         else if (k == "--tune") a.tune = atoi(next());
