@@ -71,7 +71,8 @@ def parse():
     ap.add_argument("--cpu-n", type=int, default=0, help="cube edge of the CPU-baseline sample (0 = 1024 if RAM allows, else 512)")
     ap.add_argument("--tune-placement", type=int, default=-1,
                     help="physical backings tried per buffer (work area, out, back) before the warm-up: dfft_tune_placement keeps the one "
-                         "the plan's own passes run fastest on.  -1 = 6 on one GPU, off otherwise; 0 / 1 = plain allocations")
+                         "the plan's own passes run fastest on.  Default off: buffers come from the library's default backing, which probes its own "
+                         "candidates at allocation (dfft_malloc(DFFT_CHUNK_DEFAULT)); --plain-buffers for the caller's plain allocator")
     ap.add_argument("--plain-buffers", action="store_true",
                     help="the reference's ownership contract as it stands: out / back from the caller's plain allocator (torch / hipMalloc) "
                          "and a hipMalloc work area, no tuner (the N = 1 line carries this figure anyway: config.plain_buffers)")
@@ -388,7 +389,9 @@ def main():
     # Placement: the passes that scatter 128-byte runs depend on the physical backing of the buffer they write
     # to.  Before the warm-up the plan tries a few backings for its work area and for out / back (virtual-memory API, chunks
     # of different sizes) and keeps the fastest; that needs room for two candidates of a buffer at a time.
-    tries = args.tune_placement if args.tune_placement >= 0 else (6 if world == 1 else 0)
+    # (round 4: the library's default backing probes its own candidates -- local, 0-5 s, csrc/dfft.hip dev_alloc_default -- and lands
+    # in the same range as the plan-level search, so that search is no longer the default; --tune-placement 6 brings it back)
+    tries = args.tune_placement if args.tune_placement >= 0 else 0
     if args.plain_buffers:
         tries = 0
     placement = None
@@ -402,11 +405,14 @@ def main():
                              "back one at a time on other physical backings; a candidate is kept when the plan's own passes run faster on it",
                      "seconds": round(time.perf_counter() - t_tune, 2)}
     else:
+        t_alloc = time.perf_counter()
         d_out = lib_buffer(domain, cdt)
         d_back = d_in if aliased else lib_buffer(n_in * esz, cdt)
-        placement = {"tries_per_buffer": 0, "what": "no search: out / back from the caller's plain allocator, hipMalloc work area (--plain-buffers)"
-                     if args.plain_buffers else "no search: out / back from dfft_malloc(DFFT_CHUNK_DEFAULT) and the library-owned work area on the "
-                     "same default backing (virtual-memory API, 1 GiB physical chunks)"}
+        t_alloc = time.perf_counter() - t_alloc
+        placement = {"tries_per_buffer": 0, "alloc_seconds_out_and_back": round(t_alloc, 2), "what": "no search: out / back from the caller's plain allocator, hipMalloc work area (--plain-buffers)"
+                     if args.plain_buffers else "no plan-level search: out / back from dfft_malloc(DFFT_CHUNK_DEFAULT) and the library-owned work area on the "
+                     "same default backing (virtual-memory API, 1 GiB physical chunks; buffers of 1 GiB and more: "
+                     "probed with a streaming write, up to 6 candidates, the fastest kept -- local to the device, csrc/dfft.hip dev_alloc_default)"}
     if comm is not None and transport == "torch":
         comm.register(d_out)
     torch.cuda.synchronize()

@@ -1579,14 +1579,72 @@ static size_t default_chunk_mib()
     }();
     return v;
 }
-static int dev_alloc_default(size_t bytes, void **out)
+static int dev_alloc_recipe(size_t bytes, void **out)
 {
-    if (bytes < ((size_t)32 << 20)) return dev_alloc(bytes, 0, out);      // small buffers live in the caches: nothing to place
     for (size_t c = default_chunk_mib(); c >= 2; c /= 8) {
         if (dev_alloc(bytes, c, out) == 0) return 0;
         (void)hipGetLastError();
     }
     return dev_alloc(bytes, 0, out);
+}
+
+// Streaming-write rate of a buffer in bytes per second (best of two passes after a warm-up pass).  It is the cheapest thing that
+// tells a good target of the scatter passes from a bad one: ten 16 GiB buffers from the same recipe in one process streamed
+// writes at 6.5 TB/s (three of them) or 5.2 TB/s (seven), and the plan's x pass ran 5.63-5.66 ms on exactly the former and
+// 6.47-6.55 ms on the latter (tools/placeprobe.hip, profiles/r4_placement_probe.txt).  Local to the device: no plan, no collective.
+__global__ __launch_bounds__(512) void placement_probe_kernel(double2 *d, size_t n)
+{
+    const double2 v = make_double2(1.0, 2.0);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = v;
+}
+static double placement_probe(void *buf, size_t bytes)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) (void)hipEventDestroy(e0); return 0.0; }
+    float best = 0;
+    for (int r = 0; r < 3; r++) {
+        float ms = 0;
+        (void)hipEventRecord(e0, nullptr);
+        hipLaunchKernelGGL(placement_probe_kernel, dim3(4096), dim3(512), 0, nullptr, static_cast<double2 *>(buf), bytes / sizeof(double2));
+        (void)hipEventRecord(e1, nullptr);
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { best = 0; break; }
+        if (r && (best == 0 || ms < best)) best = ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipGetLastError();
+    return best > 0 ? (double)bytes / (best * 1e-3) : 0.0;
+}
+
+// Default backing with a placement probe: buffers of 1 GiB and more are allocated up to DFFT_PLACEMENT_TRIES (default 6) times --
+// every candidate stays alive while the next is tried: a freed candidate's physical pages would simply be handed out again --, each
+// is probed (3 streaming passes: 8 ms for 16 GiB) and the fastest is kept; a candidate above 5.9 TB/s ends the search at once.
+// Purely local: every rank of a multi-rank plan does it by itself.  DFFT_PLACEMENT_TRIES=1 switches the probe off.
+// Measured (1024^3 fp64, fresh processes after 64 GiB buffers had come and gone, no plan-level search: profiles/bench_r4_c_probe_*.json):
+// 34.05 / 33.70 / 33.89 / 34.44 ms per forward + inverse -- the range of dfft_tune_placement's 8-12 s search (33.3-34.4) -- for 0.03 s
+// (first candidates good) to 5 s (four candidates per buffer; releasing 16 GiB takes longer than creating them).
+static int dev_alloc_default(size_t bytes, void **out)
+{
+    if (bytes < ((size_t)32 << 20)) return dev_alloc(bytes, 0, out);      // small buffers live in the caches: nothing to place
+    static const int tries = [] { const char *e = getenv("DFFT_PLACEMENT_TRIES"); const int v = e ? atoi(e) : 6; return v < 1 ? 1 : v > 16 ? 16 : v; }();
+    if (bytes < ((size_t)1 << 30) || tries == 1 || default_chunk_mib() == 0) return dev_alloc_recipe(bytes, out);
+    void *best = nullptr;
+    double best_rate = -1.0;
+    std::vector<void *> losers;
+    for (int t = 0; t < tries; t++) {
+        if (t) {      // room for one more candidate next to what is alive?
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)2 << 30)) break;
+        }
+        void *cand = nullptr;
+        if (const int rc = dev_alloc_recipe(bytes, &cand)) { if (!best) return rc; break; }
+        const double rate = placement_probe(cand, bytes);
+        if (rate > best_rate) { if (best) losers.push_back(best); best = cand; best_rate = rate; }
+        else losers.push_back(cand);
+        if (rate == 0.0 || rate >= 5.9e12) break;      // (no probe possible: take what we have) / a good one
+    }
+    for (void *l : losers) (void)dev_free(l);
+    *out = best;
+    return 0;
 }
 
 static int check_ready(dfft_plan *p)

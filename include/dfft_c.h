@@ -299,16 +299,16 @@ int dfft_axis_plan_info(int precision, size_t N, int two_level, size_t info[8]);
  * The passes that write 128-byte runs (y, x) run 5-10 % faster or slower depending on the PHYSICAL backing of the
  * buffer they scatter to -- per buffer, for the life of the allocation (profiles/r3_placement.txt).
  * dfft_malloc: chunk_mib = 0 is hipMalloc; otherwise one virtual range backed by physical allocations of chunk_mib MiB
- * each (HIP virtual-memory API).  chunk_mib = DFFT_CHUNK_DEFAULT: the library's default backing -- 1 GiB chunks, smaller
- * ones and finally hipMalloc if that fails -- which is also what the library uses for a work area it owns
- * (dfft_init(allocate = 1), dfft_set_work_area(plan, NULL, NULL)).  What a caller gets by allocating `out` (and the inverse's
- * output) this way, measured over 30 fresh processes at 1024^3 fp64 (profiles/r4_fixed_recipes.txt, r4_placement_shuffle.txt):
- * 34.2 - 36.0 ms per forward + inverse in most of them, 37 ms -- as slow as hipMalloc buffers, which are 36.9 - 37.5 always --
- * in some (right after very large buffers were freed); dfft_tune_placement's search finds 33.6 - 34.4 reliably.  The backing
- * improves the average, only the search guarantees the result: which physical pages a buffer gets is what matters, and no
- * recipe (chunk size, shuffled mapping order) was found that controls it.  Environment DFFT_DEFAULT_CHUNK_MIB overrides the
- * default (0 = hipMalloc).  Free with dfft_free (which also takes pointers it did not allocate: hipFree; it synchronises the
- * device first, like hipFree). */
+ * each (HIP virtual-memory API).  chunk_mib = DFFT_CHUNK_DEFAULT: the library's default backing, which is also what the library
+ * uses for a work area it owns (dfft_init(allocate = 1), dfft_set_work_area(plan, NULL, NULL)): 1 GiB chunks (smaller ones and
+ * finally hipMalloc if that fails) and, for buffers of 1 GiB and more, a PLACEMENT PROBE -- up to DFFT_PLACEMENT_TRIES (6)
+ * candidates are allocated, all alive, a streaming write is timed on each (8 ms per 16 GiB), the first above 5.9 TB/s or else
+ * the fastest is kept.  A good scatter target streams writes at 6.5 TB/s, a bad one at 5.2 TB/s, and the plan's scatter passes
+ * follow (5.65 vs 6.5 ms per pass at 1024^3 fp64; hipMalloc buffers are always the bad kind): profiles/r4_placement_probe.txt.
+ * 1024^3 fp64 forward + inverse on buffers from this call: 33.7 - 34.4 ms, on hipMalloc buffers 37.6.  Local to the device (no
+ * plan, no collective): safe on every rank of a multi-rank job.  Costs 0.03 - 5 s per 16 GiB buffer.  Environment:
+ * DFFT_DEFAULT_CHUNK_MIB (0 = hipMalloc), DFFT_PLACEMENT_TRIES (1 = no probe).  Free with dfft_free (which also takes
+ * pointers it did not allocate: hipFree; it synchronises the device first, like hipFree). */
 #define DFFT_CHUNK_DEFAULT ((size_t)-1)
 int dfft_malloc(size_t bytes, size_t chunk_mib, void **ptr);
 int dfft_free(void *ptr);
