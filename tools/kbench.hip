@@ -136,6 +136,7 @@ struct Args {
     int tune = 0;
     // --tune-variants: dfft_tune_variants on the run's buffers before the timed iterations
     int tune_variants = 0;
+    int lib_buffers = 0;
 };
 
 static int dry_exchange(void *, const void *, const size_t *, const size_t *, void *, const size_t *, const size_t *, const int *, int, int, void *)
@@ -214,6 +215,7 @@ static Args parse(int argc, char **argv)
         else if (k == "--rank") a.rank = atoi(next());
         else if (k == "--tune") a.tune = atoi(next());
         else if (k == "--tune-variants") a.tune_variants = 1;
+        else if (k == "--lib-buffers") a.lib_buffers = 1;
         else if (k == "--sweep") {
             std::string all = next();
             size_t pos = 0;
@@ -355,12 +357,16 @@ template <typename R> static int run_plan(const Args &a)
         for (int i = 0; i < nrep; i++) printf(" %.3f", rep[i]);
         printf("\n");
     } else {
+        // --lib-buffers: out / back from the library's allocator (dfft_malloc(DFFT_CHUNK_DEFAULT): probed candidates), what a drop-in
+        // caller is advised to use; default: plain hipMalloc, the reference's contract as it stands
         HIPCHK(hipMalloc(&in, in_bytes));
-        HIPCHK(hipMalloc(&out, dom));
+        if (a.lib_buffers) DCHK(dfft_malloc(dom, DFFT_CHUNK_DEFAULT, (void **)&out)); else HIPCHK(hipMalloc(&out, dom));
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         alias_back = free_b < in_bytes + (1ull << 30);       // 2048^3: the inverse writes over the input buffer
-        if (!alias_back) HIPCHK(hipMalloc(&back, in_bytes)); else back = in;
+        if (alias_back) back = in;
+        else if (a.lib_buffers) DCHK(dfft_malloc(in_bytes, DFFT_CHUNK_DEFAULT, (void **)&back));
+        else HIPCHK(hipMalloc(&back, in_bytes));
     }
     if (!part) HIPCHK(hipMalloc(&part, nblk * sizeof(double)));
     const size_t nreal = in_bytes / sizeof(R);
@@ -441,6 +447,7 @@ template <typename R> static int run_plan(const Args &a)
     for (auto &kv : sets[si]) optstr += " " + kv.first + "=" + std::to_string(kv.second);
     if (sweeping) optstr += " [set " + std::to_string(si) + ", shared buffers]";
     if (a.vmm_mib) optstr += " vmm=" + std::to_string(a.vmm_mib) + "MiB" + (a.shuffle ? " shuffled" : "");
+    if (a.lib_buffers) optstr += " library buffers";
     if (a.tune > 1) optstr += " tuned placement (" + std::to_string(a.tune) + ")";
     if (a.slab) optstr += " slab perm=" + a.perm + " delta=" + std::to_string(a.delta);
     if (nranks > 1) optstr += " rank " + std::to_string(a.rank) + " of " + std::to_string(a.P1) + "x" + std::to_string(a.P2) + " (exchange stubbed), chunks=" + std::to_string(dfft_get_pipeline_chunks(plan));
@@ -469,8 +476,8 @@ template <typename R> static int run_plan(const Args &a)
     else if (a.vmm_mib) { /* process exit unmaps */ }
     else if (a.tune > 1) { HIPCHK(hipFree(in)); DCHK(dfft_free(out)); DCHK(dfft_free(back)); }
     else {
-        HIPCHK(hipFree(in)); HIPCHK(hipFree(out));
-        if (!alias_back) HIPCHK(hipFree(back));
+        HIPCHK(hipFree(in)); DCHK(dfft_free(out));
+        if (!alias_back) DCHK(dfft_free(back));
     }
     HIPCHK(hipFree(part));
     return 0;
