@@ -468,3 +468,21 @@ def test_comm_options_and_variant_range():
     plan.setOption("variant_fy", 15)
     plan.setOption("uniform_tables", 0)
     assert plan.getOption("uniform_tables") == 0
+
+
+def test_bench_xgmi_model_with_the_relay():
+    """bench.py's model of the exchanges (bytes per link / 153 GB/s) and of their two-hop relay: C4 = 1024^3 fp64 on pencil 2 x 4 --
+    exchange 2 moves 1 GiB over ONE link (7.0 ms) or, relayed, 2 x 1/8 GiB over each of seven (1.75 ms); exchange 1 3.5 -> 2.6 ms;
+    a slab exchange spans the world: nothing to relay through"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    m = bench.xgmi_model(16, 1024, 8, 2, 4)
+    assert m["exchange 2"]["links"] == 1 and abs(m["exchange 2"]["predicted_ms"] - 7.018) < 0.01
+    assert m["exchange 2"]["relay"] == {"links": 7, "phases": 2, "bytes_per_link_per_phase": 2 ** 27, "predicted_ms": 1.754}
+    assert m["exchange 1"]["links"] == 3 and abs(m["exchange 1"]["predicted_ms"] - 3.509) < 0.01
+    assert m["exchange 1"]["relay"]["phases"] == 6 and abs(m["exchange 1"]["relay"]["predicted_ms"] - 2.632) < 0.01
+    s = bench.xgmi_model(16, 1024, 8, 8, 1)
+    assert list(s) == ["exchange 2"] and "relay" not in s["exchange 2"] and s["exchange 2"]["links"] == 7
+    assert bench.choose_partition(8, "auto") == (2, 4) and bench.choose_partition(4, "auto") == (2, 2) and bench.choose_partition(2, "auto") == (2, 1)

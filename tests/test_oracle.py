@@ -171,3 +171,14 @@ def test_mpi_form_of_the_pencil_path_matches_the_oracle(shape, P1, P2):
     scale = want[2]
     for got, ref in zip(r["checksum"], want):
         assert abs(got - ref) / scale < 1e-12, (r["checksum"], want)
+
+
+def test_usable_cores_and_thread_control():
+    """bench.py sizes its CPU legs by the CPUs the job's cgroup grants (the GPU boxes: 256 cores, cpu.max = 16)"""
+    n = orc.usable_cores()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    before = orc.num_threads()
+    orc.set_num_threads(1)
+    assert orc.num_threads() == 1
+    orc.set_num_threads(before)
+    assert orc.num_threads() == before
