@@ -13,6 +13,13 @@ __global__ __launch_bounds__(512) void wr(v2d *d, size_t n)
     v2d v; v.x = 1.0; v.y = 2.0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = v;
 }
+__global__ __launch_bounds__(512) void wr_group(v2d **tab, int G, size_t n)
+{
+    v2d v; v.x = 1.0; v.y = 2.0;
+    v2d *d = tab[blockIdx.x % G];
+    const size_t wg = blockIdx.x / G, nwg = gridDim.x / G;
+    for (size_t i = wg * (size_t)blockDim.x + threadIdx.x; i < n; i += nwg * blockDim.x) d[i] = v;
+}
 __global__ __launch_bounds__(512) void rd(const v2d *d, size_t n, double *sink)
 {
     double s = 0;
@@ -53,5 +60,26 @@ int main(int argc, char **argv)
         printf("%3zu  %5.2f  %5.2f%s", k, chunk / bw / 1e9, chunk / br / 1e9, (k % 4 == 3) ? "\n" : "   |  ");
     }
     printf("\n");
+    // pairs / groups of chunks written at the same time (workgroup w writes chunk w % G): does spreading the write front over distant
+    // physical chunks lift the rate above what one contiguous chunk gives?
+    if (va.size() >= 200) {
+        v2d **tab; HIPCHK(hipMalloc(&tab, 64 * sizeof(v2d *)));
+        const int dist[] = {1, 2, 8, 32, 64, 128};
+        for (int G : {2, 4, 16}) {
+            for (int d : dist) {
+                if ((size_t)(G - 1) * d + 1 > va.size()) continue;
+                std::vector<v2d *> h(G);
+                for (int g = 0; g < G; g++) h[g] = (v2d *)va[(size_t)g * d];
+                HIPCHK(hipMemcpy(tab, h.data(), G * sizeof(v2d *), hipMemcpyHostToDevice));
+                float best = 1e30f;
+                for (int r = 0; r < 4; r++) {
+                    float ms;
+                    HIPCHK(hipEventRecord(e0)); hipLaunchKernelGGL(wr_group, dim3(4096), dim3(512), 0, 0, tab, G, n); HIPCHK(hipEventRecord(e1)); HIPCHK(hipEventSynchronize(e1));
+                    HIPCHK(hipEventElapsedTime(&ms, e0, e1)); if (r && ms < best) best = ms;
+                }
+                printf("write %2d chunks at once, %3d chunks apart: %5.2f TB/s\n", G, d, (double)G * chunk / best / 1e9);
+            }
+        }
+    }
     return 0;
 }
