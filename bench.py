@@ -677,9 +677,9 @@ def main():
         # measured so far (config.relay says what happened) and every rank leaves; the headline never depends on this leg.
         import threading
 
-        def bail():
+        def bail(why=None):
             if rank == 0:
-                out["config"]["relay"] = {"error": "the relayed run did not finish within %d s: abandoned, the line holds the direct run only" % RELAY_TIMEOUT_S}
+                out["config"]["relay"] = {"error": why or "the relayed run did not finish within %d s: abandoned, the line holds the direct run only" % RELAY_TIMEOUT_S}
                 print(json.dumps(out), flush=True)
             os._exit(0)
         watchdog = threading.Timer(RELAY_TIMEOUT_S, bail)
@@ -704,7 +704,9 @@ def main():
             relay_leg["overlap"] = overlap_report(relay_leg["ms_per_step"], sum(ms for n_, ms in phr.items() if "FFT" in n_) / args.steps,
                                                   sum(ms for n_, ms in phr.items() if "FFT" not in n_) / args.steps)
         except Exception as e:   # noqa: BLE001
-            relay_leg = {"error": str(e)}
+            # a failure on this rank leaves the others inside a collective: the job cannot go on together.  This rank leaves at once
+            # (rank 0 with the direct line), the others when their watchdogs fire.
+            bail("the relayed run failed on rank %d: %s; the line holds the direct run only" % (rank, e))
         finally:
             watchdog.cancel()
             comm.setOption("relay", 0)
