@@ -301,12 +301,13 @@ int dfft_axis_plan_info(int precision, size_t N, int two_level, size_t info[8]);
  * dfft_malloc: chunk_mib = 0 is hipMalloc; otherwise one virtual range backed by physical allocations of chunk_mib MiB
  * each (HIP virtual-memory API).  chunk_mib = DFFT_CHUNK_DEFAULT: the library's default backing, which is also what the library
  * uses for a work area it owns (dfft_init(allocate = 1), dfft_set_work_area(plan, NULL, NULL)): 1 GiB chunks (smaller ones and
- * finally hipMalloc if that fails) and, for buffers of 1 GiB and more, a PLACEMENT PROBE -- up to DFFT_PLACEMENT_TRIES (6)
- * candidates are allocated, all alive, a streaming write is timed on each (8 ms per 16 GiB), the first above 5.9 TB/s or else
- * the fastest is kept.  A good scatter target streams writes at 6.5 TB/s, a bad one at 5.2 TB/s, and the plan's scatter passes
- * follow (5.65 vs 6.5 ms per pass at 1024^3 fp64; hipMalloc buffers are always the bad kind): profiles/r4_placement_probe.txt.
- * 1024^3 fp64 forward + inverse on buffers from this call: 33.7 - 34.4 ms, on hipMalloc buffers 37.6.  Local to the device (no
- * plan, no collective): safe on every rank of a multi-rank job.  Costs 0.03 - 5 s per 16 GiB buffer.  Environment:
+ * finally hipMalloc if that fails) and, for buffers of 1 GiB and more, PLACEMENT: the buffer is built from chunks that lie far
+ * apart (every K-th of K times as many, K <= 8), a streaming write is timed on it (8 ms per 16 GiB) and it is kept if it is
+ * good (>= 5.9 TB/s); otherwise up to DFFT_PLACEMENT_TRIES (6) plain candidates are drawn, all alive, and the fastest is kept.
+ * A good scatter target streams writes at 6.5 TB/s, a bad one at 5.2 TB/s, and the plan's scatter passes follow (5.65 vs 6.5 ms
+ * per pass at 1024^3 fp64; hipMalloc buffers are always the bad kind): profiles/r4_placement_probe.txt.  1024^3 fp64 forward +
+ * inverse on buffers from this call: 33.5 - 33.6 ms, on hipMalloc buffers 37.6 - 38.3.  Local to the device (no plan, no
+ * collective): safe on every rank of a multi-rank job.  Costs about 3.4 s per 16 GiB buffer, 0.4 s per 2 GiB.  Environment:
  * DFFT_DEFAULT_CHUNK_MIB (0 = hipMalloc), DFFT_PLACEMENT_TRIES (1 = no probe).  Free with dfft_free (which also takes
  * pointers it did not allocate: hipFree; it synchronises the device first, like hipFree). */
 #define DFFT_CHUNK_DEFAULT ((size_t)-1)
