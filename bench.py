@@ -9,8 +9,9 @@ reference's jobs: 10 warm-up + 20 timed iterations (jobs/bwunicluster/pencil/ben
 
     python bench.py                      # 1 GPU, 1024^3 fp64, 10 warm-up + 20 steps
     python bench.py --size 2048 --precision float          # config 5's grid on one GPU (in = back aliased)
+    python bench.py --gpus 8             # starts its own 8 ranks (torch.distributed.run on 127.0.0.1, a free port) ...
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        --master-port 29500 bench.py --gpus 8
+        --master-port 29500 bench.py --gpus 8        # ... or runs inside ranks somebody else started
     python bench.py --dry-run            # build the C4 / C5 plans of all 8 ranks on a host without a GPU
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
@@ -86,6 +87,8 @@ def parse():
                     help="skip dfft_tune_variants (the y / x passes try the streaming sibling of their kernel configuration on the run's own "
                          "buffers before the warm-up; already part of the placement tuner where that runs)")
     ap.add_argument("--dry-run", action="store_true", help="plan C4 / C5 for all 8 ranks without a GPU and print the memory budget")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launcher check (no GPU needed): the ranks meet over gloo, rank 0 prints the world it saw, everybody leaves")
     return ap.parse_args()
 
 
@@ -268,27 +271,68 @@ def dry_run():
     print(json.dumps({"dry_run": out}))
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves, one process per GPU on this node
+    (the reference's launcher builds its own `mpiexec -n P ...` line the same way, launch.py:168-247).  The child processes are
+    this script under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>`
+    with the caller's argv; rank 0's JSON line goes to our stdout, the return code is non-zero if any rank failed."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["DFFT_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks: {' '.join(cmd[1:8])} bench.py ...", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     if args.dry_run:
         return dry_run()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
-
-    import distributedfft_amd as dfft
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     ngpus = args.gpus
     if world != ngpus:
-        if world == 1 and ngpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        if rank == 0:
+            print(f"[bench] --gpus {ngpus} but WORLD_SIZE = {world}: running on {world} ranks", file=sys.stderr, flush=True)
         ngpus = world
+    dist = None
+    if args.rendezvous_only:
+        # launcher check that needs no GPU (tests/test_cpu_multiprocess.py): the ranks meet over gloo, agree on the world and leave
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.tensor([rank + 1], dtype=torch.int64)
+            dist.all_reduce(t)
+            total = int(t.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            total = 1
+        if rank == 0:
+            print(json.dumps({"rendezvous": "ok", "world_size": world, "sum_of_ranks_plus_1": total,
+                              "self_launched": os.environ.get("DFFT_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+        return None
+
+    import distributedfft_amd as dfft
+
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     ndev = torch.cuda.device_count()
+    if world > ndev and args.backend == "nccl":
+        sys.exit(f"bench.py --gpus {world}: {ndev} device(s) visible; RCCL needs one GPU per rank (--backend gloo lets ranks share a GPU, functional test only)")
     dev = local_rank % ndev
     torch.cuda.set_device(dev)
-    dist = None
     if world > 1:
         import torch.distributed as dist
         if args.backend == "nccl":

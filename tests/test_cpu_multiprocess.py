@@ -55,3 +55,36 @@ def run_world(P1, P2, shape, seq, extra_env=None):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{out}"
         assert f"rank {r} ok" in out
+
+
+def _clean_env():
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` as the driver calls it -- NOT inside torch.distributed.run -- starts its N ranks itself
+    (the reference's launcher builds its own `mpiexec -n P` line, launch.py:168-247).  Without a GPU the ranks can only meet:
+    --rendezvous-only has them agree on the world over gloo and leave."""
+    import json
+    root = os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--rendezvous-only"], capture_output=True, text=True,
+                         timeout=300, env=_clean_env())
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line == {"rendezvous": "ok", "world_size": 3, "sum_of_ranks_plus_1": 6, "self_launched": True}
+
+
+def test_bench_fails_loudly_when_a_rank_fails():
+    """a rank that cannot run (here: no GPU) makes the self-launched job return non-zero and print no result line"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this box has a GPU: the ranks would run")
+    root = os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", "64", "--steps", "1",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=300, env=_clean_env())
+    assert out.returncode != 0
+    assert "needs a GPU" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]

@@ -382,17 +382,20 @@ def test_variant_options_outside_the_key_range_are_rejected():
 # ------------------------------------------------------------------------------------------
 # bench.py lines
 # ------------------------------------------------------------------------------------------
-def _bench(args, nproc=1, port=29671):
+def _bench(args, nproc=1, port=29671, self_launch=False):
+    """self_launch: `python bench.py --gpus N` exactly as the driver's command line has it -- bench.py starts its own ranks"""
     import json
     import subprocess
     import sys
-    if nproc > 1:
+    if nproc > 1 and not self_launch:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
     else:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
-    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900,
-                         env=dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
 
@@ -405,7 +408,7 @@ def test_bench_multi_rank_line_is_self_documenting(nproc, want, alt):
     # (4 ranks: the relayed run is made the headline whatever its time, to exercise that branch: on ranks that share one GPU over
     # gloo it is never the faster one)
     line = _bench(["--gpus", str(nproc), "--backend", "gloo", "--size", "128", "--steps", "2", "--warmup", "1"] + (["--prefer-relay"] if nproc == 4 else []),
-                  nproc=nproc, port=29671 + nproc)
+                  nproc=nproc, port=29671 + nproc, self_launch=nproc != 4)      # 2 and 8 ranks: bench.py launches them itself
     assert line["n_gpus"] == nproc and line["round_trip_rel_linf"] < 1e-10
     assert line["config"]["decomposition"] == want
     if alt:
