@@ -119,10 +119,12 @@ def xgmi_model(esz, N, ngpus, P1, P2):
             out[name] = {"group_ranks": P, "links": P - 1, "bytes_per_link": per_link, "bytes_out": per_link * (P - 1),
                          "predicted_ms": round(per_link / (XGMI_LINK_GBS * 1e9) * 1e3, 3)}
             if P < ngpus:
-                # two-hop relay (dfft_comm_set_option "relay", csrc/comm.hip): a message to a partner is cut into n_gpus parts, per
-                # partner two world-wide phases in each of which every link of the GPU carries ONE part
+                # two-hop relay (dfft_comm_set_option "relay", csrc/comm.hip): every message is cut into n_gpus parts; all P - 1 partners
+                # travel together, so an exchange is TWO grouped operations (hops) in each of which every link of the GPU carries
+                # one part of each of the P - 1 messages
                 part = per_link / ngpus
-                out[name]["relay"] = {"links": ngpus - 1, "phases": 2 * (P - 1), "bytes_per_link_per_phase": part,
+                out[name]["relay"] = {"links": ngpus - 1, "phases": 2, "pieces_per_link_per_phase": P - 1,
+                                      "bytes_per_link_per_phase": (P - 1) * part,
                                       "predicted_ms": round(2 * (P - 1) * part / (XGMI_LINK_GBS * 1e9) * 1e3, 3)}
     return out
 
@@ -369,9 +371,10 @@ def main():
             comm, transport = make_comm(dist, rank, world, P1, P2, tmode_box[0])
             if transport.startswith("rccl") and P1 > 1 and P2 > 1 and not args.no_dup_channel:
                 # row- and column-group exchanges use disjoint links: give the second one its own communicator (collective)
+                # (3: one for exchange 2 and one per exchange for the relay's first hop, which runs under the second hop of the chunk before)
                 try:
-                    comm.setOption("dup_channel", 1)
-                    transport += ", duplicated communicator for exchange 2"
+                    comm.setOption("dup_channel", 3)
+                    transport += ", duplicated communicators for exchange 2 and the relay's first hops"
                 except Exception as e:   # noqa: BLE001
                     if rank == 0:
                         print(f"[bench] dup_channel unavailable: {e}", file=sys.stderr, flush=True)
@@ -740,11 +743,12 @@ def main():
             dtr, phr, launches_r = run_steps(plan, args.steps, d_out, d_back, collect=True)
             exr = {name: round(ms / args.steps / 2.0, 3) for name, ms in phr.items() if "FFT" not in name}
             relay_leg = {"what": "the headline plan with dfft_comm_set_option(comm, 'relay', %d): every message of the relayed exchanges cut into "
-                                 "n_gpus parts, two direct and the others through the ranks outside the pair, as two world-wide all-to-alls per "
-                                 "partner (csrc/comm.hip)" % want_relay,
+                                 "n_gpus parts, two direct and the others through the ranks outside the pair; all partners together: two grouped "
+                                 "send/receive operations per exchange and pipeline chunk, hop 1 of a chunk under hop 2 of the chunk before (csrc/comm.hip)" % want_relay,
                          "relay": want_relay, "ms_per_step": round(dtr / args.steps * 1e3, 3), "round_trip_rel_linf": rt_r,
                          "value": round(2 * flops_per_direction(N) * args.steps / dtr / 1e9, 1),
-                         "exchange_ms_per_transform": exr, "per_pass": per_pass(phr, args.steps)}
+                         "exchange_ms_per_transform": exr, "per_pass": per_pass(phr, args.steps),
+                         "transport_counters": comm.comm.counters() if hasattr(comm, "comm") else comm.counters()}
             relay_leg["overlap"] = overlap_report(relay_leg["ms_per_step"], sum(ms for n_, ms in phr.items() if "FFT" in n_) / args.steps,
                                                   sum(ms for n_, ms in phr.items() if "FFT" not in n_) / args.steps)
         except Exception as e:   # noqa: BLE001

@@ -9,6 +9,9 @@ LIB_PATH = os.path.join(_HERE, "libdfft_amd.so")
 ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                            C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int),
                            C.c_int, C.c_int, C.c_void_p)
+# dfft_sendrecv_list_fn: (user, nsend, speer, sptr, sbytes, nrecv, rpeer, rptr, rbytes, stream)
+SENDRECV_LIST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                               C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p)
 
 
 class Config(C.Structure):
@@ -37,7 +40,9 @@ SYMBOLS = [
     ("dfft_rccl_unique_id", _i, [_vp]),
     ("dfft_comm_create_rccl", _i, [_vp, _i, _i, C.POINTER(_vp)]),
     ("dfft_comm_create_callback", _i, [_i, _i, ALLTOALLV_FN, _vp, C.POINTER(_vp)]),
+    ("dfft_comm_set_list_callback", _i, [_vp, SENDRECV_LIST_FN, _vp]),
     ("dfft_comm_info", _i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    ("dfft_comm_get_counter", _i, [_vp, C.c_char_p, C.POINTER(C.c_long)]),
     ("dfft_comm_set_option", _i, [_vp, C.c_char_p, C.c_long]),
     ("dfft_comm_alltoallv", _i, [_vp, _i, _vp, C.POINTER(_sz), C.POINTER(_sz), _vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_i), _i, _i, _vp]),
     ("dfft_comm_destroy", _i, [_vp]),

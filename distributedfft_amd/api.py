@@ -183,6 +183,33 @@ class Comm:
         check(lib().dfft_comm_create_callback(nranks, rank, cfn, None, C.byref(h)))
         return cls(h, nranks, rank, keep=cfn)
 
+    def setListCallback(self, fn):
+        """optional second callback of a callback communicator (dfft_comm_set_list_callback): a point-to-point schedule in one call,
+        fn(sends, recvs, stream) with sends / recvs = [(peer, ptr, nbytes), ...] in matching order at both ends of every link"""
+
+        def tramp(user, ns, sp, sptr, sby, nr, rp, rptr, rby, stream):
+            try:
+                fn([(sp[i], sptr[i] or 0, sby[i]) for i in range(ns)], [(rp[i], rptr[i] or 0, rby[i]) for i in range(nr)], stream)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        cfn = _lib.SENDRECV_LIST_FN(tramp)
+        check(lib().dfft_comm_set_list_callback(self._h, cfn, None))
+        self._keep = (self._keep, cfn)
+
+    def counters(self):
+        """what went through the transport since the communicator was made (dfft_comm_get_counter): all-to-all-v operations, native
+        point-to-point schedules (one per hop of a relayed exchange), relayed exchanges, table gathers of the relay"""
+        out = {}
+        for k in ("alltoallv", "list", "relayed", "relay_meta"):
+            v = C.c_long(0)
+            check(lib().dfft_comm_get_counter(self._h, k.encode(), C.byref(v)))
+            out[k] = v.value
+        return out
+
     @staticmethod
     def rccl_unique_id():
         buf = C.create_string_buffer(128)

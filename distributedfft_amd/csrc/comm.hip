@@ -38,6 +38,8 @@ struct LocalWorld : dfft_comm {
         const int *group = nullptr;
         int ngroup = 0;
         hipEvent_t ready = nullptr, done = nullptr;
+        const dfft_xfer *sends = nullptr;      // sendrecv_list: the published schedule
+        int ns = 0;
     };
     std::vector<Slot> slots;
     std::mutex mu;
@@ -101,6 +103,42 @@ struct LocalWorld : dfft_comm {
             if (group[q] != myrank && slots[group[q]].done) note(hipStreamWaitEvent(stream, slots[group[q]].done, 0), "hipStreamWaitEvent");
         return err;
     }
+    // the schedule in one go, "pull" like alltoallv: publish my send pieces, meet, copy every piece addressed to me
+    int sendrecv_list(int myrank, const dfft_xfer *sends, int ns, const dfft_xfer *recvs, int nr, int /*nlayers*/, hipStream_t stream,
+                      int /*channel*/) override
+    {
+        int err = 0;
+        auto note = [&](hipError_t e, const char *what) {
+            if (e != hipSuccess && !err) { err = (int)e; set_error(std::string(what) + ": " + hipGetErrorString(e)); }
+        };
+        counters.list++;
+        Slot &mine = slots[myrank];
+        if (!mine.ready) {
+            note(hipEventCreateWithFlags(&mine.ready, hipEventDisableTiming), "hipEventCreate");
+            if (!err) note(hipEventCreateWithFlags(&mine.done, hipEventDisableTiming), "hipEventCreate");
+        }
+        mine.sends = sends;
+        mine.ns = ns;
+        if (!err) note(hipEventRecord(mine.ready, stream), "hipEventRecord");
+        barrier(myrank);   // everyone has published
+        std::vector<char> waited(nranks, 0);
+        for (int i = 0; i < nr && !err; i++) {
+            const dfft_xfer &r = recvs[i];
+            if (r.peer < 0 || r.peer >= nranks || r.peer == myrank) { if (!err) { err = 1; set_error("sendrecv_list: bad peer"); } break; }
+            const Slot &peer = slots[r.peer];
+            const dfft_xfer *m = nullptr;
+            for (int j = 0; j < peer.ns; j++)
+                if (peer.sends[j].peer == myrank && peer.sends[j].layer == r.layer) { m = &peer.sends[j]; break; }
+            if (!m || m->bytes != r.bytes) { err = 1; set_error("sendrecv_list: a receive piece has no matching send piece of its size"); break; }
+            if (!waited[r.peer] && peer.ready) { note(hipStreamWaitEvent(stream, peer.ready, 0), "hipStreamWaitEvent"); waited[r.peer] = 1; }
+            if (!err) note(hipMemcpyAsync(r.ptr, m->ptr, r.bytes, hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync");
+        }
+        if (!err) note(hipEventRecord(mine.done, stream), "hipEventRecord");
+        barrier(myrank);   // everyone has enqueued its pulls
+        for (int y = 0; y < nranks && !err; y++)
+            if (y != myrank && slots[y].done) note(hipStreamWaitEvent(stream, slots[y].done, 0), "hipStreamWaitEvent");
+        return err;
+    }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -162,17 +200,27 @@ static RcclApi *rccl()
 
 struct RcclComm : dfft_comm {
     void *comm = nullptr;
-    void *comm2 = nullptr;     // duplicate communicator (ncclCommSplit, colour 0) for channel 1
+    // duplicate communicators (ncclCommSplit, colour 0): extra[0] for channel 1 (the second exchange of a pencil plan), extra[1] /
+    // extra[2] for channels 2 / 3 (the relay's first hop of exchange 1 / 2 while the second hop of the previous chunk is on the wire)
+    void *extra[3] = {nullptr, nullptr, nullptr};
     int rank = 0;
     bool self_send = false;    // testing: the self block goes through ncclSend / ncclRecv to the own rank instead of a device copy
                                // (lets a 1-GPU box hand caller buffers -- virtual-memory ranges included -- to RCCL)
     int fixed_rank() const override { return rank; }
     // one ncclComm serialises its operations: only a duplicated communicator allows overlap
-    bool concurrent_channels() const override { return comm2 != nullptr; }
+    bool concurrent_channels() const override { return extra[0] != nullptr; }
+    bool concurrent_hops(int channel) const override { return channel >= 0 && channel < 2 && extra[channel + 1] != nullptr; }
+    void *comm_of(int channel) const
+    {
+        if (channel >= 1 && channel <= 3 && extra[channel - 1]) return extra[channel - 1];
+        if (channel == 3 && extra[0]) return extra[0];      // no communicator of its own: at least not the one of the other exchange
+        return comm;
+    }
     ~RcclComm() override
     {
         RcclApi *R = rccl();
-        if (R && comm2 && R->CommDestroy) R->CommDestroy(comm2);
+        for (void *c : extra)
+            if (R && c && R->CommDestroy) R->CommDestroy(c);
         if (R && comm && R->CommDestroy) R->CommDestroy(comm);
     }
     int transport_nranks() const override
@@ -182,23 +230,25 @@ struct RcclComm : dfft_comm {
         if (!R || !R->CommCount || !comm || R->CommCount(comm, &n) != 0) return 0;
         return n;
     }
-    // "dup_channel" = 1: second communicator over the same ranks (ncclCommSplit, colour 0) for channel 1.  Collective: every
-    // rank calls it at the same point.  Without it both exchanges of a pencil plan share one communicator and RCCL
-    // serialises them.
+    // "dup_channel" = 1: second communicator over the same ranks (ncclCommSplit, colour 0) for channel 1; = 3: three of them, for
+    // channels 1, 2, 3 (2 / 3 carry the relay's first hop).  Collective: every rank calls it at the same point.  Without it both
+    // exchanges of a pencil plan share one communicator and RCCL serialises them.
     int set_option(const char *key, long value) override
     {
         if (std::string(key ? key : "") == "self_send") { self_send = value != 0; return 0; }
         if (std::string(key ? key : "") != "dup_channel") return 1;
         RcclApi *R = rccl();
         if (!R || !comm) { set_error("librccl not available"); return 1; }
-        if (value == 0) {
-            if (comm2 && R->CommDestroy) R->CommDestroy(comm2);
-            comm2 = nullptr;
-            return 0;
+        if (value < 0 || value > 3) { set_error("dup_channel: 0 .. 3 extra communicators"); return 2; }
+        for (int i = 2; i >= (int)value; i--) {
+            if (extra[i] && R->CommDestroy) R->CommDestroy(extra[i]);
+            extra[i] = nullptr;
         }
-        if (comm2) return 0;
-        if (!R->CommSplit) { set_error("this librccl has no ncclCommSplit"); return 1; }
-        NCCL_TRY(R->CommSplit(comm, 0, rank, &comm2, nullptr));
+        for (int i = 0; i < (int)value; i++) {
+            if (extra[i]) continue;
+            if (!R->CommSplit) { set_error("this librccl has no ncclCommSplit"); return 1; }
+            NCCL_TRY(R->CommSplit(comm, 0, rank, &extra[i], nullptr));
+        }
         return 0;
     }
     int alltoallv(int myrank, const void *send, const size_t *scount, const size_t *sdispl, void *recv,
@@ -209,7 +259,7 @@ struct RcclComm : dfft_comm {
         if (!R) { set_error("librccl not available"); return 1; }
         const char *s = static_cast<const char *>(send);
         char *r = static_cast<char *>(recv);
-        void *use = (channel == 1 && comm2) ? comm2 : comm;
+        void *use = comm_of(channel);
         // self block: plain device copy, never goes through RCCL
         // (the reference skips self in its send tables, src/pencil/mpicufft_pencil.cpp:282-289)
         if (rcount[me] && !self_send)
@@ -237,6 +287,32 @@ struct RcclComm : dfft_comm {
             return 1000 + err;
         }
         (void)myrank;
+        return 0;
+    }
+    // the schedule as ONE group of ncclSend / ncclRecv: RCCL matches the pieces between two ranks in the order they were issued, and
+    // both ends list them by layer
+    int sendrecv_list(int /*myrank*/, const dfft_xfer *sends, int ns, const dfft_xfer *recvs, int nr, int nlayers, hipStream_t stream,
+                      int channel) override
+    {
+        RcclApi *R = rccl();
+        if (!R) { set_error("librccl not available"); return 1; }
+        void *use = comm_of(channel);
+        counters.list++;
+        NCCL_TRY(R->GroupStart());
+        int err = 0;
+        std::string what;
+        for (int layer = 0; layer < nlayers && !err; layer++) {
+            for (int i = 0; i < ns && !err; i++)
+                if (sends[i].layer == layer && sends[i].bytes && (err = R->Send(sends[i].ptr, sends[i].bytes, /*ncclInt8*/ 0, sends[i].peer, use, stream)) != 0) what = "ncclSend";
+            for (int i = 0; i < nr && !err; i++)
+                if (recvs[i].layer == layer && recvs[i].bytes && (err = R->Recv(recvs[i].ptr, recvs[i].bytes, 0, recvs[i].peer, use, stream)) != 0) what = "ncclRecv";
+        }
+        const int end = R->GroupEnd();      // a failing call inside the group must not leave it open
+        if (!err && end) { err = end; what = "ncclGroupEnd"; }
+        if (err) {
+            set_error(what + ": " + (R->GetErrorString ? R->GetErrorString(err) : "rccl error"));
+            return 1000 + err;
+        }
         return 0;
     }
 };
@@ -276,6 +352,8 @@ dfft_comm *make_rccl_comm(const void *id128, int nranks, int rank)
 struct CallbackComm : dfft_comm {
     dfft_alltoallv_fn fn = nullptr;
     void *user = nullptr;
+    dfft_sendrecv_list_fn list_fn = nullptr;
+    void *list_user = nullptr;
     int rank = 0;
     int fixed_rank() const override { return rank; }
     int alltoallv(int myrank, const void *send, const size_t *scount, const size_t *sdispl, void *recv,
@@ -287,16 +365,44 @@ struct CallbackComm : dfft_comm {
         if (r != 0) set_error("all-to-all callback failed with code " + std::to_string(r));
         return r;
     }
+    int sendrecv_list(int myrank, const dfft_xfer *sends, int ns, const dfft_xfer *recvs, int nr, int nlayers, hipStream_t stream, int channel) override
+    {
+        if (!list_fn) return dfft_comm::sendrecv_list(myrank, sends, ns, recvs, nr, nlayers, stream, channel);
+        // by layer, so that both ends of a link see its pieces in the same order
+        std::vector<int> sp, rp;
+        std::vector<void *> sptr, rptr;
+        std::vector<size_t> sby, rby;
+        for (int layer = 0; layer < nlayers; layer++) {
+            for (int i = 0; i < ns; i++)
+                if (sends[i].layer == layer && sends[i].bytes) { sp.push_back(sends[i].peer); sptr.push_back(sends[i].ptr); sby.push_back(sends[i].bytes); }
+            for (int i = 0; i < nr; i++)
+                if (recvs[i].layer == layer && recvs[i].bytes) { rp.push_back(recvs[i].peer); rptr.push_back(recvs[i].ptr); rby.push_back(recvs[i].bytes); }
+        }
+        counters.list++;
+        int r = list_fn(list_user, (int)sp.size(), sp.data(), sptr.data(), sby.data(), (int)rp.size(), rp.data(), rptr.data(), rby.data(), (void *)stream);
+        if (r != 0) set_error("send/receive schedule callback failed with code " + std::to_string(r));
+        return r;
+    }
 };
+int callback_comm_set_list(dfft_comm *comm, void *fn, void *user)
+{
+    CallbackComm *c = dynamic_cast<CallbackComm *>(comm);
+    if (!c) { set_error("not a callback communicator"); return 1; }
+    c->list_fn = (dfft_sendrecv_list_fn)fn;
+    c->list_user = user;
+    return 0;
+}
 
 // ------------------------------------------------------------------------------------------
-// Two-hop relay (see comm.hpp).  Per partner round k = 1 .. ngroup - 1 (rank `me` of a group sends to member me + k and
-// receives from member me - k):
-//   phase A  world all-to-all: part 0 of my message straight to the partner, part 2 + h to helper h (every rank outside the
-//            pair, ascending); I receive part 0 of my source's message in place and, as a helper of every other pair, one
-//            part each into the staging buffer
-//   phase B  world all-to-all: part 1 straight to the partner, every staged part on to its destination; I receive parts
-//            1 .. nranks - 1 of my source's message in place
+// Two-hop relay (see comm.hpp), one-shot form.  Round k = 1 .. ngroup - 1 names the partners: member `me` of a group sends to member
+// me + k and receives from member me - k; a message of S bytes is cut into nranks parts (relay_part): part 0 and part 1 travel
+// directly (hop 1 / hop 2), part 2 + h through helper h, the h-th rank outside the pair.
+//   hop 1  to every rank x, for every round k: the part of my round-k message that x carries (part 0 if x is that round's partner);
+//          from every rank x, for every round k: part 0 of x's round-k message if it is for me (in place), else the part I carry for
+//          that pair (into the staging buffer)
+//   hop 2  to every rank x, for every round k: part 1 of my message if x is my round-k partner, else the part I hold of the round-k
+//          message for x; from every rank x, for every round k: the part of my round-k source's message that x carried (in place)
+// Both ends of a link list its pieces by round, which is the `layer` the transports match them by.
 // ------------------------------------------------------------------------------------------
 void relay_part(size_t S, int nranks, int p, size_t *off, size_t *len)
 {
@@ -312,43 +418,74 @@ struct RelayMeta {
     int R = 0;                        // rounds = group size - 1
     std::vector<int> partner;         // [y * R + k - 1]: the rank y sends to in round k
     std::vector<size_t> bytes;        // ... and the size of that message
+    // the schedule of this rank, built once from the gathered tables: where = 0 send buffer, 1 receive buffer, 2 staging
+    struct Piece { int peer, layer, where; size_t off, bytes; };
+    std::vector<Piece> sendA, recvA, sendB, recvB;
+    size_t staging = 0;
+    bool built = false;
 };
 struct RelayBuf { char *p = nullptr; size_t cap = 0; bool device = false; };
+// per (stream, channel) of the exchanges that use the relay: staging (two buffers when the hops of neighbouring chunks overlap), the
+// side stream of hop 1 and the events that order the two streams
+struct RelayLane {
+    RelayBuf staging[2];
+    hipStream_t side = nullptr;
+    hipEvent_t in = nullptr, hop1 = nullptr, hop2[2] = {nullptr, nullptr};
+    bool hop2_used[2] = {false, false};
+    int parity = 0;
+};
 struct RelayCache {
     std::map<uint64_t, RelayMeta> meta;
-    std::map<std::pair<void *, int>, RelayBuf> staging;      // per (stream, channel): calls on one stream are ordered
+    std::map<std::pair<void *, int>, RelayLane> lanes;
     RelayBuf msend, mrecv;
 };
 RelayCache *relay_cache_new() { return new RelayCache; }
 static void relay_buf_free(RelayBuf &b)
 {
     if (!b.p) return;
-    if (b.device) (void)hipFree(b.p); else free(b.p);
+    if (b.device) (void)dfft_free(b.p); else free(b.p);
     b = RelayBuf();
 }
 void relay_cache_free(RelayCache *c)
 {
     if (!c) return;
-    for (auto &kv : c->staging) relay_buf_free(kv.second);
+    for (auto &kv : c->lanes) {
+        RelayLane &L = kv.second;
+        if (L.side) { (void)hipStreamSynchronize(L.side); (void)hipStreamDestroy(L.side); }
+        for (hipEvent_t e : {L.in, L.hop1, L.hop2[0], L.hop2[1]})
+            if (e) (void)hipEventDestroy(e);
+        relay_buf_free(L.staging[0]);
+        relay_buf_free(L.staging[1]);
+    }
     relay_buf_free(c->msend);
     relay_buf_free(c->mrecv);
     delete c;
 }
-// is this a device pointer?  (the CPU tests drive the exchange with host tensors through the callback transport)
-static bool relay_on_device(const void *ptr)
+// Device or host buffer?  (The CPU tests drive the exchange with host tensors through the callback transport.)  0 host, 1 device,
+// -1 the query failed for another reason than "this is plain host memory" -- the caller returns an error instead of guessing.
+static int relay_on_device(const void *ptr)
 {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { (void)hipGetLastError(); return 0; }      // no GPU: everything is host memory
     hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, ptr) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeUnified || at.type == hipMemoryTypeManaged;
+    const hipError_t e = hipPointerGetAttributes(&at, ptr);
+    if (e == hipErrorInvalidValue) { (void)hipGetLastError(); return 0; }      // a pointer the runtime does not know: malloc'ed host memory
+    if (e != hipSuccess) { set_error(std::string("relay: hipPointerGetAttributes: ") + hipGetErrorString(e)); (void)hipGetLastError(); return -1; }
+    return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeUnified || at.type == hipMemoryTypeManaged ? 1 : 0;
 }
 static int relay_reserve(RelayBuf &b, size_t bytes, bool device, hipStream_t stream)
 {
     if (b.p && b.cap >= bytes && b.device == device) return 0;
-    if (b.p && b.device) HIP_TRY(hipStreamSynchronize(stream));      // earlier exchanges on this stream may still read it
+    if (b.p && b.device) HIP_TRY(hipDeviceSynchronize());      // earlier exchanges (either hop stream) may still read it
+    (void)stream;
     relay_buf_free(b);
     bytes = (bytes + 4095) & ~(size_t)4095;
-    if (device) HIP_TRY(hipMalloc((void **)&b.p, bytes));
-    else if (!(b.p = (char *)malloc(bytes))) { set_error("relay: out of host memory"); return 1; }
+    if (device) {
+        // the library's default backing (csrc/dfft.hip dev_alloc_default: hipMalloc'ed buffers are the slow scatter / stream targets)
+        void *ptr = nullptr;
+        if (int r = dfft_malloc(bytes, DFFT_CHUNK_DEFAULT, &ptr)) return r;
+        b.p = (char *)ptr;
+    } else if (!(b.p = (char *)malloc(bytes))) { set_error("relay: out of host memory"); return 1; }
     b.cap = bytes;
     b.device = device;
     return 0;
@@ -372,10 +509,13 @@ static int relay_gather_meta(dfft_comm *comm, RelayCache *cache, RelayMeta &M, i
     std::vector<size_t> cnt(n, rec), dsp(n);
     std::vector<int> world(n);
     for (int y = 0; y < n; y++) { dsp[y] = (size_t)y * rec; world[y] = y; }
+    // once per exchange table and plan: the two copies below are blocking on purpose (the tables are needed on the host)
     if (device) {
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipMemcpy(cache->msend.p, rep.data(), rec * n, hipMemcpyHostToDevice));
     } else memcpy(cache->msend.p, rep.data(), rec * n);
+    comm->counters.relay_meta++;
+    comm->counters.alltoallv++;
     if (int r = comm->alltoallv(myrank, cache->msend.p, cnt.data(), dsp.data(), cache->mrecv.p, cnt.data(), dsp.data(), world.data(), n,
                                 myrank, stream, channel)) return r;
     if (device) {
@@ -402,13 +542,75 @@ static int relay_gather_meta(dfft_comm *comm, RelayCache *cache, RelayMeta &M, i
     return 0;
 }
 
+// this rank's pieces of both hops, from the gathered tables and its own exchange table (offsets relative to the send / receive
+// buffer of the call and to the staging buffer)
+static int relay_build(RelayMeta &M, int n, int myrank, const size_t *scount, const size_t *sdispl, const size_t *rcount, const size_t *rdispl,
+                       const int *group, int ngroup, int me)
+{
+    const int R = M.R;
+    auto helper_index = [](int h, int a, int b) { return h - (a < h) - (b < h); };      // position of h among the ranks outside {a, b}
+    auto partner = [&](int y, int k) { return M.partner[(size_t)y * R + k - 1]; };
+    auto bytes = [&](int y, int k) { return M.bytes[(size_t)y * R + k - 1]; };
+    std::vector<int> src(n);
+    // staged parts: [k][y] for every pair (y, partner(y, k)) I am outside of
+    std::vector<size_t> stoff((size_t)R * n, 0), stlen((size_t)R * n, 0);
+    size_t need = 0;
+    M.sendA.clear(); M.recvA.clear(); M.sendB.clear(); M.recvB.clear();
+    for (int k = 1; k <= R; k++) {
+        const int ti = (me + k) % ngroup, si = (me - k + ngroup) % ngroup;
+        const int t = group[ti], s = group[si];
+        const size_t St = scount[ti], Ss = rcount[si];
+        if (partner(myrank, k) != t || partner(s, k) != myrank || bytes(s, k) != Ss || bytes(myrank, k) != St) {
+            set_error("relay: the gathered tables do not match this call");
+            return 1;
+        }
+        for (int y = 0; y < n; y++) src[partner(y, k)] = y;
+        for (int y = 0; y < n; y++) {
+            if (y == myrank || y == s) continue;      // (y == s: its partner is me)
+            size_t off, len;
+            relay_part(bytes(y, k), n, 2 + helper_index(myrank, y, partner(y, k)), &off, &len);
+            stoff[(size_t)(k - 1) * n + y] = need;
+            stlen[(size_t)(k - 1) * n + y] = len;
+            need += (len + 255) & ~(size_t)255;
+        }
+        for (int x = 0; x < n; x++) {
+            if (x == myrank) continue;
+            size_t off, len;
+            // ---- hop 1 ----
+            relay_part(St, n, x == t ? 0 : 2 + helper_index(x, myrank, t), &off, &len);
+            if (len) M.sendA.push_back({x, k - 1, 0, sdispl[ti] + off, len});
+            if (x == s) {
+                relay_part(Ss, n, 0, &off, &len);
+                if (len) M.recvA.push_back({x, k - 1, 1, rdispl[si] + off, len});
+            } else if (stlen[(size_t)(k - 1) * n + x]) {
+                M.recvA.push_back({x, k - 1, 2, stoff[(size_t)(k - 1) * n + x], stlen[(size_t)(k - 1) * n + x]});
+            }
+            // ---- hop 2 ----
+            if (x == t) {
+                relay_part(St, n, 1, &off, &len);
+                if (len) M.sendB.push_back({x, k - 1, 0, sdispl[ti] + off, len});
+            } else {
+                const int y = src[x];      // the rank whose round-k message goes to x (y != me: only t has me as its source)
+                if (stlen[(size_t)(k - 1) * n + y]) M.sendB.push_back({x, k - 1, 2, stoff[(size_t)(k - 1) * n + y], stlen[(size_t)(k - 1) * n + y]});
+            }
+            relay_part(Ss, n, x == s ? 1 : 2 + helper_index(x, s, myrank), &off, &len);
+            if (len) M.recvB.push_back({x, k - 1, 1, rdispl[si] + off, len});
+        }
+    }
+    M.staging = need ? need : 256;
+    M.built = true;
+    return 0;
+}
+
 int relay_alltoallv(dfft_comm *comm, RelayCache *cache, uint64_t tag, int myrank, const void *send, const size_t *scount,
                     const size_t *sdispl, void *recv, const size_t *rcount, const size_t *rdispl, const int *group, int ngroup,
-                    int me, hipStream_t stream, int channel)
+                    int me, hipStream_t stream, int channel, hipEvent_t ready)
 {
     const int n = comm->nranks, R = ngroup - 1;
-    const bool device = relay_on_device(send);
-    const char *sb = static_cast<const char *>(send);
+    const int dev = relay_on_device(send);
+    if (dev < 0) return 1;
+    const bool device = dev == 1;
+    char *sb = const_cast<char *>(static_cast<const char *>(send));
     char *rb = static_cast<char *>(recv);
     auto it = cache->meta.find(tag);
     if (it == cache->meta.end()) {
@@ -416,79 +618,51 @@ int relay_alltoallv(dfft_comm *comm, RelayCache *cache, uint64_t tag, int myrank
         if (int r = relay_gather_meta(comm, cache, M, myrank, scount, group, ngroup, me, device, stream, channel)) return r;
         it = cache->meta.emplace(tag, std::move(M)).first;
     }
-    const RelayMeta &M = it->second;
+    RelayMeta &M = it->second;
     if (M.R != R) { set_error("relay: exchange table changed under its tag"); return 1; }
+    if (!M.built)
+        if (int r = relay_build(M, n, myrank, scount, sdispl, rcount, rdispl, group, ngroup, me)) return r;
+    RelayLane &L = cache->lanes[std::make_pair((void *)stream, channel)];
+    // hop 1 on a side stream, so that it overlaps hop 2 of the previous call on this lane (the previous pipeline chunk)?
+    const bool overlap = device && comm->relay_overlap && comm->concurrent_hops(channel);
+    const int par = overlap ? L.parity : 0;
+    if (overlap) L.parity ^= 1;
+    RelayBuf &st = L.staging[par];
+    if (int r = relay_reserve(st, M.staging, device, stream)) return r;
+    hipStream_t s1 = stream;
+    if (overlap) {
+        if (!L.side) {
+            HIP_TRY(hipStreamCreateWithFlags(&L.side, hipStreamNonBlocking));
+            for (hipEvent_t *e : {&L.in, &L.hop1, &L.hop2[0], &L.hop2[1]}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        }
+        s1 = L.side;
+        // hop 1 of this call writes the staging buffer that hop 2 of the call before the previous one read
+        if (L.hop2_used[par]) HIP_TRY(hipStreamWaitEvent(s1, L.hop2[par], 0));
+        if (ready) HIP_TRY(hipStreamWaitEvent(s1, ready, 0));
+        else { HIP_TRY(hipEventRecord(L.in, stream)); HIP_TRY(hipStreamWaitEvent(s1, L.in, 0)); }
+    }
     // self block: a local copy, as in every transport
     if (rcount[me]) {
-        if (device) HIP_TRY(hipMemcpyAsync(rb + rdispl[me], sb + sdispl[me], rcount[me], hipMemcpyDeviceToDevice, stream));
+        if (device) HIP_TRY(hipMemcpyAsync(rb + rdispl[me], sb + sdispl[me], rcount[me], hipMemcpyDeviceToDevice, s1));
         else memcpy(rb + rdispl[me], sb + sdispl[me], rcount[me]);
     }
-    std::vector<int> world(n), src(n);
-    for (int y = 0; y < n; y++) world[y] = y;
-    std::vector<size_t> sc(n), sd(n), rc(n), rd(n), stoff(n), stlen(n);
-    auto helper_index = [](int h, int a, int b) { return h - (a < h) - (b < h); };      // position of h among the ranks outside {a, b}
-    for (int k = 1; k <= R; k++) {
-        const int ti = (me + k) % ngroup, si = (me - k + ngroup) % ngroup;
-        const int t = group[ti], s = group[si];
-        const size_t St = scount[ti], Ss = rcount[si];
-        if (M.partner[(size_t)myrank * R + k - 1] != t || M.partner[(size_t)s * R + k - 1] != myrank || M.bytes[(size_t)s * R + k - 1] != Ss) {
-            set_error("relay: the gathered tables do not match this call");
-            return 1;
-        }
-        for (int y = 0; y < n; y++) src[M.partner[(size_t)y * R + k - 1]] = y;
-        // staging: one part from every rank outside {me, s}
-        size_t need = 0;
-        for (int y = 0; y < n; y++) {
-            stoff[y] = stlen[y] = 0;
-            if (y == myrank || y == s) continue;
-            size_t off, len;
-            relay_part(M.bytes[(size_t)y * R + k - 1], n, 2 + helper_index(myrank, y, M.partner[(size_t)y * R + k - 1]), &off, &len);
-            stoff[y] = need;
-            stlen[y] = len;
-            need += (len + 255) & ~(size_t)255;
-        }
-        RelayBuf &st = cache->staging[std::make_pair((void *)stream, channel)];
-        if (int r = relay_reserve(st, need ? need : 256, device, stream)) return r;
-        // ---- phase A ----
-        const char *sbaseA = sb;
-        char *rbaseA = rb < st.p ? rb : st.p;
-        for (int x = 0; x < n; x++) {
-            sc[x] = sd[x] = rc[x] = rd[x] = 0;
-            if (x == myrank) continue;
-            size_t off, len;
-            relay_part(St, n, x == t ? 0 : 2 + helper_index(x, myrank, t), &off, &len);
-            sc[x] = len;
-            sd[x] = sdispl[ti] + off;
-            if (x == s) {
-                relay_part(Ss, n, 0, &off, &len);
-                rc[x] = len;
-                rd[x] = (size_t)((rb + rdispl[si] + off) - rbaseA);
-            } else {
-                rc[x] = stlen[x];
-                rd[x] = (size_t)((st.p + stoff[x]) - rbaseA);
-            }
-        }
-        if (int r = comm->alltoallv(myrank, sbaseA, sc.data(), sd.data(), rbaseA, rc.data(), rd.data(), world.data(), n, myrank, stream, channel)) return r;
-        // ---- phase B ----
-        const char *sbaseB = sb < st.p ? sb : st.p;
-        for (int x = 0; x < n; x++) {
-            sc[x] = sd[x] = rc[x] = rd[x] = 0;
-            if (x == myrank) continue;
-            size_t off, len;
-            if (x == t) {
-                relay_part(St, n, 1, &off, &len);
-                sc[x] = len;
-                sd[x] = (size_t)((sb + sdispl[ti] + off) - sbaseB);
-            } else {
-                const int y = src[x];      // the rank whose message to x I hold a part of (y != me: only t has me as its source)
-                sc[x] = stlen[y];
-                sd[x] = (size_t)((st.p + stoff[y]) - sbaseB);
-            }
-            relay_part(Ss, n, x == s ? 1 : 2 + helper_index(x, s, myrank), &off, &len);
-            rc[x] = len;
-            rd[x] = rdispl[si] + off;
-        }
-        if (int r = comm->alltoallv(myrank, sbaseB, sc.data(), sd.data(), rb, rc.data(), rd.data(), world.data(), n, myrank, stream, channel)) return r;
+    char *const bases[3] = {sb, rb, st.p};
+    auto hop = [&](const std::vector<RelayMeta::Piece> &sp, const std::vector<RelayMeta::Piece> &rp, hipStream_t s, int ch) -> int {
+        std::vector<dfft_xfer> sx(sp.size()), rx(rp.size());
+        for (size_t i = 0; i < sp.size(); i++) sx[i] = dfft_xfer{sp[i].peer, sp[i].layer, bases[sp[i].where] + sp[i].off, sp[i].bytes};
+        for (size_t i = 0; i < rp.size(); i++) rx[i] = dfft_xfer{rp[i].peer, rp[i].layer, bases[rp[i].where] + rp[i].off, rp[i].bytes};
+        return comm->sendrecv_list(myrank, sx.data(), (int)sx.size(), rx.data(), (int)rx.size(), R, s, ch);
+    };
+    comm->counters.relayed++;
+    if (int r = hop(M.sendA, M.recvA, s1, overlap ? channel + 2 : channel)) return r;
+    if (overlap) {
+        HIP_TRY(hipEventRecord(L.hop1, s1));
+        HIP_TRY(hipStreamWaitEvent(stream, L.hop1, 0));
+    }
+    if (int r = hop(M.sendB, M.recvB, stream, channel)) return r;
+    if (overlap) {
+        HIP_TRY(hipEventRecord(L.hop2[par], stream));
+        L.hop2_used[par] = true;
     }
     return 0;
 }
@@ -505,3 +679,40 @@ dfft_comm *make_callback_comm(int nranks, int rank, void *fn, void *user)
 }
 
 }  // namespace dfft
+
+// The schedule as `nlayers` all-to-all-v calls over the whole communicator (transports without a native form).  The pieces of a layer
+// lie in unrelated allocations: the displacements are differences to the lowest address of the layer (flat addressing).
+int dfft_comm::sendrecv_list(int myrank, const dfft_xfer *sends, int ns, const dfft_xfer *recvs, int nr, int nlayers, hipStream_t stream,
+                             int channel)
+{
+    const int n = nranks;
+    std::vector<int> world(n);
+    for (int y = 0; y < n; y++) world[y] = y;
+    std::vector<size_t> sc(n), sd(n), rc(n), rd(n);
+    for (int layer = 0; layer < nlayers; layer++) {
+        const char *smin = nullptr, *rmin = nullptr;
+        for (int i = 0; i < ns; i++)
+            if (sends[i].layer == layer && (!smin || (const char *)sends[i].ptr < smin)) smin = (const char *)sends[i].ptr;
+        for (int i = 0; i < nr; i++)
+            if (recvs[i].layer == layer && (!rmin || (const char *)recvs[i].ptr < rmin)) rmin = (const char *)recvs[i].ptr;
+        std::fill(sc.begin(), sc.end(), 0); std::fill(sd.begin(), sd.end(), 0);
+        std::fill(rc.begin(), rc.end(), 0); std::fill(rd.begin(), rd.end(), 0);
+        for (int i = 0; i < ns; i++)
+            if (sends[i].layer == layer) {
+                if (sends[i].peer < 0 || sends[i].peer >= n || sc[sends[i].peer]) { dfft::set_error("sendrecv_list: two pieces for one peer in one layer"); return 1; }
+                sc[sends[i].peer] = sends[i].bytes;
+                sd[sends[i].peer] = (size_t)((const char *)sends[i].ptr - smin);
+            }
+        for (int i = 0; i < nr; i++)
+            if (recvs[i].layer == layer) {
+                if (recvs[i].peer < 0 || recvs[i].peer >= n || rc[recvs[i].peer]) { dfft::set_error("sendrecv_list: two pieces for one peer in one layer"); return 1; }
+                rc[recvs[i].peer] = recvs[i].bytes;
+                rd[recvs[i].peer] = (size_t)((const char *)recvs[i].ptr - rmin);
+            }
+        static const char none = 0;
+        counters.alltoallv++;
+        if (int r = alltoallv(myrank, smin ? smin : &none, sc.data(), sd.data(), rmin ? const_cast<char *>(rmin) : const_cast<char *>(&none), rc.data(),
+                              rd.data(), world.data(), n, myrank, stream, channel)) return r;
+    }
+    return 0;
+}

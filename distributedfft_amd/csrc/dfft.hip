@@ -990,8 +990,10 @@ static int launch_real(dfft_plan *p, const Launch &L, int mode, const char *in, 
     return 0;
 }
 
+// `ready`: an event recorded when the send data was complete (the producer kernel of this pipeline chunk), if the caller has one:
+// the relay orders its first hop after it instead of after everything on `stream` (comm.hpp)
 static int exchange_tables(dfft_plan *p, int which, const A2A &T, bool forward, const char *send, char *recv,
-                           hipStream_t stream, uint64_t tag = 0)
+                           hipStream_t stream, uint64_t tag = 0, hipEvent_t ready = nullptr)
 {
     const bool first = which == 1;
     const std::vector<int> &grp = first ? p->group1 : p->group2;
@@ -1004,12 +1006,13 @@ static int exchange_tables(dfft_plan *p, int which, const A2A &T, bool forward, 
         if (!p->relay) p->relay = relay_cache_new();
         if (!tag) tag = (uint64_t)(uintptr_t)&T;      // the pipeline's tables live as long as the plan's initialisation
         const int r = forward ? relay_alltoallv(p->comm, p->relay, tag, p->rank, send, T.sc.data(), T.sd.data(), recv, T.rc.data(), T.rd.data(),
-                                                grp.data(), (int)grp.size(), me, stream, channel)
+                                                grp.data(), (int)grp.size(), me, stream, channel, ready)
                               : relay_alltoallv(p->comm, p->relay, tag, p->rank, send, T.rc.data(), T.rd.data(), recv, T.sc.data(), T.sd.data(),
-                                                grp.data(), (int)grp.size(), me, stream, channel);
+                                                grp.data(), (int)grp.size(), me, stream, channel, ready);
         return r ? fail(r, "relay exchange failed: " + g_error) : 0;
     }
     // the inverse all-to-all swaps the send and receive tables (mpicufft_pencil_opt1.cpp:829-830)
+    p->comm->counters.alltoallv++;
     if (forward)
         return p->comm->alltoallv(p->rank, send, T.sc.data(), T.sd.data(), recv, T.rc.data(), T.rd.data(), grp.data(),
                                   (int)grp.size(), me, stream, channel);
@@ -1121,7 +1124,7 @@ static int enqueue_forward(dfft_plan *p, void *out, const void *in)
             EV_RECORD(c, Sc);
             EV_WAIT(c, Sm);
             TRY(span_begin(p, 1, Sm));
-            TRY(exchange_tables(p, 1, pl.f1[c], true, zdst, ysrc, Sm));
+            TRY(exchange_tables(p, 1, pl.f1[c], true, zdst, ysrc, Sm, 0, pipe_event(p, c)));
             TRY(span_end(p, Sm));
             EV_RECORD(C + c, Sm);
         }
@@ -1136,7 +1139,7 @@ static int enqueue_forward(dfft_plan *p, void *out, const void *in)
             EV_RECORD(2 * C + c, Sc);
             EV_WAIT(2 * C + c, Sm2);
             TRY(span_begin(p, 3, Sm2));
-            TRY(exchange_tables(p, 2, pl.f2[c], true, ydst, xsrc, Sm2));
+            TRY(exchange_tables(p, 2, pl.f2[c], true, ydst, xsrc, Sm2, 0, pipe_event(p, 2 * C + c)));
             TRY(span_end(p, Sm2));
             EV_RECORD(3 * C + c, Sm2);
         }
@@ -1202,7 +1205,7 @@ static int enqueue_inverse(dfft_plan *p, void *out, void *in)
             EV_RECORD(c, Sc);
             EV_WAIT(c, Sm2);
             TRY(span_begin(p, 1, Sm2));
-            TRY(exchange_tables(p, 2, pl.i2[c], true, xdst, ysrc, Sm2));    // i2/i1 tables are already in send/recv order
+            TRY(exchange_tables(p, 2, pl.i2[c], true, xdst, ysrc, Sm2, 0, pipe_event(p, c)));    // i2/i1 tables are already in send/recv order
             TRY(span_end(p, Sm2));
             EV_RECORD(C + c, Sm2);
         }
@@ -1218,7 +1221,7 @@ static int enqueue_inverse(dfft_plan *p, void *out, void *in)
             EV_RECORD(2 * C + c, Sc);
             EV_WAIT(2 * C + c, Sm);
             TRY(span_begin(p, 3, Sm));
-            TRY(exchange_tables(p, 1, pl.i1[c], true, ydst, zsrc, Sm));
+            TRY(exchange_tables(p, 1, pl.i1[c], true, ydst, zsrc, Sm, 0, pipe_event(p, 2 * C + c)));
             TRY(span_end(p, Sm));
             EV_RECORD(3 * C + c, Sm);
         }
@@ -1366,7 +1369,7 @@ static int enqueue_partial_forward(dfft_plan *p, void *out, const void *in, int 
         else TRY(launch_real(p, pl.fz[c], 1, I, zdst));
         if (p->P2 > 1) {
             EV_RECORD(c, Sc); EV_WAIT(c, Sm);
-            TRY(exchange_tables(p, 1, pl.f1[c], true, zdst, ysrc, Sm));
+            TRY(exchange_tables(p, 1, pl.f1[c], true, zdst, ysrc, Sm, 0, pipe_event(p, c)));
             EV_RECORD(C + c, Sm);
         }
     }
@@ -1394,7 +1397,7 @@ static int enqueue_partial_inverse(dfft_plan *p, void *out, void *in, int d)
         TRY(launch(p, pl.qy2[c], p->vinv[1], 1, I, ydst));
         if (p->P2 > 1) {
             EV_RECORD(c, Sc); EV_WAIT(c, Sm);
-            TRY(exchange_tables(p, 1, pl.i1[c], true, ydst, zsrc, Sm));
+            TRY(exchange_tables(p, 1, pl.i1[c], true, ydst, zsrc, Sm, 0, pipe_event(p, c)));
             EV_RECORD(C + c, Sm);
         }
     }
@@ -1733,12 +1736,33 @@ int dfft_comm_info(const dfft_comm *comm, int *nranks, int *transport_nranks)
     if (transport_nranks) *transport_nranks = comm->transport_nranks();
     return 0;
 }
+int dfft_comm_set_list_callback(dfft_comm *comm, dfft_sendrecv_list_fn fn, void *user)
+{
+    if (!comm) return fail(ERR_ARG, "null communicator");
+    return callback_comm_set_list(comm, (void *)fn, user) ? fail(ERR_ARG, g_error) : 0;
+}
+int dfft_comm_get_counter(const dfft_comm *comm, const char *name, long *value)
+{
+    if (!comm || !name || !value) return fail(ERR_ARG, "null argument");
+    const std::string k(name);
+    if (k == "alltoallv") *value = comm->counters.alltoallv;
+    else if (k == "list") *value = comm->counters.list;
+    else if (k == "relayed") *value = comm->counters.relayed;
+    else if (k == "relay_meta") *value = comm->counters.relay_meta;
+    else return fail(ERR_ARG, "unknown counter " + k + " (alltoallv, list, relayed, relay_meta)");
+    return 0;
+}
 int dfft_comm_set_option(dfft_comm *comm, const char *key, long value)
 {
     if (!comm || !key) return fail(ERR_ARG, "null communicator or key");
     if (std::string(key) == "relay") {      // handled above the transports (comm.hpp): every transport can relay
         if (value < 0 || value > 3) return fail(ERR_ARG, "relay: 0 off, 1 = exchange 2 (column groups), 2 = exchange 1 (row groups), 3 = both");
         comm->relay = (int)value;
+        return 0;
+    }
+    if (std::string(key) == "relay_overlap") {
+        if (value < 0 || value > 1) return fail(ERR_ARG, "relay_overlap: 0 or 1");
+        comm->relay_overlap = (int)value;
         return 0;
     }
     const int r = comm->set_option(key, value);
@@ -1750,6 +1774,7 @@ int dfft_comm_alltoallv(dfft_comm *comm, int myrank, const void *send, const siz
 {
     if (!comm || !send || !recv || !scounts || !sdispls || !rcounts || !rdispls || !group) return fail(ERR_ARG, "null argument");
     if (ngroup < 1 || me < 0 || me >= ngroup) return fail(ERR_ARG, "bad group");
+    comm->counters.alltoallv++;
     const int r = comm->alltoallv(myrank, send, scounts, sdispls, recv, rcounts, rdispls, group, ngroup, me, (hipStream_t)hip_stream, 0);
     return r ? fail(r, "all-to-all failed: " + g_error) : 0;
 }

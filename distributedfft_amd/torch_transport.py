@@ -44,8 +44,10 @@ class TorchComm:
         self.groups.setdefault(tuple(range(world)), None)
         self.buffers = []
         self.comm = api.Comm.callback(world, rank, self._alltoallv)
+        self.comm.setListCallback(self._sendrecv_list)
         self.calls = 0
         self.p2p_calls = 0
+        self.list_calls = 0
 
     def register(self, tensor):
         """make a tensor's storage known to the pointer -> tensor lookup"""
@@ -90,12 +92,49 @@ class TorchComm:
             t.copy_(h)
         self.p2p_calls += 1
 
+    def _sendrecv_list(self, sends, recvs, stream):
+        """a point-to-point schedule over the whole world in ONE batch (dfft_sendrecv_list_fn: a hop of the two-hop relay -- several
+        pieces per peer, matched in list order at both ends of a link)"""
+        pg = self.groups[tuple(range(self.world))]
+        on_device = bool(self.buffers and self.buffers[0].is_cuda)
+        # gloo moves device tensors in its collectives but not in point-to-point operations: stage those through the host
+        stage = on_device and self.dist.get_backend(pg) == "gloo"
+
+        def run():
+            ops, landed = [], []
+            for peer, ptr, nb in sends:
+                t = self._slice(ptr, nb)
+                ops.append(self.dist.P2POp(self.dist.isend, t.cpu() if stage else t, peer, group=pg))
+            for peer, ptr, nb in recvs:
+                t = self._slice(ptr, nb)
+                if stage:
+                    h = torch.empty(nb, dtype=torch.uint8)
+                    landed.append((t, h))
+                    t = h
+                ops.append(self.dist.P2POp(self.dist.irecv, t, peer, group=pg))
+            if ops:
+                for req in self.dist.batch_isend_irecv(ops):
+                    req.wait()
+            for t, h in landed:
+                t.copy_(h)
+
+        if on_device:
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream or 0)):
+                run()
+        else:
+            run()
+        self.list_calls += 1
+
     def _alltoallv(self, send, sc, sd, recv, rc, rd, group, me, stream):
-        packed = all(sd[q] == sd[q - 1] + sc[q - 1] and rd[q] == rd[q - 1] + rc[q - 1] for q in range(1, len(group)))
-        packed = packed and all(c % 8 == 0 for c in sc + rc) and sum(sc) > 0 and sum(rc) > 0
+        # one all_to_all_single when the peer blocks lie back to back in rank order (every exchange table of a plan: on every rank, so
+        # that all members take the same path -- an empty block is back to back with anything; zero splits are fine)
+        nzs, nzr = [q for q in range(len(group)) if sc[q]], [q for q in range(len(group)) if rc[q]]
+        packed = all(sd[b] == sd[a] + sc[a] for a, b in zip(nzs, nzs[1:])) and all(rd[b] == rd[a] + rc[a] for a, b in zip(nzr, nzr[1:]))
+        packed = packed and all(c % 8 == 0 for c in sc + rc)
         if packed:      # peer blocks back to back in rank order: one all_to_all_single
-            s = self._slice(send + sd[0], sum(sc)).view(torch.int64)
-            r = self._slice(recv + rd[0], sum(rc)).view(torch.int64)
+            first_s, first_r = (nzs or [0])[0], (nzr or [0])[0]
+            s = self._slice(send + sd[first_s], sum(sc)).view(torch.int64)
+            r = self._slice(recv + rd[first_r], sum(rc)).view(torch.int64)
         on_device = bool(self.buffers and self.buffers[0].is_cuda)
 
         def run():

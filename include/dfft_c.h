@@ -79,6 +79,15 @@ typedef int (*dfft_alltoallv_fn)(void *user, const void *sendbuf, const size_t *
                                  const size_t *rdispls, const int *group, int ngroup, int me,
                                  void *stream);
 
+/* Optional second callback of a callback communicator: a schedule of point-to-point pieces over the WHOLE communicator as one
+ * grouped operation (the two hops of the relay, see "relay" below: several pieces per peer, not back to back).  Piece i of the send
+ * list goes to global rank speer[i], piece j of the receive list comes from rpeer[j]; pointers are absolute; the pieces between two
+ * ranks appear in the same order at both ends (match them in that order: grouped ncclSend / ncclRecv, torch.distributed
+ * batch_isend_irecv, MPI_Isend / MPI_Irecv with the position as the tag).  Must return 0 on success.  Without it the library runs a
+ * schedule as group_size - 1 all-to-all-v callbacks. */
+typedef int (*dfft_sendrecv_list_fn)(void *user, int nsend, const int *speer, void *const *sptr, const size_t *sbytes, int nrecv,
+                                     const int *rpeer, void *const *rptr, const size_t *rbytes, void *stream);
+
 /* nranks virtual ranks inside this process sharing the current device; each rank's exec must be
  * called from its own host thread (they meet in a barrier like MPI ranks would). */
 int dfft_comm_create_local(int nranks, dfft_comm **world);
@@ -88,14 +97,21 @@ int dfft_rccl_unique_id(void *id128);
 int dfft_comm_create_rccl(const void *id128, int nranks, int rank, dfft_comm **comm);
 /* caller-supplied exchange (e.g. torch.distributed.all_to_all_single, MPI_Alltoallv) */
 int dfft_comm_create_callback(int nranks, int rank, dfft_alltoallv_fn fn, void *user, dfft_comm **comm);
+int dfft_comm_set_list_callback(dfft_comm *comm, dfft_sendrecv_list_fn fn, void *user);
 /* nranks = the size the communicator was created with; transport_nranks = what the transport itself reports
  * (ncclCommCount for the RCCL transport, 0 for the others), so that a caller can verify that RCCL really
  * spans the ranks it claims */
 int dfft_comm_info(const dfft_comm *comm, int *nranks, int *transport_nranks);
+/* What went through a communicator since it was made: "alltoallv" (all-to-all-v operations of the transport: the direct exchanges, the
+ * relay's table gathers, the layers of a schedule on a transport without a native form), "list" (native point-to-point schedules:
+ * one per hop of a relayed exchange), "relayed" (relayed exchanges), "relay_meta" (table gathers: one per exchange table).  A relayed
+ * exchange of one pipeline chunk is 2 "list" operations on the RCCL, the local-world and the torch transport. */
+int dfft_comm_get_counter(const dfft_comm *comm, const char *name, long *value);
 /* transport knobs.  "dup_channel" = 1 (RCCL transport only; COLLECTIVE -- every rank of the communicator calls it at
  * the same point): duplicate the communicator (ncclCommSplit) for the second exchange of pencil plans, so that the row-
  * and the column-group exchange -- which use disjoint xGMI links -- may be on the wire at the same time; without it one
- * ncclComm serialises them.  Replaces nothing in the reference (its two MPI sub-communicators are independent by
+ * ncclComm serialises them.  "dup_channel" = 3: two more duplicates for the relay's first hop of either exchange, which then
+ * overlaps the second hop of the previous pipeline chunk ("relay_overlap").  Replaces nothing in the reference (its two MPI sub-communicators are independent by
  * construction, src/pencil/mpicufft_pencil_opt1.cpp:103-104).
  * "self_send" = 1 (RCCL transport, testing): a rank's own block goes through ncclSend / ncclRecv to itself instead of a device
  * copy, so that a single-GPU box can hand caller buffers (virtual-memory ranges from dfft_malloc included) to RCCL.
@@ -103,8 +119,11 @@ int dfft_comm_info(const dfft_comm *comm, int *nranks, int *transport_nranks);
  * exec): two-hop relay of the group exchanges.  bit 0 = exchange 2 (column groups), bit 1 = exchange 1 (row groups).  xGMI is
  * point to point, so the column groups of a 2 x 4 pencil grid move half of the volume over ONE of a GPU's seven links; with the
  * relay a message is cut into nranks parts, two travel directly and each of the others through one of the ranks outside the
- * pair, as two world-wide all-to-alls (all links equally loaded in both; 1 GiB: 7.0 -> 1.75 ms at 153 GB/s per link).  The bytes
- * land exactly where the direct exchange puts them.  The reference's answer to its slow exchanges was per-peer overlap
+ * pair.  All partners of an exchange travel together: TWO grouped transport operations per exchange and pipeline chunk (hop 1: every
+ * link carries one part of each of the rank's messages; hop 2: the second direct parts and everything staged goes on to its
+ * destination), all links equally loaded in both (1 GiB over one link: 7.0 -> 1.75 ms at 153 GB/s per link).  The bytes
+ * land exactly where the direct exchange puts them.  "relay_overlap" = 1 (default) / 0: hop 1 of a pipeline chunk runs on a side
+ * stream (on the RCCL transport: on its own communicator if "dup_channel" = 3 made one) under hop 2 of the chunk before it.  The reference's answer to its slow exchanges was per-peer overlap
  * (src/pencil/mpicufft_pencil_opt1.cpp:1116-1275); this is the xGMI analogue.  Default off.
  * Returns 0, or nonzero for an unknown key / a failure. */
 int dfft_comm_set_option(dfft_comm *comm, const char *key, long value);

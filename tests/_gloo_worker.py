@@ -151,17 +151,21 @@ def main():
     want = np.fft.fftn(g)[:, ost[1]:ost[1] + yo, ost[2]:ost[2] + zs]
     err = np.max(np.abs(got - want)) / np.max(np.abs(want))
     assert err < 1e-12, err
-    # a relayed exchange (group = a strict subset of the world) is one table gather at its first use plus two world-wide
-    # all-to-alls per partner, whose pieces are not back to back (the transport's per-peer path)
+    # a relayed exchange (group = a strict subset of the world) is one table gather at its first use (an all-to-all-v) plus TWO
+    # point-to-point schedules -- hop 1 and hop 2, all partners together -- whatever the group size
     def ncalls(bit, ng):
         if ng <= 1:
             return 0, 0
         if relay & bit and ng < world:
-            return 1 + 2 * (ng - 1), 2 * (ng - 1)
+            return 1, 2
         return 1, 0
-    c2, p2 = ncalls(1, P1)
-    c1, p1 = ncalls(2, P2)
-    assert tc.calls == c2 + 2 * c1 and tc.p2p_calls == p2 + 2 * p1, (tc.calls, tc.p2p_calls, c2, c1, p2, p1)
+    c2, l2 = ncalls(1, P1)
+    c1, l1 = ncalls(2, P2)
+    assert tc.calls == c2 + 2 * c1 and tc.p2p_calls == 0 and tc.list_calls == l2 + 2 * l1, (tc.calls, tc.p2p_calls, tc.list_calls, c2, c1, l2, l1)
+    cnt = tc.comm.counters()
+    nrel = (1 if l2 else 0) + (2 if l1 else 0)
+    assert cnt["relayed"] == nrel and cnt["list"] == 2 * nrel and cnt["relay_meta"] == nrel, cnt
+    assert cnt["alltoallv"] == tc.calls, (cnt, tc.calls)
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank} ok err={err:.2e}")

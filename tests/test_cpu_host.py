@@ -480,9 +480,10 @@ def test_bench_xgmi_model_with_the_relay():
     spec.loader.exec_module(bench)
     m = bench.xgmi_model(16, 1024, 8, 2, 4)
     assert m["exchange 2"]["links"] == 1 and abs(m["exchange 2"]["predicted_ms"] - 7.018) < 0.01
-    assert m["exchange 2"]["relay"] == {"links": 7, "phases": 2, "bytes_per_link_per_phase": 2 ** 27, "predicted_ms": 1.754}
+    assert m["exchange 2"]["relay"] == {"links": 7, "phases": 2, "pieces_per_link_per_phase": 1, "bytes_per_link_per_phase": 2 ** 27, "predicted_ms": 1.754}
     assert m["exchange 1"]["links"] == 3 and abs(m["exchange 1"]["predicted_ms"] - 3.509) < 0.01
-    assert m["exchange 1"]["relay"]["phases"] == 6 and abs(m["exchange 1"]["relay"]["predicted_ms"] - 2.632) < 0.01
+    assert m["exchange 1"]["relay"]["phases"] == 2 and m["exchange 1"]["relay"]["pieces_per_link_per_phase"] == 3
+    assert abs(m["exchange 1"]["relay"]["predicted_ms"] - 2.632) < 0.01
     s = bench.xgmi_model(16, 1024, 8, 8, 1)
     assert list(s) == ["exchange 2"] and "relay" not in s["exchange 2"] and s["exchange 2"]["links"] == 7
     assert bench.choose_partition(8, "auto") == (2, 4) and bench.choose_partition(4, "auto") == (2, 2) and bench.choose_partition(2, "auto") == (2, 1)

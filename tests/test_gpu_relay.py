@@ -1,6 +1,6 @@
 """Two-hop relay of the group exchanges (include/dfft_c.h: dfft_comm_set_option "relay"; csrc/comm.hip relay_alltoallv) on
 virtual ranks of one GPU: every message is cut into nranks parts, two travel directly and the others through the ranks outside
-the pair, as two world-wide all-to-alls per partner.  The bytes must land exactly where the direct exchange puts them, so the
+the pair; all partners travel together, as two grouped send/receive schedules per exchange (hop 1, hop 2).  The bytes must land exactly where the direct exchange puts them, so the
 spectrum and the round trip are BIT-identical to the direct run -- on even and uneven splits, pipeline depths 1-4, groups of
 2, 3 and 4, C2C and R2C.  The reference's counterpart is its per-peer overlap (src/pencil/mpicufft_pencil_opt1.cpp:1116-1275);
 the multi-process form of the same layer runs over gloo in tests/test_cpu_multiprocess.py."""
@@ -63,3 +63,46 @@ def test_relay_leaves_whole_world_groups_alone():
     _, _, spec_r, backs_r = run_distributed(shape, 4, 1, "double", comm_options={"relay": 3})
     for r in range(4):
         assert np.array_equal(spec_d[r], spec_r[r]) and np.array_equal(backs_d[r], backs_r[r])
+
+
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_relay_is_two_grouped_operations_per_exchange_and_chunk(overlap):
+    """all partners of a relayed exchange travel together: hop 1 and hop 2 are ONE point-to-point schedule each (dfft_comm_get_counter
+    "list"), whatever the group size -- exchange 1 of a 2 x 4 grid has three partners per rank -- plus one table gather (an
+    all-to-all-v) per exchange table at its first use.  relay_overlap = 1 runs hop 1 of a chunk on the relay's side stream under hop 2
+    of the chunk before (double-buffered staging); both settings are bit-identical to the direct exchange."""
+    shape, P1, P2, chunks = (66, 50, 38), 2, 4, 3
+    plans, ins, spec_d, backs_d = run_distributed(shape, P1, P2, "double", chunks=chunks)
+    plans_r, _, spec_r, backs_r = run_distributed(shape, P1, P2, "double", chunks=chunks, comm_options={"relay": 3, "relay_overlap": overlap})
+    for r in range(P1 * P2):
+        assert np.array_equal(spec_d[r], spec_r[r]) and np.array_equal(backs_d[r], backs_r[r])
+    cnt = plans_r[0].comm.counters()      # one communicator, shared by the 8 virtual ranks
+    per_rank = 2 * 2 * chunks             # (exchange 1 + exchange 2) x (forward + inverse) x chunks
+    assert cnt["relayed"] == 8 * per_rank and cnt["list"] == 2 * cnt["relayed"], cnt
+    assert cnt["relay_meta"] == 8 * per_rank and cnt["alltoallv"] == cnt["relay_meta"], cnt
+    assert plans[0].comm.counters() == {"alltoallv": 8 * per_rank, "list": 0, "relayed": 0, "relay_meta": 0}
+    # a second transform gathers nothing again
+    from concurrent.futures import ThreadPoolExecutor
+    outs = [torch.zeros(pl.getDomainSize() // 16, dtype=torch.complex128, device="cuda") for pl in plans_r]
+    tin = [torch.from_numpy(x).cuda() for x in ins]
+    with ThreadPoolExecutor(8) as ex:
+        list(ex.map(lambda r: plans_r[r].execC2C(outs[r], tin[r], dfft.FORWARD), range(8)))
+    torch.cuda.synchronize()
+    cnt2 = plans_r[0].comm.counters()
+    assert cnt2["relay_meta"] == cnt["relay_meta"] and cnt2["list"] == cnt["list"] + 8 * 2 * 2 * chunks, (cnt, cnt2)
+    for r, pl in enumerate(plans_r):
+        s = pl.getOutSize()
+        assert np.array_equal(outs[r][:s[0] * s[1] * s[2]].cpu().numpy().reshape(s), spec_d[r])
+
+
+def test_relay_overlap_option_values():
+    world = dfft.Comm.local(4)
+    for v in (0, 1):
+        world.setOption("relay_overlap", v)
+    with pytest.raises(dfft.DfftError, match="relay_overlap"):
+        world.setOption("relay_overlap", 2)
+    with pytest.raises(dfft.DfftError, match="counter"):
+        import ctypes as C
+        from distributedfft_amd._lib import check, lib
+        v = C.c_long(0)
+        check(lib().dfft_comm_get_counter(world._h, b"nonsense", C.byref(v)))
