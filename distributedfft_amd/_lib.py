@@ -64,6 +64,7 @@ SYMBOLS = [
     ("dfft_get_in_start", _i, [_vp, _psz]),
     ("dfft_get_out_size", _i, [_vp, _psz]),
     ("dfft_get_out_start", _i, [_vp, _psz]),
+    ("dfft_get_out_strides", _i, [_vp, _psz]),
     ("dfft_get_partition_dimensions", _i, [_vp, _i, _i, _psz, _psz, _sz, _psz]),
     ("dfft_domain_size", _sz, [_vp]),
     ("dfft_work_size_device", _sz, [_vp]),

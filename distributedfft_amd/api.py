@@ -369,6 +369,17 @@ class MPIcuFFT:
     def getOutStart(self):
         return self._get3(lib().dfft_get_out_start)
 
+    def getOutStrides(self):
+        """element strides of the spectrum block along (kx, ky_local, kz_local) (dfft_get_out_strides): (yo*zs, zs, 1) for the
+        reference's [Nx][yo][zs], (1, zs*Nx, Nx) with setOption("spectral_layout", 1)"""
+        return self._get3(lib().dfft_get_out_strides)
+
+    def spectrumView(self, out):
+        """the spectrum block held by the torch tensor `out` as a (Nx, yo, zs) view, whatever the plan's spectral layout -- pointwise
+        work on it (a Laplacian, a filter: the reference's testcase 4) is layout-independent"""
+        n, st = self.getOutSize(), self.getOutStrides()
+        return out.reshape(-1).as_strided(tuple(n), tuple(st))
+
     def getPartitionDimensions(self):
         """(input_dim, transposed_dim, output_dim) of include/mpicufft_pencil.hpp:112-116, each a
         Partition_Dimensions with size_x/y/z and start_x/y/z lists (include/params.hpp:58-81)"""

@@ -339,6 +339,9 @@ struct Options {
     int native_mixed = 1;    // lengths 2^a 3^b 5^c 7^d with a configuration run the native chain (0: Bluestein, for A/B runs and tests)
     int two_level = 0;       // 1: every axis whose length splits as N1*N2 runs as a two-level line (tests, A/B runs; 0: only lengths
                              // that have no other plan)
+    int spectral = 0;        // 1: the spectrum is kept x-contiguous, [yo][zs][Nx] (lines along kx natural), instead of the reference's
+                             // [Nx][yo][zs]: the forward x pass stores natural lines and the inverse x pass loads them -- neither
+                             // touches the point-major layout whose strided read is the slowest pass of every multi-rank plan
     int order[6] = {-1, -1, -1, -1, -1, -1};     // workgroup->tile order per pass: fz fy fx ix iy iz; a_fastest + 2*xcd_swizzle
     int variant[6] = {-1, -1, -1, -1, -1, -1};   // kernel configuration per pass, same order (-1 = the plan's choice)
 };
@@ -349,6 +352,7 @@ struct dfft_plan {
     dfft_comm *comm = nullptr;
     int rank = 0, nranks = 1;
     bool initialized = false, c2c = false;
+    bool spectral_mirror = false;   // one rank with an x-contiguous spectrum (option spectral_layout): the inverse runs the mirrored pass order
     bool zyx = false;            // slab sequence Z_Then_YX: input split along x, output split along z
     bool yzx = false;            // slab sequence Y_Then_ZX: R2C along y, output [Nx][(Ny/2+1)/P][Nz], forward only
     size_t Nyc = 0;              // y extent of the spectrum (Ny/2+1 for a Y_Then_ZX R2C plan, else Ny)
@@ -462,6 +466,11 @@ static int build_pipeline(dfft_plan *p, Pipeline &pl)
         // neighbouring tiles along z' share cache lines whenever the pitch zs is not a multiple of the
         // tile; keeping consecutive tiles on one XCD lets its L2 merge them (R2C, 513-wide: 6.3 -> 4.5 ms)
         X.a_fastest = 0; X.xcd_swizzle = 1;
+        if (p->opt.spectral) {
+            // x-contiguous spectrum [ky][kz'][kx]: natural lines out (a = ky, lines of a slice = kz'), no point-major store
+            X.store_kind = STORE_LINES;
+            X.KS_out = 0; X.AS_out = 0;
+        } else
         set_shift(p, X);
         // segments of the x axis, ascending: peer q major, chunk c minor
         std::vector<size_t> r2c_of(C, 0);
@@ -529,6 +538,13 @@ static int build_pipeline(dfft_plan *p, Pipeline &pl)
             L.args.xcd_swizzle = 1;
             L.args.a_fastest = zs % TL == 0 ? 1 : 0;
             L.in_off = e * k0[c] * zs;
+            if (p->opt.spectral) {
+                // x-contiguous spectrum: natural lines in, [ky][kz'][kx], this chunk's ky rows first
+                L.args.load_kind = LOAD_LINES;
+                L.args.KS_in = 0; L.args.AS_in = 0;
+                L.args.a_fastest = 0;
+                L.in_off = e * k0[c] * zs * Nx;
+            }
             for (int q = 0; q < P1; q++) seg_push(L.sseg, p->xstart[q], p->xs[q], S2i + p->xstart[q] * zs * kl[c]);
             L.args.LA = (uint32_t)kl[c];
         }
@@ -792,7 +808,7 @@ static int build_pipeline_single(dfft_plan *p, Pipeline &pl)
     // its contiguous 128 KiB read (8 lines from 8 x planes instead): 1024^3 fp64 38.0-38.8 vs 37.5 ms per step, fp32 21.4
     // vs 20.1, 2048^3 fp32 181 vs 192 ms
     const int order = p->opt.single_order >= 0 ? p->opt.single_order : (p->prec == DFFT_F32 && Nx >= 2048 && Ny >= 2048 ? 1 : 0);
-    if (p->nranks != 1 || !p->c2c || p->zyx || p->yzx || !order) return 0;
+    if (p->nranks != 1 || !p->c2c || p->zyx || p->yzx || !order || p->opt.spectral) return 0;
     const size_t nb = (Nz + TL - 1) / TL;
     const size_t pad = (size_t)std::max(0, p->opt.single_pad) / p->esz;      // elements
     pl.sz = Launch(); pl.sx = Launch(); pl.sy = Launch();
@@ -1098,7 +1114,7 @@ static int enqueue_forward(dfft_plan *p, void *out, const void *in)
 {
     if (p->zyx) return enqueue_forward_zyx(p, out, in);
     if (p->yzx) return enqueue_forward_yzx(p, out, in);
-    if (p->pl.single && !p->opt.mirror) return enqueue_single(p, out, in, 0);
+    if (p->pl.single && !p->opt.mirror && !p->spectral_mirror) return enqueue_single(p, out, in, 0);
     Pipeline &pl = p->pl;
     const int C = pl.C;
     char *A = static_cast<char *>(out), *W = static_cast<char *>(p->work_d);
@@ -1168,7 +1184,7 @@ static int enqueue_inverse(dfft_plan *p, void *out, void *in)
 {
     if (p->zyx) return enqueue_inverse_zyx(p, out, in);
     if (p->yzx) return fail(ERR_UNSUPPORTED, "the Y_Then_ZX sequence is forward only (as in the reference)");
-    if (p->pl.single && !p->opt.mirror) return enqueue_single(p, out, in, 1);
+    if (p->pl.single && !p->opt.mirror && !p->spectral_mirror) return enqueue_single(p, out, in, 1);
     Pipeline &pl = p->pl;
     const int C = pl.C;
     char *I = static_cast<char *>(in), *W = static_cast<char *>(p->work_d), *O = static_cast<char *>(out);
@@ -1180,7 +1196,7 @@ static int enqueue_inverse(dfft_plan *p, void *out, void *in)
     hipStream_t Sc = p->stream, Sm = pl.comm_stream;
     hipStream_t Sm2 = (pl.comm_stream2 && p->comm && p->comm->concurrent_channels()) ? pl.comm_stream2 : Sm;
     p->nspans = 0; p->last_dir = DFFT_INVERSE;
-    if (p->nranks == 1 && p->c2c && !p->opt.mirror) {
+    if (p->nranks == 1 && p->c2c && !p->opt.mirror && !p->spectral_mirror) {
         // single rank, complex: input and output are both natural [x][y][z], so the inverse may use
         // the forward pass order (z, y, x) with conjugation -- it avoids the strided *read* of the
         // x-first order (the fft3d branch of the reference is one cuFFT plan, order is not observable)
@@ -1823,6 +1839,7 @@ static int *option_slot(Options &o, const std::string &k)
     if (k == "single_pad") return &o.single_pad;
     if (k == "native_mixed") return &o.native_mixed;
     if (k == "graph") return &o.graph;
+    if (k == "spectral_layout") return &o.spectral;
     for (int i = 0; i < 6; i++) {
         if (k == std::string("variant_") + kPassNames[i]) return &o.variant[i];
         if (k == std::string("order_") + kPassNames[i]) return &o.order[i];
@@ -1967,6 +1984,10 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         if (C < 1) C = 1;
         p->pl.C = C;
     }
+    if (p->opt.spectral && (zyx || yzx)) return fail(ERR_UNSUPPORTED, "spectral_layout: pencil and default slab plans only (not the Z_Then_YX / Y_Then_ZX sequences)");
+    if (p->opt.spectral && p->opt.spectral != 1) return fail(ERR_ARG, "spectral_layout: 0 = the reference's [Nx][yo][zs], 1 = x-contiguous [yo][zs][Nx]");
+    // (one rank: the inverse of an x-contiguous spectrum cannot be the forward launches with conjugation -- their input is the natural grid)
+    p->spectral_mirror = p->opt.spectral && p->nranks == 1;
     TRY(zyx ? build_pipeline_zyx(p, p->pl) : yzx ? build_pipeline_yzx(p, p->pl) : build_pipeline(p, p->pl));
     TRY(build_pipeline_single(p, p->pl));
     if (p->pl.single) {
@@ -2013,6 +2034,10 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
             if (p->c2c) p->vfwd[0] = p->vinv[0] = zrole;
             // the inverse y pass stores tiled-transpose chunks (1 KiB runs)
             if (has64(p->ax[1], ROLE_STREAM)) p->vinv[1] = ROLE_STREAM;
+            if (p->opt.spectral) {      // x passes with natural lines on one side, like the complex z passes
+                const int xrole = has64(p->ax[2], ROLE_LINES) ? ROLE_LINES : has64(p->ax[2], ROLE_STREAM) ? ROLE_STREAM : ROLE_DEFAULT;
+                p->vfwd[2] = p->vinv[2] = xrole;
+            }
         } else {
             if (p->c2c && has32(p->ax[0], ROLE_NATURAL_LOAD)) p->vfwd[0] = ROLE_NATURAL_LOAD;
             if (p->c2c && has32(p->ax[0], ROLE_NATURAL_STORE)) p->vinv[0] = ROLE_NATURAL_STORE;
@@ -2022,6 +2047,11 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
             // has such a configuration (2048 points: 4.80 -> 3.63 ms on rank 0 of 2 x 4 at 2048^3)
             // (a single rank's complex inverse runs the forward launches: there vinv is not used)
             if (has32(p->ax[1], ROLE_TRANSPOSED_STORE)) p->vinv[1] = ROLE_TRANSPOSED_STORE;
+            if (p->opt.spectral) {      // x-contiguous spectrum: the forward x pass stores natural lines like the inverse z pass
+                if (has32(p->ax[2], ROLE_NATURAL_STORE)) p->vfwd[2] = ROLE_NATURAL_STORE;
+                // (its inverse loads natural lines and stores same-tile blocks: no configuration has that pair of mappings --
+                // point fastest for the first pass only -- so it keeps the tiled one; dfft_tune_variants measures the others)
+            }
             // (The inverse y pass stores transposed tiles, which a line-fastest fp32 wave -- 16 lines x 4 points -- writes in 32-byte
             // pieces.  A point-fastest store mapping, PassCfg::MAP = 2, writes whole lines and was measured: 1024 points 4.42 vs 4.30 ms,
             // 2048 points 10.55 vs 10.35, no better -- L2 merges the pieces; profiles/r3_f32_inverse_y_point_fastest_store.txt.)
@@ -2271,6 +2301,15 @@ int dfft_get_out_start(const dfft_plan *p, size_t s[3])
     if (!p || !p->initialized) return fail(ERR_STATE, "plan not initialised");
     s[0] = 0; s[1] = p->yostart[p->pi]; s[2] = p->zstart[p->pj];
     if (p->zyx) { s[1] = 0; s[2] = p->zstart[p->pi]; }
+    return 0;
+}
+int dfft_get_out_strides(const dfft_plan *p, size_t s[3])
+{
+    if (!p || !p->initialized) return fail(ERR_STATE, "plan not initialised");
+    size_t n[3];
+    (void)dfft_get_out_size(p, n);
+    if (p->opt.spectral) { s[0] = 1; s[1] = n[2] * n[0]; s[2] = n[0]; }      // [yo][zs][Nx]
+    else { s[0] = n[1] * n[2]; s[1] = n[2]; s[2] = 1; }                       // [Nx][yo][zs] (and the slab sequences' [Nx][Ny][zs], [Nx][yo][Nz])
     return 0;
 }
 int dfft_get_partition_dimensions(const dfft_plan *p, int which, int axis, size_t *sizes, size_t *starts, size_t capacity,
@@ -2594,7 +2633,7 @@ static int tune_variants(dfft_plan *p, const void *in, void *o, void *b, float &
 {
     if (p->zyx || p->yzx) return 0;                 // the slab sequences keep their rules
     Pipeline &pl = p->pl;
-    const bool shared = p->nranks == 1 && !p->opt.mirror && p->c2c;      // a single rank's complex inverse runs the forward launches
+    const bool shared = p->nranks == 1 && !p->opt.mirror && !p->spectral_mirror && p->c2c;      // a single rank's complex inverse runs the forward launches
     const bool single = pl.single && shared;                            // ... in the z, x, y order (three launches)
     std::vector<Launch> *vecs[6] = {&pl.fz, &pl.fy, nullptr, &pl.ix, &pl.iy, &pl.iz};
     auto launches = [&](int k, const std::function<void(Launch &)> &f) {

@@ -176,6 +176,13 @@ int dfft_get_pipeline_chunks(const dfft_plan *plan);
  *   "single_order"     one rank, complex plan: 1 = pass order z, x, y through a padded private layout, 0 = z, y, x, -1 (default)
  *                      = where it measured faster (env default DFFT_SINGLE_ORDER); "single_layout" (0 | 1) and "single_pad"
  *                      (bytes) shape that layout
+ *   "spectral_layout"  0 (default): the spectrum has the reference's layout [Nx][yo][zs] (include/mpicufft_pencil.hpp:94-122).  1: it is kept
+ *                      x-contiguous, [yo][zs][Nx] -- entry (kx, ky, kz') at kx + Nx * (kz' + zs * ky), dfft_get_out_strides -- so
+ *                      that the forward x pass stores natural lines and the inverse x pass loads them: neither touches the
+ *                      point-major layout, whose strided read (16-byte points Nx rows apart) is the slowest pass of every multi-rank
+ *                      plan.  For callers that go forward -> pointwise work on the spectrum -> inverse (the reference's testcase 4,
+ *                      tests/src/pencil/random_dist_3D.cu:748-793, does exactly that) and can index through the strides.
+ *                      getOutSize / getOutStart / the exchange tables are unchanged.  Pencil and default slab plans, any rank count.
  *   "graph"            1: a single-rank plan replays the kernel launches of an exec as one hipGraph from the second call
  *                      with the same (operation, in, out) on; 0 (default): plain launches -- measured 6-8 us faster per
  *                      exec on ROCm 7.2 (profiles/r2_graph_latency.txt)
@@ -226,6 +233,10 @@ int dfft_get_out_start(const dfft_plan *plan, size_t start[3]);
  * which = 0 input_dim, 1 transposed_dim, 2 output_dim; axis = 0 x, 1 y, 2 z.  Writes the per-rank extents and
  * offsets of that axis at that stage (one entry = the full extent when the axis is not split there); *count
  * receives the number of entries, at most `capacity` are written (sizes/starts may be NULL to query). */
+/* element strides of the spectrum block in `out` along (kx, ky_local, kz_local): entry (kx, ky, kz) of the block dfft_get_out_size
+ * describes lives at kx * s[0] + ky * s[1] + kz * s[2].  {yo * zs, zs, 1} for the reference layout, {1, zs * Nx, Nx} with option
+ * "spectral_layout" = 1. */
+int dfft_get_out_strides(const dfft_plan *plan, size_t s[3]);
 int dfft_get_partition_dimensions(const dfft_plan *plan, int which, int axis, size_t *sizes, size_t *starts,
                                   size_t capacity, size_t *count);
 /* getDomainSize / getWorkSizeDevice / getWorkSizeHost / getRank / getWorldSize

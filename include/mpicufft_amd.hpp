@@ -220,6 +220,14 @@ public:
     {
         if (plan_) check(dfft_tune_placement(plan_, in, tries, out, back, nullptr, 0, nullptr));
     }
+    // extensions (no counterpart in the reference).  setOption: the engine's knobs by name (dfft_set_option; before initFFT), e.g.
+    // setOption("spectral_layout", 1) keeps the spectrum x-contiguous, [yo][zs][Nx]: getOutStrides gives the element strides of
+    // (kx, ky, kz) in `out` for whichever layout is in use.  allocate / release: device memory on the library's default backing
+    // (dfft_malloc(DFFT_CHUNK_DEFAULT)) for `out` and the inverse's output -- a hipMalloc'ed target costs the scatter passes ~10 %.
+    void setOption(const char *key, long value) { if (plan_) check(dfft_set_option(plan_, key, value)); }
+    inline void getOutStrides(size_t *ostrides) { if (plan_) check(dfft_get_out_strides(plan_, ostrides)); }
+    static void *allocate(size_t bytes) { void *ptr = nullptr; check(dfft_malloc(bytes, DFFT_CHUNK_DEFAULT, &ptr)); return ptr; }
+    static void release(void *ptr) { check(dfft_free(ptr)); }
     // the section timer of the reference's classes (include/mpicufft_pencil.hpp:263-287, include/mpicufft_slab.hpp:208-222):
     // one block of the CSV per exec* once the warm-up rounds are used up
     Timer *getTimer() const { return timer; }

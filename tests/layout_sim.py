@@ -127,6 +127,8 @@ class World:
         # a work-area slice may be larger than the domain (padded private layouts of the single-rank z, x, y order)
         self.wel = [max(pl.getDomainSize(), pl.getWorkSizeDevice() // max(1, (self.P1 > 1) + (self.P2 > 1) + 1)) // self.esz for pl in self.plans]
         self.single = self.P == 1 and self.plans[0].debugPass("sz") is not None
+        # option spectral_layout: the spectrum stays x-contiguous and a single rank's inverse runs the mirrored pass order (dfft_init)
+        self.spectral = bool((options or {}).get("spectral_layout", 0))
 
     def buffers(self, n=3):
         return [[np.full(self.wel[r], np.nan + 0j, dtype=np.complex128) for _ in range(n)] for r in range(self.P)]
@@ -223,7 +225,7 @@ class World:
                 p.d.swap = 1
                 p.run(src, dst, N)
             return outs
-        if kind == "default" and self.P == 1 and self.c2c:
+        if kind == "default" and self.P == 1 and self.c2c and not self.spectral:
             # single rank, complex: forward pass order with conjugation (enqueue_inverse fast path)
             pl = pls[0]
             for name, src, dst, N in (("fz", spec[0], W[0][0], Nz), ("fy", W[0][0], spec[0], Ny), ("fx", spec[0], outs[0], Nx)):

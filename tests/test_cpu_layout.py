@@ -56,6 +56,41 @@ def test_default_sequence_descriptors(shape, P1, P2, c2c, chunks):
     check_round_trip(w, w.inverse(outs), ins)
 
 
+@pytest.mark.parametrize("chunks", [1, 3])
+@pytest.mark.parametrize("c2c", [True, False])
+@pytest.mark.parametrize("shape,P1,P2", DEFAULT)
+def test_x_contiguous_spectrum_descriptors(shape, P1, P2, c2c, chunks):
+    """option spectral_layout = 1: the forward x pass stores natural lines -- the spectrum block is [yo][zs][Nx], entry (kx, ky, kz) at
+    the strides dfft_get_out_strides reports -- and the inverse x pass loads them; sizes, starts and exchange tables are the
+    reference's.  One rank: the inverse runs the mirrored pass order."""
+    w = World(dfft.MPIcuFFT_Pencil_Opt1, shape, P1, P2, c2c, chunks, options={"spectral_layout": 1})
+    ref = World(dfft.MPIcuFFT_Pencil_Opt1, shape, P1, P2, c2c, chunks)
+    g = global_field(shape, c2c)
+    ins = local_inputs(w, g)
+    outs = w.forward(ins)
+    want = np.fft.fftn(g) if c2c else np.fft.rfftn(g)
+    scale = np.max(np.abs(want))
+    for pl, rp, out in zip(w.plans, ref.plans, outs):
+        s, o, st = pl.getOutSize(), pl.getOutStart(), pl.getOutStrides()
+        assert (s, o) == (rp.getOutSize(), rp.getOutStart()) and pl.getDomainSize() == rp.getDomainSize()
+        assert pl.getExchangeTables(1) == rp.getExchangeTables(1) and pl.getExchangeTables(2) == rp.getExchangeTables(2)
+        assert st == (1, s[2] * s[0], s[0]) and rp.getOutStrides() == (s[1] * s[2], s[2], 1)
+        got = np.lib.stride_tricks.as_strided(out, shape=s, strides=tuple(16 * v for v in st))
+        assert np.max(np.abs(got - want[o[0]:o[0] + s[0], o[1]:o[1] + s[1], o[2]:o[2] + s[2]])) / scale < 1e-12
+    check_round_trip(w, w.inverse(outs), ins)
+
+
+def test_x_contiguous_spectrum_is_for_the_default_sequences():
+    pl = dfft.MPIcuFFT_Slab_Z_Then_YX(dfft.Configurations(), dfft.Comm.local(2), precision="double", rank=0)
+    pl.setOption("spectral_layout", 1)
+    with pytest.raises(dfft.DfftError, match="spectral_layout"):
+        pl.initFFT(dfft.GlobalSize(8, 8, 8), dfft.Partition(2, 1), allocate=False, c2c=True)
+    pl = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), None, precision="double", rank=0)
+    pl.setOption("spectral_layout", 2)
+    with pytest.raises(dfft.DfftError, match="spectral_layout"):
+        pl.initFFT(dfft.GlobalSize(8, 8, 8), dfft.Partition(1, 1), allocate=False, c2c=True)
+
+
 @pytest.mark.parametrize("chunks", [1, 2])
 @pytest.mark.parametrize("c2c", [True, False])
 @pytest.mark.parametrize("shape,P", [((12, 10, 14), 2), ((9, 6, 20), 3), ((16, 5, 16), 4)])

@@ -105,9 +105,8 @@ def run_distributed(shape, P1, P2, prec, seed=7, chunks=None, options=None, comm
     with ThreadPoolExecutor(P) as ex:
         list(ex.map(lambda r: plans[r].execC2C(outs[r], ins[r], dfft.FORWARD), range(P)))
     spec = []
-    for r in range(P):
-        s = plans[r].getOutSize()
-        spec.append(outs[r][:s[0] * s[1] * s[2]].cpu().numpy().reshape(s))
+    for r in range(P):      # (Nx, yo, zs) whatever the plan's spectral layout (option spectral_layout)
+        spec.append(plans[r].spectrumView(outs[r]).contiguous().cpu().numpy())
     with ThreadPoolExecutor(P) as ex:
         list(ex.map(lambda r: plans[r].execC2C(backs[r], outs[r], dfft.INVERSE), range(P)))
     torch.cuda.synchronize()
@@ -172,15 +171,14 @@ def run_distributed_real(shape, P1, P2, prec, field=None, seed=13, modify=None, 
     with ThreadPoolExecutor(P) as ex:
         list(ex.map(lambda r: plans[r].execR2C(outs[r], ins[r]), range(P)))
     spec = []
-    for r in range(P):
-        s = plans[r].getOutSize()
-        spec.append(outs[r][:s[0] * s[1] * s[2]].cpu().numpy().reshape(s))
+    for r in range(P):      # (Nx, yo, zs) whatever the plan's spectral layout (option spectral_layout)
+        spec.append(plans[r].spectrumView(outs[r]).contiguous().cpu().numpy())
     if modify is not None:
         for r in range(P):
             s, o = plans[r].getOutSize(), plans[r].getOutStart()
             blk = np.ascontiguousarray(spec[r].astype(np.complex128))
             modify(blk, s, o)
-            outs[r][:blk.size] = torch.from_numpy(blk.astype(NPDT[prec]).ravel()).cuda()
+            plans[r].spectrumView(outs[r]).copy_(torch.from_numpy(blk.astype(NPDT[prec])).cuda())
     torch.cuda.synchronize()
     with ThreadPoolExecutor(P) as ex:
         list(ex.map(lambda r: plans[r].execC2R(backs[r], outs[r]), range(P)))
