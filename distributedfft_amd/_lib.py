@@ -90,6 +90,7 @@ SYMBOLS = [
     ("dfft_axis_plan_info", _i, [_i, _sz, _i, C.POINTER(_sz)]),
     ("dfft_malloc", _i, [_sz, _sz, C.POINTER(_vp)]),
     ("dfft_free", _i, [_vp]),
+    ("dfft_last_placement_info", _i, [C.c_char_p, _sz]),
     ("dfft_tune_variants", _i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     ("dfft_tune_placement", _i, [_vp, _vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_float), _i, C.POINTER(_i)]),
 ]

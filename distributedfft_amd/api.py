@@ -142,6 +142,14 @@ class DeviceBuffer:
             pass
 
 
+def last_placement_info():
+    """what the last placement-aware allocation of this process did (dfft_last_placement_info): K, candidates, probe rates, seconds"""
+    import json
+    buf = C.create_string_buffer(1024)
+    check(lib().dfft_last_placement_info(buf, 1024))
+    return json.loads(buf.value.decode())
+
+
 class Comm:
     """Communicator handed to the plans in place of MPI_Comm (src/mpicufft.cpp:42-51)."""
 

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <complex>
 #include <functional>
 #include <map>
@@ -1479,14 +1480,14 @@ template <typename F> static int run_graphed(dfft_plan *p, int kind, const void 
 // repeatably for the life of the allocation (profiles/r2_placement_probe.txt, profiles/r3_placement.txt); what the
 // driver hands out differs from allocation to allocation.  So buffers can be backed through the virtual-memory API in
 // physical chunks of a chosen size, and a plan can try several backings and keep the one its own passes run fastest on.
-struct DevAlloc { size_t bytes, chunk; };     // chunk == 0: plain hipMalloc
+struct DevAlloc { size_t bytes, chunk; int device; };     // chunk == 0: plain hipMalloc; device = the GPU that owns the memory
 static std::mutex g_alloc_mu;
 static std::map<void *, DevAlloc> g_allocs;
 
 static int dev_free(void *ptr)
 {
     if (!ptr) return 0;
-    DevAlloc rec{0, 0};
+    DevAlloc rec{0, 0, -1};
     {
         std::lock_guard<std::mutex> lk(g_alloc_mu);
         auto it = g_allocs.find(ptr);
@@ -1494,10 +1495,17 @@ static int dev_free(void *ptr)
     }
     if (!rec.chunk) { HIP_TRY(hipFree(ptr)); return 0; }
     // hipFree synchronises implicitly, hipMemUnmap does not: work still in flight on ANY stream (the plan's, torch's, a peer
-    // device's pull in an in-process world) must not lose its mapping under it
-    HIP_TRY(hipDeviceSynchronize());
-    for (size_t off = 0; off < rec.bytes; off += rec.chunk) HIP_TRY(hipMemUnmap(static_cast<char *>(ptr) + off, rec.chunk));
-    HIP_TRY(hipMemAddressFree(ptr, rec.bytes));
+    // device's pull in an in-process world) must not lose its mapping under it.  The device to drain is the one that OWNS the
+    // range, which need not be the calling thread's current one (an in-process world over several GPUs).
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    const bool hop = rec.device >= 0 && cur >= 0 && rec.device != cur;
+    if (hop) HIP_TRY(hipSetDevice(rec.device));
+    hipError_t e = hipDeviceSynchronize();
+    for (size_t off = 0; off < rec.bytes && e == hipSuccess; off += rec.chunk) e = hipMemUnmap(static_cast<char *>(ptr) + off, rec.chunk);
+    if (e == hipSuccess) e = hipMemAddressFree(ptr, rec.bytes);
+    if (hop) (void)hipSetDevice(cur);
+    if (e != hipSuccess) { set_error(std::string("dfft_free: ") + hipGetErrorString(e)); return (int)e; }
     return 0;
 }
 // chunk_mib == 0: hipMalloc.  Otherwise one virtual range backed by physical allocations of chunk_mib MiB each.
@@ -1509,9 +1517,11 @@ static int dev_alloc(size_t bytes, size_t chunk_mib, void **out, int spread = 1)
     *out = nullptr;
     if (!bytes) return fail(ERR_ARG, "zero-sized allocation");
     if (!chunk_mib) {
+        int dev0 = -1;
+        (void)hipGetDevice(&dev0);
         HIP_TRY(hipMalloc(out, bytes));
         std::lock_guard<std::mutex> lk(g_alloc_mu);
-        g_allocs[*out] = DevAlloc{bytes, 0};
+        g_allocs[*out] = DevAlloc{bytes, 0, dev0};
         return 0;
     }
     int dev = 0;
@@ -1591,7 +1601,7 @@ static int dev_alloc(size_t bytes, size_t chunk_mib, void **out, int spread = 1)
     }
     {
         std::lock_guard<std::mutex> lk(g_alloc_mu);
-        g_allocs[va] = DevAlloc{total, chunk};
+        g_allocs[va] = DevAlloc{total, chunk, dev};
     }
     *out = va;
     return 0;
@@ -1653,51 +1663,116 @@ static double placement_probe(void *buf, size_t bytes)
 // Default backing, placement-aware: a buffer of 1 GiB and more is first BUILT from chunks that lie far apart (below), probed, and kept
 // if the probe calls it good; otherwise candidates are drawn: the buffer is allocated up to DFFT_PLACEMENT_TRIES (default 6) times --
 // every candidate stays alive while the next is tried: a freed candidate's physical pages would simply be handed out again --, each
-// is probed (3 streaming passes: 8 ms for 16 GiB) and the fastest is kept; a candidate above 5.9 TB/s ends the search at once.
-// Purely local: every rank of a multi-rank plan does it by itself.  DFFT_PLACEMENT_TRIES=1 switches the probe off.
-// Measured (1024^3 fp64, fresh processes after 64 GiB buffers had come and gone, no plan-level search: profiles/bench_r4_c_probe_*.json):
-// 34.05 / 33.70 / 33.89 / 34.44 ms per forward + inverse -- the range of dfft_tune_placement's 8-12 s search (33.3-34.4) -- for 0.03 s
-// (first candidates good) to 5 s (four candidates per buffer; releasing 16 GiB takes longer than creating them).
+// is probed (3 streaming passes: 8 ms for 16 GiB) and the fastest is kept; a good candidate ends the search at once.
+// "Good" is RELATIVE to this device: once per process and device a physically contiguous buffer (hipMalloc, <= 2 GiB: the slow case
+// by construction, profiles/r4_placement_probe.txt) is probed, and a candidate is good when it streams >= 1.08 x that rate (measured
+// classes: 5.2-5.5 TB/s against 6.0-6.6); DFFT_PLACEMENT_GOOD_TBPS sets an absolute threshold instead.
+// Bounded: everything alive during the search -- the spread pool or the drawn candidates -- stays within HALF of the free memory
+// divided by DFFT_RANKS_PER_DEVICE (processes that share the GPU all see the same free figure), and whatever fails on the way
+// (a racing process took the memory) ends in the plain recipe and finally in hipMalloc: the call never fails where hipMalloc succeeds.
+// Purely local: every rank of a multi-rank plan does it by itself.  DFFT_PLACEMENT_TRIES=1 switches the probe off,
+// DFFT_PLACEMENT_SPREAD (default 5, 1 = off, <= 8) is K.  dfft_last_placement_info says what the last call did.
+// Measured (1024^3 fp64, fresh processes): profiles/bench_r4d*.json (K = 8), profiles/bench_r5*.json (K = 5).
+struct PlacementInfo {
+    size_t bytes = 0;
+    int spread = 0, drawn = 0, fallback = 0;
+    double rate = 0, ref_rate = 0, threshold = 0, seconds = 0;
+    const char *kept = "none";
+};
+static std::mutex g_place_mu;
+static PlacementInfo g_place_last;
+static std::map<int, double> g_place_ref;      // device -> streaming rate of a contiguous buffer
+
+static double placement_reference_rate()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0.0;
+    {
+        std::lock_guard<std::mutex> lk(g_place_mu);
+        auto it = g_place_ref.find(dev);
+        if (it != g_place_ref.end()) return it->second;
+    }
+    double rate = 0.0;
+    void *ref = nullptr;
+    const size_t rb = (size_t)2 << 30;
+    if (hipMalloc(&ref, rb) == hipSuccess) {
+        rate = placement_probe(ref, rb);
+        (void)hipFree(ref);
+    } else (void)hipGetLastError();
+    std::lock_guard<std::mutex> lk(g_place_mu);
+    g_place_ref[dev] = rate;
+    return rate;
+}
+
 static int dev_alloc_default(size_t bytes, void **out)
 {
     if (bytes < ((size_t)32 << 20)) return dev_alloc(bytes, 0, out);      // small buffers live in the caches: nothing to place
     static const int tries = [] { const char *e = getenv("DFFT_PLACEMENT_TRIES"); const int v = e ? atoi(e) : 6; return v < 1 ? 1 : v > 16 ? 16 : v; }();
+    static const int spread_want = [] { const char *e = getenv("DFFT_PLACEMENT_SPREAD"); const int v = e ? atoi(e) : 5; return v < 1 ? 1 : v > 8 ? 8 : v; }();
+    static const int sharers = [] { const char *e = getenv("DFFT_RANKS_PER_DEVICE"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
+    static const double abs_good = [] { const char *e = getenv("DFFT_PLACEMENT_GOOD_TBPS"); return e ? atof(e) * 1e12 : 0.0; }();
     if (bytes < ((size_t)1 << 30) || tries == 1 || default_chunk_mib() == 0) return dev_alloc_recipe(bytes, out);
+    const auto t0 = std::chrono::steady_clock::now();
+    PlacementInfo info;
+    info.bytes = bytes;
+    info.ref_rate = abs_good > 0 ? 0.0 : placement_reference_rate();
+    info.threshold = abs_good > 0 ? abs_good : 1.08 * info.ref_rate;      // (0: no reference could be probed -- the first candidate is kept)
+    auto good = [&](double rate) { return rate == 0.0 || info.threshold == 0.0 || rate >= info.threshold; };
+    // what this call may hold alive at any time, this buffer included
+    auto budget = [&]() -> size_t {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        return free_b / 2 / (size_t)sharers;
+    };
+    auto done = [&](void *ptr, const char *kept, double rate) {
+        info.kept = kept; info.rate = rate;
+        info.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::lock_guard<std::mutex> lk(g_place_mu);
+        g_place_last = info;
+        *out = ptr;
+        return 0;
+    };
     void *best = nullptr;
     double best_rate = -1.0;
     std::vector<void *> losers;
-    // First a buffer BUILT to be good: 1 GiB chunks taken every K-th from K times as many (K up to 8, as many as fit next to what is
-    // alive).  16 chunks written at once stream at 6.0 TB/s when they are physical neighbours and 6.6 TB/s when 8 GiB apart; buffers
-    // built this way were good in 16 of 16 scatter passes (tools/kbench --vmm-spread 8 / 5, profiles/r4_placement_probe.txt).  The
-    // probe still judges it: if it is not good (an allocator that does not hand out chunks in physical order), candidates are drawn.
+    // First a buffer BUILT to be good: 1 GiB chunks taken every K-th from K times as many.  16 chunks written at once stream at
+    // 6.0 TB/s when they are physical neighbours and 6.6 TB/s when 8 GiB apart; buffers built with K = 8 and K = 5 were good in 16 of
+    // 16 scatter passes (tools/kbench --vmm-spread 8 / 5, profiles/r4_placement_probe.txt).  The probe still judges it: if it is not
+    // good (an allocator that does not hand out chunks in physical order), candidates are drawn.
     {
-        size_t free_b = 0, total_b = 0;
-        int K = 1;
-        if (default_chunk_mib() >= 256 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > ((size_t)4 << 30))
-            K = (int)std::min<size_t>(8, (free_b - ((size_t)4 << 30)) / bytes);
+        const int K = default_chunk_mib() >= 256 ? (int)std::min<size_t>((size_t)spread_want, budget() / bytes) : 1;
         void *cand = nullptr;
         if (K >= 3 && dev_alloc(bytes, default_chunk_mib(), &cand, K) == 0) {
+            info.spread = K;
             best = cand;
             best_rate = placement_probe(cand, bytes);
-            if (best_rate == 0.0 || best_rate >= 5.9e12) { *out = best; return 0; }
+            if (good(best_rate)) return done(best, "built from chunks K apart", best_rate);
         } else (void)hipGetLastError();
     }
     for (int t = 0; t < tries; t++) {
-        if (t || best) {      // room for one more candidate next to what is alive?
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)2 << 30)) break;
-        }
+        // room for one more candidate next to what this call holds alive?
+        if ((size_t)(losers.size() + (best ? 1 : 0) + 1) * bytes > std::max(budget(), bytes) && (t || best)) break;
         void *cand = nullptr;
-        if (const int rc = dev_alloc_recipe(bytes, &cand)) { if (!best) return rc; break; }
+        if (dev_alloc_recipe(bytes, &cand) != 0) { (void)hipGetLastError(); break; }
+        info.drawn++;
         const double rate = placement_probe(cand, bytes);
         if (rate > best_rate) { if (best) losers.push_back(best); best = cand; best_rate = rate; }
         else losers.push_back(cand);
-        if (rate == 0.0 || rate >= 5.9e12) break;      // (no probe possible: take what we have) / a good one
+        if (good(rate)) break;
         if (best_rate > 0 && rate < best_rate && best_rate >= 1.12 * rate) break;      // both classes seen: the best is of the good one
     }
     for (void *l : losers) (void)dev_free(l);
-    *out = best;
-    return 0;
+    if (!best) {
+        // nothing could be created with the search's footprint (another process took the memory in between, a tight device): the plain
+        // recipe once more on its own, then hipMalloc -- where that succeeds, so does this call
+        info.fallback = 1;
+        void *cand = nullptr;
+        int rc = dev_alloc_recipe(bytes, &cand);
+        if (rc != 0) { (void)hipGetLastError(); rc = dev_alloc(bytes, 0, &cand); }
+        if (rc != 0) return rc;
+        return done(cand, "plain (the search found no room)", 0.0);
+    }
+    return done(best, info.drawn ? "fastest of the drawn candidates" : "built from chunks K apart (below the threshold, nothing else fit)", best_rate);
 }
 
 static int check_ready(dfft_plan *p)
@@ -2565,6 +2640,19 @@ int dfft_malloc(size_t bytes, size_t chunk_mib, void **ptr)
     return dev_alloc(bytes, chunk_mib, ptr);
 }
 int dfft_free(void *ptr) { return dev_free(ptr); }
+int dfft_last_placement_info(char *buf, size_t capacity)
+{
+    if (!buf || !capacity) return fail(ERR_ARG, "null buffer");
+    PlacementInfo i;
+    {
+        std::lock_guard<std::mutex> lk(g_place_mu);
+        i = g_place_last;
+    }
+    snprintf(buf, capacity, "{\"bytes\": %zu, \"spread_K\": %d, \"candidates_drawn\": %d, \"fallback\": %d, \"probe_TBps\": %.3f, "
+                            "\"contiguous_reference_TBps\": %.3f, \"good_threshold_TBps\": %.3f, \"seconds\": %.3f, \"kept\": \"%s\"}",
+             i.bytes, i.spread, i.drawn, i.fallback, i.rate / 1e12, i.ref_rate / 1e12, i.threshold / 1e12, i.seconds, i.kept);
+    return 0;
+}
 
 // device time of the FFT passes (exchanges excluded) of one forward (+ inverse, if back != nullptr) execution on the given
 // buffers, best of `reps` after one untimed execution

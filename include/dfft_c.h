@@ -332,17 +332,24 @@ int dfft_axis_plan_info(int precision, size_t N, int two_level, size_t info[8]);
  * each (HIP virtual-memory API).  chunk_mib = DFFT_CHUNK_DEFAULT: the library's default backing, which is also what the library
  * uses for a work area it owns (dfft_init(allocate = 1), dfft_set_work_area(plan, NULL, NULL)): 1 GiB chunks (smaller ones and
  * finally hipMalloc if that fails) and, for buffers of 1 GiB and more, PLACEMENT: the buffer is built from chunks that lie far
- * apart (every K-th of K times as many, K <= 8), a streaming write is timed on it (8 ms per 16 GiB) and it is kept if it is
- * good (>= 5.9 TB/s); otherwise up to DFFT_PLACEMENT_TRIES (6) plain candidates are drawn, all alive, and the fastest is kept.
- * A good scatter target streams writes at 6.5 TB/s, a bad one at 5.2 TB/s, and the plan's scatter passes follow (5.65 vs 6.5 ms
- * per pass at 1024^3 fp64; hipMalloc buffers are always the bad kind): profiles/r4_placement_probe.txt.  1024^3 fp64 forward +
- * inverse on buffers from this call: 33.5 - 33.6 ms, on hipMalloc buffers 37.6 - 38.3.  Local to the device (no plan, no
- * collective): safe on every rank of a multi-rank job.  Costs about 3.4 s per 16 GiB buffer, 0.4 s per 2 GiB.  Environment:
- * DFFT_DEFAULT_CHUNK_MIB (0 = hipMalloc), DFFT_PLACEMENT_TRIES (1 = no probe).  Free with dfft_free (which also takes
- * pointers it did not allocate: hipFree; it synchronises the device first, like hipFree). */
+ * apart (every K-th of K times as many, K = 5 unless DFFT_PLACEMENT_SPREAD says otherwise), a streaming write is timed on it (8 ms
+ * per 16 GiB) and it is kept if it is good; otherwise up to DFFT_PLACEMENT_TRIES (6) plain candidates are drawn, all alive, and the
+ * fastest is kept.  "Good" is relative to the device: once per process a physically contiguous 2 GiB buffer (hipMalloc: the slow
+ * case by construction) is probed, a candidate is good at >= 1.08 x its rate (measured classes on MI355X: 5.2-5.5 against 6.0-6.6
+ * TB/s; the plan's scatter passes follow: 6.5 vs 5.65 ms per pass at 1024^3 fp64, profiles/r4_placement_probe.txt);
+ * DFFT_PLACEMENT_GOOD_TBPS sets an absolute threshold.  Everything alive during the search stays within half of the free memory
+ * divided by DFFT_RANKS_PER_DEVICE (set it when several processes share a GPU), and whatever fails on the way falls back to the
+ * plain recipe and then to hipMalloc: the call never fails where hipMalloc would succeed.  1024^3 fp64 forward + inverse on
+ * buffers from this call: 33.5 - 33.6 ms, on hipMalloc buffers 37.6 - 38.3.  Local to the device (no plan, no collective): safe
+ * on every rank of a multi-rank job.  Costs about 1.3 s per 16 GiB buffer (K = 5), 0.2 s per 2 GiB.  Environment:
+ * DFFT_DEFAULT_CHUNK_MIB (0 = hipMalloc), DFFT_PLACEMENT_TRIES (1 = no probe), DFFT_PLACEMENT_SPREAD, DFFT_RANKS_PER_DEVICE,
+ * DFFT_PLACEMENT_GOOD_TBPS.  dfft_last_placement_info writes what the last placement-aware allocation of the process did (a JSON
+ * object: K, candidates drawn, probe and reference rates, seconds, what was kept).  Free with dfft_free (which also takes
+ * pointers it did not allocate: hipFree; it synchronises the owning device first, like hipFree). */
 #define DFFT_CHUNK_DEFAULT ((size_t)-1)
 int dfft_malloc(size_t bytes, size_t chunk_mib, void **ptr);
 int dfft_free(void *ptr);
+int dfft_last_placement_info(char *buf, size_t capacity);
 /* Tries up to `tries` backings for the plan's own work area (only when the library owns it), for a new output buffer
  * *out (dfft_domain_size bytes) and, if back != NULL, for a new buffer *back of the input block's size (the inverse
  * transform's output), one buffer at a time, and keeps for each the backing on which the plan's own FFT passes

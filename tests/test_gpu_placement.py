@@ -147,3 +147,62 @@ def test_tune_variants_is_collective_with_rank_dependent_roles():
         list(ex.map(lambda r: plans[r].execC2R(backs[r], outs[r]), range(P1 * P2)))
     for r in range(P1 * P2):
         assert rel(backs[r].cpu().numpy() / float(np.prod(shape)), ins[r].cpu().numpy()) < TOL_RT["double"]
+
+
+def test_default_backing_reports_what_it_did():
+    """dfft_malloc(DFFT_CHUNK_DEFAULT) of a buffer >= 1 GiB: built from chunks K apart, probed with a streaming write and judged
+    against THIS device's contiguous reference (no absolute rate); dfft_last_placement_info says what happened"""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    nbytes = 2 << 30
+    b = dfft.DeviceBuffer.alloc(nbytes)
+    info = dfft.last_placement_info()
+    assert info["bytes"] == nbytes and info["fallback"] == 0 and info["seconds"] < 30
+    assert info["spread_K"] in (0, 3, 4, 5) and info["spread_K"] + info["candidates_drawn"] >= 1, info
+    assert info["contiguous_reference_TBps"] > 1.0 and abs(info["good_threshold_TBps"] - 1.08 * info["contiguous_reference_TBps"]) < 0.01, info
+    assert info["probe_TBps"] > 1.0, info
+    t = b.tensor(torch.float64)
+    t.fill_(3.0)
+    assert float(t.sum()) == 3.0 * (nbytes // 8)
+    del t
+    b.free()
+
+
+def test_default_backing_on_a_nearly_full_device():
+    """free < 3 x the buffer: the search may hold at most half of the free memory alive, so no pool of K x the buffer and at most one
+    drawn candidate -- and the call succeeds (it never fails where hipMalloc would succeed)"""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    nbytes = 2 << 30
+    free_b, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(free_b - int(2.6 * nbytes), dtype=torch.uint8, device="cuda")
+    try:
+        b = dfft.DeviceBuffer.alloc(nbytes)
+        info = dfft.last_placement_info()
+        assert info["bytes"] == nbytes and info["spread_K"] == 0 and info["candidates_drawn"] <= 1, info
+        t = b.tensor(torch.float32)
+        t.fill_(1.0)
+        assert float(t[:1024].sum()) == 1024.0
+        del t
+        b.free()
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+
+
+def test_default_backing_shares_the_device(tmp_path):
+    """DFFT_RANKS_PER_DEVICE: processes that share a GPU all see the same free figure; each keeps its search within its share"""
+    import subprocess
+    import sys
+    code = ("import distributedfft_amd as d, json; b = d.DeviceBuffer.alloc(2 << 30); i = d.last_placement_info(); b.free(); print(json.dumps(i))")
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root,
+                         env=dict(os.environ, PYTHONPATH=root, DFFT_RANKS_PER_DEVICE="64"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    # 64 sharers of 288 GB: 2.2 GiB each -- room for the buffer itself, not for a pool
+    assert info["spread_K"] == 0 and info["candidates_drawn"] == 1 and info["fallback"] == 0, info
