@@ -45,6 +45,7 @@ SYMBOLS = [
     ("dfft_comm_get_counter", _i, [_vp, C.c_char_p, C.POINTER(C.c_long)]),
     ("dfft_comm_set_option", _i, [_vp, C.c_char_p, C.c_long]),
     ("dfft_comm_alltoallv", _i, [_vp, _i, _vp, C.POINTER(_sz), C.POINTER(_sz), _vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_i), _i, _i, _vp]),
+    ("dfft_comm_sendrecv_list", _i, [_vp, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_vp), _psz, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_vp), _psz, _i, _vp]),
     ("dfft_comm_destroy", _i, [_vp]),
     ("dfft_plan_create", _i, [C.POINTER(_vp), _i, _i, C.POINTER(Config), _vp, _i, _i]),
     ("dfft_plan_destroy", _i, [_vp]),

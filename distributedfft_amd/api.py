@@ -241,6 +241,18 @@ class Comm:
         check(lib().dfft_comm_alltoallv(self._h, int(myrank), _ptr(send), arr(scounts), arr(sdispls), _ptr(recv), arr(rcounts), arr(rdispls),
                                         (C.c_int * n)(*[int(g) for g in group]), n, int(me), C.c_void_p(stream or 0)))
 
+    def sendrecvList(self, myrank, sends, recvs, nlayers, stream=None):
+        """the transport's point-to-point schedule by itself (dfft_comm_sendrecv_list): sends / recvs = [(peer, layer, buffer or address,
+        nbytes), ...]; one grouped operation on the RCCL / local-world / list-callback transports"""
+        def pack(lst):
+            n = len(lst)
+            return (n, (C.c_int * n)(*[int(p) for p, _, _, _ in lst]), (C.c_int * n)(*[int(l) for _, l, _, _ in lst]),
+                    (C.c_void_p * n)(*[b if isinstance(b, int) else _ptr(b).value for _, _, b, _ in lst]),
+                    (C.c_size_t * n)(*[int(nb) for _, _, _, nb in lst]))
+        ns, sp, sl, sptr, sb = pack(sends)
+        nr, rp, rl, rptr, rb = pack(recvs)
+        check(lib().dfft_comm_sendrecv_list(self._h, int(myrank), ns, sp, sl, sptr, sb, nr, rp, rl, rptr, rb, int(nlayers), C.c_void_p(stream or 0)))
+
     def destroy(self):
         if self._h:
             lib().dfft_comm_destroy(self._h)

@@ -57,6 +57,7 @@ struct dfft_comm {
     // side stream of the relay (channel + 2: its own communicator where the transport has one), so that the hops of neighbouring
     // pipeline chunks overlap; 0: both hops on the exchange's stream, one after the other
     int relay_overlap = 1;
+    int test_channel = 0;      // the channel of the bare transport calls of the C ABI (dfft_comm_alltoallv, dfft_comm_sendrecv_list)
     // what went through the transport since the communicator was made (dfft_comm_get_counter): calls of alltoallv / sendrecv_list
     // made by plans and by the relay, and relayed exchanges
     struct Counters { std::atomic<long> alltoallv{0}, list{0}, relayed{0}, relay_meta{0}; } counters;

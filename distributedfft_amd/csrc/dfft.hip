@@ -1851,6 +1851,11 @@ int dfft_comm_set_option(dfft_comm *comm, const char *key, long value)
         comm->relay = (int)value;
         return 0;
     }
+    if (std::string(key) == "test_channel") {
+        if (value < 0 || value > 3) return fail(ERR_ARG, "test_channel: 0 .. 3");
+        comm->test_channel = (int)value;
+        return 0;
+    }
     if (std::string(key) == "relay_overlap") {
         if (value < 0 || value > 1) return fail(ERR_ARG, "relay_overlap: 0 or 1");
         comm->relay_overlap = (int)value;
@@ -1866,8 +1871,25 @@ int dfft_comm_alltoallv(dfft_comm *comm, int myrank, const void *send, const siz
     if (!comm || !send || !recv || !scounts || !sdispls || !rcounts || !rdispls || !group) return fail(ERR_ARG, "null argument");
     if (ngroup < 1 || me < 0 || me >= ngroup) return fail(ERR_ARG, "bad group");
     comm->counters.alltoallv++;
-    const int r = comm->alltoallv(myrank, send, scounts, sdispls, recv, rcounts, rdispls, group, ngroup, me, (hipStream_t)hip_stream, 0);
+    const int r = comm->alltoallv(myrank, send, scounts, sdispls, recv, rcounts, rdispls, group, ngroup, me, (hipStream_t)hip_stream, comm->test_channel);
     return r ? fail(r, "all-to-all failed: " + g_error) : 0;
+}
+int dfft_comm_sendrecv_list(dfft_comm *comm, int myrank, int nsend, const int *speer, const int *slayer, void *const *sptr, const size_t *sbytes,
+                            int nrecv, const int *rpeer, const int *rlayer, void *const *rptr, const size_t *rbytes, int nlayers, void *hip_stream)
+{
+    if (!comm || nsend < 0 || nrecv < 0 || nlayers < 0) return fail(ERR_ARG, "bad arguments");
+    if ((nsend && (!speer || !slayer || !sptr || !sbytes)) || (nrecv && (!rpeer || !rlayer || !rptr || !rbytes))) return fail(ERR_ARG, "null list");
+    std::vector<dfft_xfer> sx((size_t)nsend), rx((size_t)nrecv);
+    for (int i = 0; i < nsend; i++) {
+        if (speer[i] < 0 || speer[i] >= comm->nranks || slayer[i] < 0 || slayer[i] >= nlayers) return fail(ERR_ARG, "send piece: bad peer or layer");
+        sx[i] = dfft_xfer{speer[i], slayer[i], sptr[i], sbytes[i]};
+    }
+    for (int i = 0; i < nrecv; i++) {
+        if (rpeer[i] < 0 || rpeer[i] >= comm->nranks || rlayer[i] < 0 || rlayer[i] >= nlayers) return fail(ERR_ARG, "receive piece: bad peer or layer");
+        rx[i] = dfft_xfer{rpeer[i], rlayer[i], rptr[i], rbytes[i]};
+    }
+    const int r = comm->sendrecv_list(myrank, sx.data(), nsend, rx.data(), nrecv, nlayers, (hipStream_t)hip_stream, comm->test_channel);
+    return r ? fail(r, "send/receive schedule failed: " + g_error) : 0;
 }
 int dfft_comm_destroy(dfft_comm *comm)
 {
@@ -2550,6 +2572,12 @@ int dfft_fft1d_batched_ex(int precision, size_t N, size_t batch, void *out, cons
     // scratch of two-level lines, grown on demand, one per stream: two calls of one thread on different streams must not share it
     // (growing it frees the old one with hipFree, which waits for every launch still using it)
     static thread_local std::map<void *, std::pair<void *, size_t>> lvw_of;
+    // bounded: a thread that keeps calling on fresh streams (streams come and go) must not pile up scratch buffers -- beyond 8
+    // entries everything but this stream's is released (hipFree waits for the launches that still use it)
+    if (lvw_of.size() > 8 && !lvw_of.count(hip_stream)) {
+        for (auto &kv : lvw_of) if (kv.second.first) (void)hipFree(kv.second.first);
+        lvw_of.clear();
+    }
     void *&lvw = lvw_of[hip_stream].first;
     size_t &lvw_bytes = lvw_of[hip_stream].second;
     // variant -1: the Bluestein kernel even where a native configuration exists; -2: two levels wherever the length splits

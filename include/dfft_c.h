@@ -133,6 +133,13 @@ int dfft_comm_set_option(dfft_comm *comm, const char *key, long value);
  * transport by itself (the reference's counterpart is a bare MPI_Alltoallv, src/pencil/mpicufft_pencil_opt1.cpp:784-785). */
 int dfft_comm_alltoallv(dfft_comm *comm, int myrank, const void *send, const size_t *scounts, const size_t *sdispls, void *recv,
                         const size_t *rcounts, const size_t *rdispls, const int *group, int ngroup, int me, void *hip_stream);
+/* The transport's point-to-point schedule on its own -- what the relay calls for each of its two hops: piece i of the send list goes
+ * to rank speer[i], piece j of the receive list comes from rpeer[j]; `slayer` / `rlayer` number the pieces between one ordered pair of
+ * ranks (both ends give a piece the same layer, at most one piece per peer, direction and layer; nlayers the same on all ranks).  One
+ * grouped operation on the RCCL, local-world and list-callback transports, nlayers all-to-all-v calls elsewhere.  COLLECTIVE over the
+ * communicator.  Stream-ordered.  Option "test_channel" = 0..3 picks the channel (communicator) the two bare calls use. */
+int dfft_comm_sendrecv_list(dfft_comm *comm, int myrank, int nsend, const int *speer, const int *slayer, void *const *sptr, const size_t *sbytes,
+                            int nrecv, const int *rpeer, const int *rlayer, void *const *rptr, const size_t *rbytes, int nlayers, void *hip_stream);
 /* destroy the plans that use a communicator before the communicator itself */
 int dfft_comm_destroy(dfft_comm *comm);
 

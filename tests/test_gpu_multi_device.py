@@ -26,6 +26,36 @@ def launch(nproc, args, port):
     return subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
 
 
+def rccl_smoke(nproc):
+    """tools/rccl_smoke.py: RCCL version, ncclCommCount, per-link and all-to-all rates through the library's transport -- first, so
+    that a multi-GPU lease yields link numbers even if an FFT leg fails later"""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_smoke.py"), "--gpus", str(nproc), "--mib", "64", "--iters", "3"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    print("RCCL_SMOKE", json.dumps(line))
+    assert line["world_size"] == nproc and line["ncclCommCount"] == nproc and not line.get("errors")
+    assert all(v > 0 for v in line["pair_shift_GBps"].values()) and line["alltoall_GBps_out_per_gpu"] > 0 and line["list_GBps_out_per_gpu"] > 0
+    assert line["transport_counters"]["list"] >= 4
+    return line
+
+
+@needs_two
+def test_0_rccl_smoke_on_all_gpus():
+    line = rccl_smoke(min(8, NDEV))
+    assert len(line["pair_shift_GBps"]) == min(8, NDEV) - 1
+
+
+def test_rccl_smoke_on_one_gpu():
+    """the same tool with a world of one (the own block through ncclSend / ncclRecv to itself, three duplicated communicators)"""
+    line = rccl_smoke(1)
+    assert line["duplicated_communicators"] == 3 and list(line["pair_shift_GBps"]) == ["0"]
+
+
 @needs_two
 @pytest.mark.parametrize("transport", ["rccl", "torch"])
 @pytest.mark.parametrize("kind,grid", [("slab", "all"), ("pencil", "2xN"), ("zyx", "all")])
@@ -44,10 +74,12 @@ def test_one_process_per_gpu_against_the_oracle(kind, grid, transport):
 @needs_two
 def test_bench_runs_on_all_gpus():
     nproc = 2 if NDEV < 4 else (4 if NDEV < 8 else 8)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-           "--master-port", "29655", os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--size", "256", "--steps", "3", "--warmup", "1"]
-    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900,
-                         env=dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    # exactly the driver's command line: bench.py starts its own ranks
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--size", "256", "--steps", "3", "--warmup", "1"]
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     import json
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
