@@ -520,7 +520,7 @@ def main():
         try:
             with torch.cuda.stream(side):
                 trial_ms = plan.tuneVariants(d_in, d_out, None if aliased else d_back)
-            variants = {"trial_fft_ms": [round(v, 3) for v in trial_ms],
+            variants = {"trial_fft_ms": [round(v, 3) for v in trial_ms], "chosen (variant, order, addr64) per pass": plan.getPassChoices(),
                         "what": "dfft_tune_variants before the warm-up: first entry = the plan as built (rule-based workgroup orders and kernel "
                                 "configurations), then the four workgroup-order settings (each pass keeps its fastest), the chosen orders, one entry per "
                                 "kernel-configuration number of the plan's line lengths (each pass keeps a configuration that is more than 1 % faster), "
@@ -647,7 +647,8 @@ def main():
             try:
                 with torch.cuda.stream(side):
                     tr = pl.tuneVariants(v_in, v_out, None if aliased else d_back[:nv])   # without a third buffer: forward passes only
-                tuned = {"as_built_ms": round(tr[0], 3), "chosen_ms": round(tr[-1], 3), "trials": len(tr)}
+                tuned = {"as_built_ms": round(tr[0], 3), "chosen_ms": round(tr[-1], 3), "trials": len(tr),
+                         "chosen (variant, order, addr64) per pass": pl.getPassChoices()}
             except Exception as e:   # noqa: BLE001
                 tuned = {"error": str(e)}
         pl.enablePhaseTiming(True)

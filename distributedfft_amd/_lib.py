@@ -82,6 +82,7 @@ SYMBOLS = [
     ("dfft_enable_phase_timing", _i, [_vp, _i]),
     ("dfft_fft1d_batched", _i, [_i, _sz, _sz, _vp, _vp, _i, _vp]),
     ("dfft_fft1d_batched_ex", _i, [_i, _sz, _sz, _vp, _vp, _i, _vp, _i, _i]),
+    ("dfft_get_pass_choices", _i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     ("dfft_debug_get_pass", _i, [_vp, C.c_char_p, _i, C.POINTER(PassDesc)]),
     ("dfft_debug_get_point_table", _i, [_vp, C.c_char_p, _i, _i, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
                                         C.POINTER(C.c_uint32), _sz, _psz]),

@@ -389,6 +389,13 @@ class MPIcuFFT:
     def getOutStart(self):
         return self._get3(lib().dfft_get_out_start)
 
+    def getPassChoices(self):
+        """{pass: (variant, order, addr64)} for fz fy fx ix iy iz: what every pass runs with right now (dfft_get_pass_choices) -- the
+        plan's rules, or what tuneVariants / tunePlacement kept"""
+        v, o, a = (C.c_int * 6)(), (C.c_int * 6)(), (C.c_int * 6)()
+        check(lib().dfft_get_pass_choices(self._h, v, o, a))
+        return {n: (v[i], o[i], a[i]) for i, n in enumerate(("fz", "fy", "fx", "ix", "iy", "iz"))}
+
     def getOutStrides(self):
         """element strides of the spectrum block along (kx, ky_local, kz_local) (dfft_get_out_strides): (yo*zs, zs, 1) for the
         reference's [Nx][yo][zs], (1, zs*Nx, Nx) with setOption("spectral_layout", 1)"""

@@ -90,6 +90,12 @@ using F32_1024_v7 = PassCfg<float, 1024, 16, 16, 1, 16, 8, 8, 1, 1, 1, 3, 2, 2>;
 using F32_1024_v3 = PassCfg<float, 1024, 32, 16, 1, 32, 8, 4, 1, 1, 1, 3, 2>;
 using F32_1024_v11 = PassCfg<float, 1024, 32, 16, 1, 32, 8, 4, 1, 1, 1, 3, 2, 2>;
 using F32_1024_v2 = PassCfg<float, 1024, 16, 16, 1, 16, 8, 8, 1, 1, 1, 3, 2>;
+//   1 = natural-line load, tiled store (the inverse x pass of a plan with an x-contiguous spectrum, option spectral_layout): variant 6's
+//       two-pass chain with the point-fastest mapping for the FIRST pass only (PassCfg::MAP = 3) -- the loads are 128-byte runs of one
+//       line instead of 32-byte pieces of 16 lines, the same-tile stores stay line fastest.  profiles/r5_spectral_layout.txt
+using F32_512_v1 = PassCfg<float, 512, 32, 16, 1, 32, 16, 1, 1, 1, 1, 0, 3>;
+using F32_1024_v1 = PassCfg<float, 1024, 32, 16, 1, 32, 32, 1, 1, 1, 1, 0, 3>;
+using F32_2048_v1 = PassCfg<float, 2048, 64, 16, 1, 64, 32, 1, 1, 1, 1, 0, 3>;
 #ifdef DFFT_EXPERIMENTS
 #define DFFT_F32_EXP_SMALL(X)
 #define DFFT_F32_EXP_1024(X) X(1024, 10, F32_1024_v10) X(1024, 11, F32_1024_v11) X(1024, 2, F32_1024_v2)
@@ -99,9 +105,9 @@ using F32_1024_v2 = PassCfg<float, 1024, 16, 16, 1, 16, 8, 8, 1, 1, 1, 3, 2>;
 #define DFFT_F32_EXP_1024(X)
 #define DFFT_F32_EXP_2048(X)
 #endif
-#define DFFT_F32_LIST_SMALL(X) X(512, 6, F32_512_v6) X(512, 9, F32_512_v9) X(512, 4, F32_512_v4) X(512, 5, F32_512_v5) X(2, 0, F32_2) X(4, 0, F32_4) X(8, 0, F32_8) X(16, 0, F32_16) X(32, 0, F32_32) X(64, 0, F32_64) X(128, 0, F32_128) X(256, 0, F32_256) X(512, 0, F32_512) DFFT_F32_EXP_SMALL(X)
-#define DFFT_F32_LIST_1024(X) X(1024, 4, F32_1024_v4) X(1024, 5, F32_1024_v5) X(1024, 6, F32_1024_v6) X(1024, 9, F32_1024_v9) X(1024, 7, F32_1024_v7) X(1024, 3, F32_1024_v3) X(1024, 0, F32_1024) DFFT_F32_EXP_1024(X)
-#define DFFT_F32_LIST_2048(X) X(2048, 4, F32_2048_v4) X(2048, 5, F32_2048_v5) X(2048, 6, F32_2048_v6) X(2048, 9, F32_2048_v9) X(2048, 7, F32_2048_v7) X(2048, 14, F32_2048_v14) X(2048, 15, F32_2048_v15) X(2048, 0, F32_2048) X(4096, 0, F32_4096) X(8192, 0, F32_8192) DFFT_F32_EXP_2048(X)
+#define DFFT_F32_LIST_SMALL(X) X(512, 1, F32_512_v1) X(512, 6, F32_512_v6) X(512, 9, F32_512_v9) X(512, 4, F32_512_v4) X(512, 5, F32_512_v5) X(2, 0, F32_2) X(4, 0, F32_4) X(8, 0, F32_8) X(16, 0, F32_16) X(32, 0, F32_32) X(64, 0, F32_64) X(128, 0, F32_128) X(256, 0, F32_256) X(512, 0, F32_512) DFFT_F32_EXP_SMALL(X)
+#define DFFT_F32_LIST_1024(X) X(1024, 1, F32_1024_v1) X(1024, 4, F32_1024_v4) X(1024, 5, F32_1024_v5) X(1024, 6, F32_1024_v6) X(1024, 9, F32_1024_v9) X(1024, 7, F32_1024_v7) X(1024, 3, F32_1024_v3) X(1024, 0, F32_1024) DFFT_F32_EXP_1024(X)
+#define DFFT_F32_LIST_2048(X) X(2048, 1, F32_2048_v1) X(2048, 4, F32_2048_v4) X(2048, 5, F32_2048_v5) X(2048, 6, F32_2048_v6) X(2048, 9, F32_2048_v9) X(2048, 7, F32_2048_v7) X(2048, 14, F32_2048_v14) X(2048, 15, F32_2048_v15) X(2048, 0, F32_2048) X(4096, 0, F32_4096) X(8192, 0, F32_8192) DFFT_F32_EXP_2048(X)
 
 // lengths with a packed real z pass / a Bluestein inner transform of their own configuration
 // real-transform z passes (variant 0 configurations only); M = Nz/2

@@ -1512,9 +1512,15 @@ static int dev_free(void *ptr)
 // spread > 1: `spread` times as many physical chunks are created as the buffer needs, every spread-th is mapped and the others are
 // released afterwards, so that the buffer's chunks lie `spread` chunks apart in the order the driver hands them out (see
 // dev_alloc_default: a buffer whose chunks are spread over the physical space is a good scatter target)
+// where the last dev_alloc of this thread spent its time (the placement report: dfft_last_placement_info)
+struct AllocTimes { double create = 0, map = 0, release = 0; };
+static thread_local AllocTimes g_alloc_times;
+static double seconds_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+
 static int dev_alloc(size_t bytes, size_t chunk_mib, void **out, int spread = 1)
 {
     *out = nullptr;
+    g_alloc_times = AllocTimes();
     if (!bytes) return fail(ERR_ARG, "zero-sized allocation");
     if (!chunk_mib) {
         int dev0 = -1;
@@ -1550,14 +1556,20 @@ static int dev_alloc(size_t bytes, size_t chunk_mib, void **out, int spread = 1)
         const size_t n = total / chunk;
         std::vector<hipMemGenericAllocationHandle_t> all;
         all.reserve(n * (size_t)spread);
+        auto t0 = std::chrono::steady_clock::now();
         for (size_t i = 0; i < n * (size_t)spread && err == hipSuccess; i++) {
             hipMemGenericAllocationHandle_t h;
             err = hipMemCreate(&h, chunk, &prop, 0);
             if (err == hipSuccess) all.push_back(h);
         }
+        g_alloc_times.create = seconds_since(t0);
+        t0 = std::chrono::steady_clock::now();
         for (size_t i = 0; i < n && err == hipSuccess; i++, mapped += chunk)
             err = hipMemMap(static_cast<char *>(va) + i * chunk, chunk, 0, all[i * (size_t)spread], 0);
+        g_alloc_times.map = seconds_since(t0);
+        t0 = std::chrono::steady_clock::now();
         for (auto &h : all) (void)hipMemRelease(h);      // (a mapping keeps its physical memory alive; the chunks in between go back)
+        g_alloc_times.release = seconds_since(t0);
     } else
     for (; mapped < total && err == hipSuccess; mapped += chunk) {
         hipMemGenericAllocationHandle_t h;
@@ -1677,6 +1689,7 @@ struct PlacementInfo {
     size_t bytes = 0;
     int spread = 0, drawn = 0, fallback = 0;
     double rate = 0, ref_rate = 0, threshold = 0, seconds = 0;
+    double ref_s = 0, create_s = 0, map_s = 0, release_s = 0, probe_s = 0;      // where the seconds went: reference probe, pool create / map / release, probes
     const char *kept = "none";
 };
 static std::mutex g_place_mu;
@@ -1716,6 +1729,7 @@ static int dev_alloc_default(size_t bytes, void **out)
     PlacementInfo info;
     info.bytes = bytes;
     info.ref_rate = abs_good > 0 ? 0.0 : placement_reference_rate();
+    info.ref_s = seconds_since(t0);
     info.threshold = abs_good > 0 ? abs_good : 1.08 * info.ref_rate;      // (0: no reference could be probed -- the first candidate is kept)
     auto good = [&](double rate) { return rate == 0.0 || info.threshold == 0.0 || rate >= info.threshold; };
     // what this call may hold alive at any time, this buffer included
@@ -1744,8 +1758,11 @@ static int dev_alloc_default(size_t bytes, void **out)
         void *cand = nullptr;
         if (K >= 3 && dev_alloc(bytes, default_chunk_mib(), &cand, K) == 0) {
             info.spread = K;
+            info.create_s = g_alloc_times.create; info.map_s = g_alloc_times.map; info.release_s = g_alloc_times.release;
             best = cand;
+            const auto tp = std::chrono::steady_clock::now();
             best_rate = placement_probe(cand, bytes);
+            info.probe_s += seconds_since(tp);
             if (good(best_rate)) return done(best, "built from chunks K apart", best_rate);
         } else (void)hipGetLastError();
     }
@@ -2146,8 +2163,8 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
             if (has32(p->ax[1], ROLE_TRANSPOSED_STORE)) p->vinv[1] = ROLE_TRANSPOSED_STORE;
             if (p->opt.spectral) {      // x-contiguous spectrum: the forward x pass stores natural lines like the inverse z pass
                 if (has32(p->ax[2], ROLE_NATURAL_STORE)) p->vfwd[2] = ROLE_NATURAL_STORE;
-                // (its inverse loads natural lines and stores same-tile blocks: no configuration has that pair of mappings --
-                // point fastest for the first pass only -- so it keeps the tiled one; dfft_tune_variants measures the others)
+                // ... and its inverse loads them: point fastest for the first pass only, the same-tile stores stay line fastest
+                if (has32(p->ax[2], ROLE_NATURAL_LOAD_TILED_STORE)) p->vinv[2] = ROLE_NATURAL_LOAD_TILED_STORE;
             }
             // (The inverse y pass stores transposed tiles, which a line-fastest fp32 wave -- 16 lines x 4 points -- writes in 32-byte
             // pieces.  A point-fastest store mapping, PassCfg::MAP = 2, writes whole lines and was measured: 1024 points 4.42 vs 4.30 ms,
@@ -2513,6 +2530,24 @@ int dfft_debug_get_pass(const dfft_plan *p, const char *name, int index, dfft_pa
     return 0;
 }
 
+int dfft_get_pass_choices(const dfft_plan *p, int variant[6], int order[6], int addr64[6])
+{
+    if (!p || !p->initialized) return fail(ERR_STATE, "plan not initialised");
+    const Pipeline &pl = p->pl;
+    const bool single = pl.single && p->nranks == 1 && !p->opt.mirror && !p->spectral_mirror && p->c2c;
+    const std::vector<Launch> *vecs[6] = {&pl.fz, &pl.fy, nullptr, &pl.ix, &pl.iy, &pl.iz};
+    for (int k = 0; k < 6; k++) {
+        const Launch *L = nullptr;
+        if (single) L = k == 0 ? &pl.sz : k == 1 ? &pl.sy : k == 2 ? &pl.sx : nullptr;
+        else if (k == 2) L = &pl.fx;
+        else if (!vecs[k]->empty()) L = &(*vecs[k])[0];
+        if (variant) variant[k] = k < 3 ? p->vfwd[k] : p->vinv[5 - k];
+        if (order) order[k] = L ? (L->args.a_fastest ? 1 : 0) + (L->args.xcd_swizzle ? 2 : 0) : -1;
+        if (addr64) addr64[k] = L ? L->args.addr64 : -1;
+    }
+    return 0;
+}
+
 int dfft_debug_get_point_table(const dfft_plan *p, const char *name, int index, int store, uint64_t *base, uint32_t *ln,
                                uint32_t *aux, size_t capacity, size_t *count)
 {
@@ -2677,8 +2712,11 @@ int dfft_last_placement_info(char *buf, size_t capacity)
         i = g_place_last;
     }
     snprintf(buf, capacity, "{\"bytes\": %zu, \"spread_K\": %d, \"candidates_drawn\": %d, \"fallback\": %d, \"probe_TBps\": %.3f, "
-                            "\"contiguous_reference_TBps\": %.3f, \"good_threshold_TBps\": %.3f, \"seconds\": %.3f, \"kept\": \"%s\"}",
-             i.bytes, i.spread, i.drawn, i.fallback, i.rate / 1e12, i.ref_rate / 1e12, i.threshold / 1e12, i.seconds, i.kept);
+                            "\"contiguous_reference_TBps\": %.3f, \"good_threshold_TBps\": %.3f, \"seconds\": %.3f, "
+                            "\"seconds_reference_probe\": %.3f, \"seconds_pool_create\": %.3f, \"seconds_pool_map\": %.3f, \"seconds_pool_release\": %.3f, "
+                            "\"seconds_probes\": %.3f, \"kept\": \"%s\"}",
+             i.bytes, i.spread, i.drawn, i.fallback, i.rate / 1e12, i.ref_rate / 1e12, i.threshold / 1e12, i.seconds, i.ref_s, i.create_s, i.map_s,
+             i.release_s, i.probe_s, i.kept);
     return 0;
 }
 
@@ -2803,7 +2841,7 @@ static int tune_variants(dfft_plan *p, const void *in, void *o, void *b, float &
     // (-DDFFT_EXPERIMENTS) carries further configuration numbers that are measured by hand, never picked here
     auto validated = [&](int v) {
         if (p->prec == DFFT_F64) return (v >= 0 && v <= 3) || v == 7 || v == 8;
-        return v == 0 || (v >= 3 && v <= 7) || v == 9 || v == 14 || v == 15;
+        return v == 0 || v == 1 || (v >= 3 && v <= 7) || v == 9 || v == 14 || v == 15;
     };
     for (int v = 0; v < 16; v++) {
         if (!validated(v)) continue;

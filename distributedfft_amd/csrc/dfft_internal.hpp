@@ -16,6 +16,7 @@ struct PassInfo { int N, E, TL, G, threads, lds_bytes, npass, sub; };
 enum PassRole {
     ROLE_DEFAULT = 0,
     ROLE_STRIDED_READ = 1,     // fp64: loads the point-major API layout (multi-rank inverse x pass)
+    ROLE_NATURAL_LOAD_TILED_STORE = 1,   // fp32: natural lines in (point fastest), same-tile blocks out (line fastest): inverse x pass, x-contiguous spectrum
     ROLE_STREAM = 3,           // fp64: stores in long runs (tiled-transpose chunks, natural lines): nontemporal
     ROLE_NATURAL_LOAD = 4,     // fp32: natural lines in (point-fastest mapping in every pass)
     ROLE_NATURAL_STORE = 5,    // fp32: natural lines out (point-fastest mapping after the first pass)

@@ -333,6 +333,8 @@ template <int R, int OFF, int STRIDE, typename C> struct Dif {
 // MAP: thread <-> (line, point) mapping.  0 = line fastest in every pass (lane = line + TW*t).
 //      1 = point fastest (16 adjacent points of one line in adjacent lanes) in every pass,
 //      2 = line fastest for the first pass (its loads), point fastest afterwards (its stores).
+//      3 = point fastest for the first pass (its loads: natural lines), line fastest afterwards (its stores: tiles) -- the mirror
+//          image of 2: the fp32 inverse x pass of a plan with an x-contiguous spectrum (option spectral_layout).
 //      The point-fastest forms exist for fp32: with 8-byte points and 16-line tiles a line-fastest
 //      wave touches natural lines and transposed tiles in 32-byte pieces; point fastest makes
 //      those accesses 128-byte runs.  The LDS exchange between passes does the re-mapping for free.
@@ -367,7 +369,10 @@ struct PassCfg {
     // consecutive banks like the linear gathers have
     static constexpr int PADB = R1 == 64 ? 64 : 32, PADSH = ilog2(PADB);
     static constexpr int PITCH_BASE = N + N / PADB;
-    static constexpr int PITCH_WANT = MAP == 2 ? 17 : 16;
+    static constexpr int PITCH_WANT = MAP == 2 || MAP == 3 ? 17 : 16;
+    // which passes run point fastest: the first one (and its loads) / the later ones (and the stores)
+    static constexpr bool PF_FIRST = MAP == 1 || MAP == 3;
+    static constexpr bool PF_REST = MAP == 1 || (MAP == 2 && (R2 > 1)) || (MAP == 3 && !(R2 > 1));
     static constexpr int PITCH = PITCH_BASE + ((PITCH_WANT - PITCH_BASE % 32 + 32) % 32);
     static constexpr int PLANE_SLOTS = MAP == 0 ? SLOTS + ((SLOTS >> PS) << PWS) : TW * PITCH;
     static_assert(MAP == 0 || ((N / E) % 16 == 0 && G == 1), "point-fastest mapping needs >= 16 threads per line");
@@ -376,8 +381,8 @@ struct PassCfg {
     // later passes): line fastest 64 / TW, point fastest 16.  Wave-uniform table reads (seg_entry_uniform) need them <= 16,
     // the transposed-tile store <= the consumer's tile (TL): sub-tile workgroups with fewer than 4 lines do not qualify.
     static constexpr int SPAN_LF = TW >= 64 ? 1 : 64 / TW;
-    static constexpr int SPAN_LOAD = MAP == 1 ? PGRP : SPAN_LF;
-    static constexpr int SPAN_STORE = (MAP != 0 && NPASS > 1) || MAP == 1 ? PGRP : SPAN_LF;
+    static constexpr int SPAN_LOAD = PF_FIRST ? PGRP : SPAN_LF;
+    static constexpr int SPAN_STORE = PF_REST ? PGRP : SPAN_LF;
     static constexpr bool UNI_LOAD = is_pow2(N) && SPAN_LOAD <= 16;
     static constexpr bool UNI_STORE_SAME = is_pow2(N) && SPAN_STORE <= 16;
     static constexpr bool UNI_STORE_TRANSPOSE = is_pow2(N) && SPAN_STORE <= TL;
@@ -1021,7 +1026,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_pass_kernel(const PassArgs A
 
     const int tid = threadIdx.x;
     // coordinates for the load / first pass, and for the later passes / the store
-    constexpr bool PF_FIRST = Cfg::kMAP == 1, PF_REST = Cfg::kMAP != 0 && Cfg::NPASS > 1 ? true : Cfg::kMAP == 1;
+    constexpr bool PF_FIRST = Cfg::PF_FIRST, PF_REST = Cfg::PF_REST;
     int lw, t, lw2, t2;
     thread_map<Cfg, PF_FIRST>(tid, lw, t);
     thread_map<Cfg, PF_REST>(tid, lw2, t2);
@@ -1110,6 +1115,26 @@ __device__ __forceinline__ uint64_t tiled_load_offset(const PassArgs &A, const T
     if (A.IA) return bs + (uint64_t)c.a * A.IA + (uint64_t)c.b * A.IB + (uint64_t)(n - s0) * c.tw + c.l;      // one segment, explicit strides
     return bs + (uint64_t)c.a * ln * A.LB + (uint64_t)c.b * TL * ln + (uint64_t)(n - s0) * c.tw + c.l;
 }
+// The same for the line-fastest waves of the real kernels: a wave covers SPAN consecutive values of t, whose points k run up or
+// down from kf (the point of t0 = the wave's first t) to kl (the point of t0 + SPAN - 1); k, kf, kl come from the same formula.
+// If both ends lie in one segment -- their entries carry the same block base -- every lane's entry is the first one moved by
+// k - kf points: two scalar loads (s_load_dwordx4) instead of a 16-byte vector load per lane and point.  The segments of an R2C
+// spectrum start where the reference's split of Nz/2 + 1 puts them (129 + 128 + 128 + 128: not at multiples of 16 points, so the
+// host cannot promise it per launch, PassArgs::luni); the few waves that straddle a segment boundary read their entries per lane.
+// Rank 0 of 2 x 4 at 1024^3 fp64, C2R z pass: profiles/r5_c2r_uniform_tables.txt.
+template <int TL>
+__device__ __forceinline__ uint64_t tiled_load_offset_wave(const PassArgs &A, const TileCtx<TL> &c, uint32_t k, uint32_t kf, uint32_t kl, bool linear)
+{
+    if (A.ltab) {
+        const SegEntry e0 = seg_entry_uniform(A.ltab + kf), e1 = seg_entry_uniform(A.ltab + kl);
+        if (linear && e0.base == e1.base && (uint32_t)(e1.aux - e0.aux) == (uint32_t)(kl - kf)) {
+            const uint32_t aux = e0.aux + (k - kf);      // (k below kf: the unsigned wrap-around is the negative step)
+            return e0.base + (uint64_t)e0.ln * (c.a * A.LB + c.b * TL) + (uint64_t)aux * c.tw + c.l;
+        }
+    }
+    return tiled_load_offset<TL>(A, c, k);
+}
+
 template <int TL>
 __device__ __forceinline__ uint64_t tiled_transpose_store_offset(const PassArgs &A, const TileCtx<TL> &c, uint32_t k)
 {
@@ -1401,10 +1426,27 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
             });
             if (special) xM = in[offset_of((uint32_t)M)];
         };
+        // segmented tiled load with wave-uniform table entries where the wave's points lie in one segment (tiled_load_offset_wave).
+        // Line-fastest first pass only; thread 0's mirrored butterflies (pair_j: t = 0 is its own mirror) break the run of a wave.
+        auto fetch_paired_wave = [&]() {
+            constexpr int SPAN = Cfg::SPAN_LF;
+            const int t0 = __builtin_amdgcn_readfirstlane(t);
+            static_for<0, E>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                constexpr int i = c % S1, m = c / S1;
+                const int k = pair_j<Cfg, R1, i>(t) + m * LEG;
+                const int kf = pair_j<Cfg, R1, i>(t0) + m * LEG, kl = pair_j<Cfg, R1, i>(t0 + SPAN - 1) + m * LEG;
+                const bool linear = i < H || t0 != 0;
+                x[c] = stream_load<Cfg>(in + tiled_load_offset_wave<TL>(A, tc, (uint32_t)k, (uint32_t)kf, (uint32_t)kl, linear));
+            });
+            if (special) xM = in[tiled_load_offset<TL>(A, tc, (uint32_t)M)];
+        };
         if (active) {
             if (A.load_kind == LOAD_LINES) {
                 const uint64_t row = ((uint64_t)tc.a * A.LB + (uint64_t)tc.b * TL + tc.l) * (uint64_t)(M + 1);
                 fetch_paired([&](uint32_t k) { return row + k; });
+            } else if (A.ltab && !PF_FIRST && Cfg::TW <= 64) {
+                fetch_paired_wave();
             } else if (A.ltab || A.lnseg != 1) {
                 fetch_paired([&](uint32_t k) { return tiled_load_offset<TL>(A, tc, k); });
             } else {

@@ -309,6 +309,12 @@ typedef struct dfft_pass_desc {
     uint32_t sstart[32], slen[32];
     uint64_t sbase[32];
 } dfft_pass_desc;
+/* What every pass of the plan runs with right now -- the rules of dfft_init, or what dfft_tune_variants / dfft_tune_placement kept:
+ * passes in the order fz fy fx ix iy iz; variant = kernel configuration number (the role numbers of csrc/cfg_f64.hip.h / cfg_f32.hip.h),
+ * order = a_fastest + 2 * xcd_swizzle of the workgroup -> tile mapping, addr64 = 1 where the pass keeps per-point 64-bit vector
+ * addresses.  Any of the arrays may be NULL.  (A caller can pin the same choices on another plan with the "variant_<pass>" /
+ * "order_<pass>" options.) */
+int dfft_get_pass_choices(const dfft_plan *plan, int variant[6], int order[6], int addr64[6]);
 /* name: "fz" "fy" "ix" "iy" "iz" "py2" "qy2" "zy" "ziy" (index = chunk, or chunk*P + peer for zy/ziy)
  * and "fx" "zix" "yz" "pz1" "qz1" "sz" "sx" "sy" (index 0; the last three: single-rank complex plans, order z, x, y).  Returns nonzero if the plan has no such launch. */
 int dfft_debug_get_pass(const dfft_plan *plan, const char *name, int index, dfft_pass_desc *desc);

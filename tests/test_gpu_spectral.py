@@ -32,8 +32,8 @@ def test_x_contiguous_spectrum_c2c(shape, P1, P2, prec):
         s, o, st = pl.getOutSize(), pl.getOutStart(), pl.getOutStrides()
         assert (s, o) == (ref_plans[r].getOutSize(), ref_plans[r].getOutStart()) and st == (1, s[2] * s[0], s[0])
         assert np.max(np.abs(spec[r] - want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]])) / scale < TOL_FWD[prec]
-        # the same passes up to the last store: the values are those of the reference layout, bit for bit
-        assert np.array_equal(spec[r], spec_ref[r])
+        # the same values as the reference layout holds (not bit for bit: the x pass may run another radix chain for its natural-line store)
+        assert np.max(np.abs(spec[r] - spec_ref[r])) / scale < TOL_FWD[prec]
         assert rel(backs[r] / float(np.prod(shape)), ins[r]) < TOL_RT[prec]
 
 
@@ -74,7 +74,7 @@ def test_tuner_and_pipeline_depths_with_the_x_contiguous_spectrum():
         plans, ins, spec, backs = run_distributed(shape, P1, P2, "double", chunks=chunks, options=OPT)
         _, _, spec_ref, _ = run_distributed(shape, P1, P2, "double", chunks=chunks)
         for r in range(4):
-            assert np.array_equal(spec[r], spec_ref[r]) and rel(backs[r] / float(np.prod(shape)), ins[r]) < 1e-10
+            assert np.max(np.abs(spec[r] - spec_ref[r])) / np.max(np.abs(spec_ref[r])) < 1e-11 and rel(backs[r] / float(np.prod(shape)), ins[r]) < 1e-10
     # one rank: dfft_tune_variants on a plan whose inverse runs the mirrored order
     n = 64
     pl = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), None, precision="double", rank=0)

@@ -394,6 +394,14 @@ template <typename R> static int run_plan(const Args &a)
         printf("\n");
         if (alias_back) { fill_random<R><<<nblk, 256>>>((R *)in, nreal); HIPCHK(hipDeviceSynchronize()); }
     }
+    {
+        int var[6], ord[6], a64[6];
+        static const char *const names[6] = {"fz", "fy", "fx", "ix", "iy", "iz"};
+        DCHK(dfft_get_pass_choices(plan, var, ord, a64));
+        printf("CHOICES (variant/order/addr64)");
+        for (int k = 0; k < 6; k++) printf(" %s=%d/%d/%d", names[k], var[k], ord[k], a64[k]);
+        printf("\n");
+    }
     fwd(); inv();                                   // warm-up
     if (a.check && !dbg) {
         check_random<R><<<nblk, 256>>>((const R *)back, nreal, 1.0 / (double)n, part);
