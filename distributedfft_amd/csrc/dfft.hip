@@ -1672,13 +1672,14 @@ static double placement_probe(void *buf, size_t bytes)
     return best > 0 ? (double)bytes / (best * 1e-3) : 0.0;
 }
 
-// Default backing, placement-aware: a buffer of 1 GiB and more is first BUILT from chunks that lie far apart (below), probed, and kept
-// if the probe calls it good; otherwise candidates are drawn: the buffer is allocated up to DFFT_PLACEMENT_TRIES (default 6) times --
-// every candidate stays alive while the next is tried: a freed candidate's physical pages would simply be handed out again --, each
-// is probed (3 streaming passes: 8 ms for 16 GiB) and the fastest is kept; a good candidate ends the search at once.
-// "Good" is RELATIVE to this device: once per process and device a physically contiguous buffer (hipMalloc, <= 2 GiB: the slow case
-// by construction, profiles/r4_placement_probe.txt) is probed, and a candidate is good when it streams >= 1.08 x that rate (measured
-// classes: 5.2-5.5 TB/s against 6.0-6.6); DFFT_PLACEMENT_GOOD_TBPS sets an absolute threshold instead.
+// Default backing, placement-aware: for a buffer of 1 GiB and more one plain candidate is probed (3 streaming passes: 8 ms for 16 GiB)
+// and kept if the probe calls it good; if not, a buffer is BUILT from chunks that lie far apart (below) and probed; if that is not
+// good either, more plain candidates are drawn, up to DFFT_PLACEMENT_TRIES (default 6) in all -- every candidate stays alive while
+// the next is tried: a freed candidate's physical pages would simply be handed out again -- and the fastest is kept.
+// "Good" is RELATIVE to this device: once per process and device a physically contiguous buffer (hipMalloc, 2 GiB: the slow case by
+// construction, profiles/r4_placement_probe.txt) is probed, and a candidate is good when it streams >= 1.26 x that rate -- measured on
+// MI355X: the contiguous 2 GiB reference 4.50-4.62 TB/s, bad 16 GiB buffers 5.2-5.5 (<= 1.22 x), good ones 6.0-6.8 (>= 1.30 x),
+// profiles/r5_allocator.txt; DFFT_PLACEMENT_GOOD_TBPS sets an absolute threshold instead.
 // Bounded: everything alive during the search -- the spread pool or the drawn candidates -- stays within HALF of the free memory
 // divided by DFFT_RANKS_PER_DEVICE (processes that share the GPU all see the same free figure), and whatever fails on the way
 // (a racing process took the memory) ends in the plain recipe and finally in hipMalloc: the call never fails where hipMalloc succeeds.
@@ -1730,7 +1731,7 @@ static int dev_alloc_default(size_t bytes, void **out)
     info.bytes = bytes;
     info.ref_rate = abs_good > 0 ? 0.0 : placement_reference_rate();
     info.ref_s = seconds_since(t0);
-    info.threshold = abs_good > 0 ? abs_good : 1.08 * info.ref_rate;      // (0: no reference could be probed -- the first candidate is kept)
+    info.threshold = abs_good > 0 ? abs_good : 1.26 * info.ref_rate;      // (0: no reference could be probed -- the first candidate is kept)
     auto good = [&](double rate) { return rate == 0.0 || info.threshold == 0.0 || rate >= info.threshold; };
     // what this call may hold alive at any time, this buffer included
     auto budget = [&]() -> size_t {
@@ -1749,34 +1750,54 @@ static int dev_alloc_default(size_t bytes, void **out)
     void *best = nullptr;
     double best_rate = -1.0;
     std::vector<void *> losers;
-    // First a buffer BUILT to be good: 1 GiB chunks taken every K-th from K times as many.  16 chunks written at once stream at
-    // 6.0 TB/s when they are physical neighbours and 6.6 TB/s when 8 GiB apart; buffers built with K = 8 and K = 5 were good in 16 of
-    // 16 scatter passes (tools/kbench --vmm-spread 8 / 5, profiles/r4_placement_probe.txt).  The probe still judges it: if it is not
-    // good (an allocator that does not hand out chunks in physical order), candidates are drawn.
+    auto probe = [&](void *cand) {
+        const auto tp = std::chrono::steady_clock::now();
+        const double r = placement_probe(cand, bytes);
+        info.probe_s += seconds_since(tp);
+        return r;
+    };
+    auto room_for_one_more = [&]() { return (size_t)(losers.size() + (best ? 1 : 0) + 1) * bytes <= std::max(budget(), bytes); };
+    // 1. one plain candidate (milliseconds): on a device whose allocator hands out scattered chunks it is good as it is
+    //    (round 5, fresh processes: 6.05 / 6.15 / 6.52 TB/s for 32 + 16 + 16 GiB in 0.3 s altogether; round 4: three of ten)
     {
-        const int K = default_chunk_mib() >= 256 ? (int)std::min<size_t>((size_t)spread_want, budget() / bytes) : 1;
+        void *cand = nullptr;
+        if (dev_alloc_recipe(bytes, &cand) == 0) {
+            info.drawn++;
+            best = cand;
+            best_rate = probe(cand);
+            if (good(best_rate)) return done(best, "the first plain candidate", best_rate);
+        } else (void)hipGetLastError();
+    }
+    // 2. a buffer BUILT to be good: 1 GiB chunks taken every K-th from K times as many.  16 chunks written at once stream at
+    //    6.0 TB/s when they are physical neighbours and 6.6 TB/s when 8 GiB apart; buffers built with K = 8, 5 and 3 were good in every
+    //    run (tools/kbench --vmm-spread, profiles/r4_placement_probe.txt, profiles/r5_allocator.txt).  Creating the pool costs ~30 ms per
+    //    GiB (the driver clears fresh memory: tools/vmm_cycle), 2 - 3 s for a 16 GiB buffer -- which is why it is not the first thing tried.
+    {
+        size_t bud = budget();
+        const size_t held = best ? bytes : 0;
+        const int K = default_chunk_mib() >= 256 && bud > held ? (int)std::min<size_t>((size_t)spread_want, (bud - held) / bytes) : 1;
         void *cand = nullptr;
         if (K >= 3 && dev_alloc(bytes, default_chunk_mib(), &cand, K) == 0) {
             info.spread = K;
             info.create_s = g_alloc_times.create; info.map_s = g_alloc_times.map; info.release_s = g_alloc_times.release;
-            best = cand;
-            const auto tp = std::chrono::steady_clock::now();
-            best_rate = placement_probe(cand, bytes);
-            info.probe_s += seconds_since(tp);
-            if (good(best_rate)) return done(best, "built from chunks K apart", best_rate);
+            const double rate = probe(cand);
+            if (rate > best_rate || rate == 0.0) { if (best) losers.push_back(best); best = cand; best_rate = rate; }
+            else losers.push_back(cand);
+            if (good(rate)) { for (void *l : losers) (void)dev_free(l); return done(best, "built from chunks K apart", best_rate); }
         } else (void)hipGetLastError();
     }
-    for (int t = 0; t < tries; t++) {
-        // room for one more candidate next to what this call holds alive?
-        if ((size_t)(losers.size() + (best ? 1 : 0) + 1) * bytes > std::max(budget(), bytes) && (t || best)) break;
+    // 3. more plain candidates, all alive (a freed candidate's pages would simply be handed out again), the fastest wins
+    for (int t = 1; t < tries; t++) {
+        if (!room_for_one_more()) break;
         void *cand = nullptr;
         if (dev_alloc_recipe(bytes, &cand) != 0) { (void)hipGetLastError(); break; }
         info.drawn++;
-        const double rate = placement_probe(cand, bytes);
+        const double rate = probe(cand);
+        const double prev = best_rate;
         if (rate > best_rate) { if (best) losers.push_back(best); best = cand; best_rate = rate; }
         else losers.push_back(cand);
         if (good(rate)) break;
-        if (best_rate > 0 && rate < best_rate && best_rate >= 1.12 * rate) break;      // both classes seen: the best is of the good one
+        if (prev > 0 && rate > 0 && std::max(prev, rate) >= 1.12 * std::min(prev, rate)) break;      // both classes seen: the best is of the good one
     }
     for (void *l : losers) (void)dev_free(l);
     if (!best) {
@@ -1789,7 +1810,7 @@ static int dev_alloc_default(size_t bytes, void **out)
         if (rc != 0) return rc;
         return done(cand, "plain (the search found no room)", 0.0);
     }
-    return done(best, info.drawn ? "fastest of the drawn candidates" : "built from chunks K apart (below the threshold, nothing else fit)", best_rate);
+    return done(best, "the fastest candidate (none reached the threshold)", best_rate);
 }
 
 static int check_ready(dfft_plan *p)
@@ -2161,6 +2182,12 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
             // has such a configuration (2048 points: 4.80 -> 3.63 ms on rank 0 of 2 x 4 at 2048^3)
             // (a single rank's complex inverse runs the forward launches: there vinv is not used)
             if (has32(p->ax[1], ROLE_TRANSPOSED_STORE)) p->vinv[1] = ROLE_TRANSPOSED_STORE;
+            // 2048 points and more on a multi-rank plan: the forward y pass and the inverse x pass (the strided read of the API layout)
+            // run the streaming sibling of the tiled configuration -- what dfft_tune_variants picked on every 2048^3 plan measured
+            // (rank 0 of 2 x 4: y 4.93 -> 3.78 ms, x^-1 5.36 -> 4.46; of 8 x 1 the same two; profiles/r5_tuner_choices.txt).  The
+            // forward x pass and the inverse y pass lose with it (round 3), shorter lines were not measured: they keep their rule.
+            if (p->nranks > 1 && p->ax[1].N >= 2048 && has32(p->ax[1], ROLE_TILED_STREAM)) p->vfwd[1] = ROLE_TILED_STREAM;
+            if (p->nranks > 1 && p->ax[2].N >= 2048 && has32(p->ax[2], ROLE_TILED_STREAM)) p->vinv[2] = ROLE_TILED_STREAM;
             if (p->opt.spectral) {      // x-contiguous spectrum: the forward x pass stores natural lines like the inverse z pass
                 if (has32(p->ax[2], ROLE_NATURAL_STORE)) p->vfwd[2] = ROLE_NATURAL_STORE;
                 // ... and its inverse loads them: point fastest for the first pass only, the same-tile stores stay line fastest

@@ -3,7 +3,7 @@
 #   gpurun --timeout 2400 -- 'bash tools/final_check.sh r4'
 # full GPU parity suite, the default bench line, the same line under rocprofv3 --kernel-trace --stats, and the PMC traffic of the
 # library as it is (FETCH_SIZE / WRITE_SIZE in separate passes; the json records the library's sha256, bench.py refuses another's).
-TAG=${1:-r4}
+TAG=${1:-r5}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/final_check
 mkdir -p $OUT
@@ -32,7 +32,7 @@ for f in ("${TAG}_pmc_traffic.json", "${TAG}_pmc_traffic_f32_2048.json", "${TAG}
 PY
 timeout 1500 python -m pytest tests -x -q -m gpu --durations=12 > $OUT/${TAG}_pytest_gpu.txt 2>&1; tail -22 $OUT/${TAG}_pytest_gpu.txt
 timeout 500 python bench.py > $OUT/bench_${TAG}.json 2> $OUT/bench.err; tail -c 400 $OUT/bench_${TAG}.json; echo; tail -3 $OUT/bench.err
-timeout 300 python bench.py --tune-placement 6 --no-cpu-baseline --no-multi-rank-path --no-plain-leg > $OUT/bench_${TAG}_search.json 2> $OUT/bench_search.err   # the plan-level search, for comparison
+timeout 300 python bench.py --size 2048 --precision float --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_${TAG}_f32_2048.json 2> $OUT/bench_f32_2048.err; tail -c 300 $OUT/bench_${TAG}_f32_2048.json; echo
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o bench -- python $R/bench.py --no-cpu-baseline --no-multi-rank-path --no-plain-leg > $OUT/bench_${TAG}_profiled.json 2> $OUT/prof_bench.log )
 find $OUT/prof_bench -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_bench_kernel_stats.csv \;
 find $OUT/prof_bench -name "*kernel_trace.csv" -exec cp {} $OUT/${TAG}_bench_kernel_trace.csv \;
