@@ -487,3 +487,32 @@ def test_bench_xgmi_model_with_the_relay():
     s = bench.xgmi_model(16, 1024, 8, 8, 1)
     assert list(s) == ["exchange 2"] and "relay" not in s["exchange 2"] and s["exchange 2"]["links"] == 7
     assert bench.choose_partition(8, "auto") == (2, 4) and bench.choose_partition(4, "auto") == (2, 2) and bench.choose_partition(2, "auto") == (2, 1)
+
+
+def test_pass_choices_follow_the_role_rules():
+    """dfft_get_pass_choices on plans built without a GPU: the kernel configuration of every pass by the rules of dfft_init (the role
+    numbers of csrc/cfg_f64.hip.h / cfg_f32.hip.h) -- what dfft_tune_variants starts from and reports after it ran"""
+    import distributedfft_amd as dfft
+
+    def choices(prec, n, P1, P2, c2c=True, options=None, rank=0):
+        world = dfft.Comm.local(P1 * P2) if P1 * P2 > 1 else None
+        pl = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), world, precision=prec, rank=rank)
+        for k, v in (options or {}).items():
+            pl.setOption(k, v)
+        pl.initFFT(dfft.GlobalSize(n, n, n), dfft.Partition(P1, P2), allocate=False, c2c=c2c)
+        return {k: v[0] for k, v in pl.getPassChoices().items()}
+
+    # fp64 1024^3 on 2 x 4: streaming z passes, the strided-read configuration on the inverse x pass, streaming inverse y
+    assert choices("double", 1024, 2, 4) == {"fz": 3, "fy": 0, "fx": 0, "ix": 1, "iy": 3, "iz": 3}
+    # ... R2C: 129-wide rows are not whole tiles -- the inverse x pass keeps the default (8 lines, two workgroups per CU)
+    assert choices("double", 1024, 2, 4, c2c=False)["ix"] == 0
+    # ... x-contiguous spectrum: both x passes have natural lines on one side
+    assert choices("double", 1024, 2, 4, options={"spectral_layout": 1}) == {"fz": 3, "fy": 0, "fx": 3, "ix": 3, "iy": 3, "iz": 3}
+    # fp32 2048^3 on 2 x 4: natural-line z passes (4 / 5), the streaming tiled configuration on forward y and inverse x (round 5:
+    # what the tuner kept on every 2048^3 plan), whole-line transposed stores on the inverse y pass (7)
+    assert choices("float", 2048, 2, 4) == {"fz": 4, "fy": 9, "fx": 6, "ix": 9, "iy": 7, "iz": 5}
+    assert choices("float", 2048, 2, 4, options={"spectral_layout": 1}) == {"fz": 4, "fy": 9, "fx": 5, "ix": 1, "iy": 7, "iz": 5}
+    # one rank keeps the tiled configuration on its y pass (the rule is for multi-rank plans)
+    assert choices("float", 2048, 1, 1, options={"single_order": 0})["fy"] == 6
+    # a pinned pass stays pinned
+    assert choices("double", 1024, 2, 4, options={"variant_ix": 2})["ix"] == 2
