@@ -1672,20 +1672,21 @@ static double placement_probe(void *buf, size_t bytes)
     return best > 0 ? (double)bytes / (best * 1e-3) : 0.0;
 }
 
-// Default backing, placement-aware: for a buffer of 1 GiB and more one plain candidate is probed (3 streaming passes: 8 ms for 16 GiB)
-// and kept if the probe calls it good; if not, a buffer is BUILT from chunks that lie far apart (below) and probed; if that is not
-// good either, more plain candidates are drawn, up to DFFT_PLACEMENT_TRIES (default 6) in all -- every candidate stays alive while
-// the next is tried: a freed candidate's physical pages would simply be handed out again -- and the fastest is kept.
-// "Good" is RELATIVE to this device: once per process and device a physically contiguous buffer (hipMalloc, 2 GiB: the slow case by
-// construction, profiles/r4_placement_probe.txt) is probed, and a candidate is good when it streams >= 1.26 x that rate -- measured on
-// MI355X: the contiguous 2 GiB reference 4.50-4.62 TB/s, bad 16 GiB buffers 5.2-5.5 (<= 1.22 x), good ones 6.0-6.8 (>= 1.30 x),
-// profiles/r5_allocator.txt; DFFT_PLACEMENT_GOOD_TBPS sets an absolute threshold instead.
+// Default backing, placement-aware.  The first buffer of 1 GiB and more that a process allocates on a device is BUILT from chunks that
+// lie far apart (dev_alloc_default: every K-th of K times as many) and probed with a streaming write (3 passes: 8 ms for 16 GiB): that
+// is the good class by construction, and its rate becomes the device's yardstick.  Every later buffer first tries one plain candidate
+// (milliseconds) and keeps it if it streams at >= 0.92 x the yardstick; if not, it is built too; if even that is not good, more plain
+// candidates are drawn, up to DFFT_PLACEMENT_TRIES (default 6) in all -- every candidate stays alive while the next is tried: a freed
+// candidate's physical pages would simply be handed out again -- and the fastest is kept.
+// Nothing is absolute: the yardstick is measured on the device at hand, and a physically contiguous buffer (hipMalloc, 2 GiB: the slow
+// case by construction, profiles/r4_placement_probe.txt) is probed once to check that the built buffer really is of another class
+// (>= 1.2 x: MI355X 4.5 - 4.6 TB/s against 6.5 - 7.0); DFFT_PLACEMENT_GOOD_TBPS sets an absolute threshold instead.
 // Bounded: everything alive during the search -- the spread pool or the drawn candidates -- stays within HALF of the free memory
 // divided by DFFT_RANKS_PER_DEVICE (processes that share the GPU all see the same free figure), and whatever fails on the way
 // (a racing process took the memory) ends in the plain recipe and finally in hipMalloc: the call never fails where hipMalloc succeeds.
 // Purely local: every rank of a multi-rank plan does it by itself.  DFFT_PLACEMENT_TRIES=1 switches the probe off,
 // DFFT_PLACEMENT_SPREAD (default 5, 1 = off, <= 8) is K.  dfft_last_placement_info says what the last call did.
-// Measured (1024^3 fp64, fresh processes): profiles/bench_r4d*.json (K = 8), profiles/bench_r5*.json (K = 5).
+// Measured (1024^3 fp64, fresh processes): profiles/bench_r4d*.json (K = 8, pool always), profiles/r5_allocator.txt, profiles/bench_r5*.json.
 struct PlacementInfo {
     size_t bytes = 0;
     int spread = 0, drawn = 0, fallback = 0;
@@ -1718,6 +1719,8 @@ static double placement_reference_rate()
     return rate;
 }
 
+static std::map<int, double> g_place_good;     // device -> streaming rate of a buffer BUILT from chunks far apart (the good class, learned once)
+
 static int dev_alloc_default(size_t bytes, void **out)
 {
     if (bytes < ((size_t)32 << 20)) return dev_alloc(bytes, 0, out);      // small buffers live in the caches: nothing to place
@@ -1727,12 +1730,24 @@ static int dev_alloc_default(size_t bytes, void **out)
     static const double abs_good = [] { const char *e = getenv("DFFT_PLACEMENT_GOOD_TBPS"); return e ? atof(e) * 1e12 : 0.0; }();
     if (bytes < ((size_t)1 << 30) || tries == 1 || default_chunk_mib() == 0) return dev_alloc_recipe(bytes, out);
     const auto t0 = std::chrono::steady_clock::now();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     PlacementInfo info;
     info.bytes = bytes;
     info.ref_rate = abs_good > 0 ? 0.0 : placement_reference_rate();
     info.ref_s = seconds_since(t0);
-    info.threshold = abs_good > 0 ? abs_good : 1.26 * info.ref_rate;      // (0: no reference could be probed -- the first candidate is kept)
-    auto good = [&](double rate) { return rate == 0.0 || info.threshold == 0.0 || rate >= info.threshold; };
+    // The yardstick is measured on THIS device: the rate of a buffer built from chunks far apart (the good class by construction),
+    // learned by the first large allocation of the process; a candidate is good at >= 0.92 x it (measured: bad 5.2 - 5.76 TB/s, built
+    // buffers 6.46 - 7.0 => bad <= 0.89 x; a small buffer that probes a few % low is rebuilt, which costs it 0.3 s).  The contiguous
+    // reference only tells whether the built buffer really is of another class (>= 1.2 x), i.e. whether the yardstick means anything.
+    double yard = 0.0;
+    {
+        std::lock_guard<std::mutex> lk(g_place_mu);
+        auto it = g_place_good.find(dev);
+        if (it != g_place_good.end()) yard = it->second;
+    }
+    auto threshold = [&]() { return abs_good > 0 ? abs_good : 0.92 * yard; };      // 0: nothing known yet
+    auto good = [&](double rate) { return rate == 0.0 || (threshold() > 0 && rate >= threshold()); };
     // what this call may hold alive at any time, this buffer included
     auto budget = [&]() -> size_t {
         size_t free_b = 0, total_b = 0;
@@ -1740,8 +1755,8 @@ static int dev_alloc_default(size_t bytes, void **out)
         return free_b / 2 / (size_t)sharers;
     };
     auto done = [&](void *ptr, const char *kept, double rate) {
-        info.kept = kept; info.rate = rate;
-        info.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        info.kept = kept; info.rate = rate; info.threshold = threshold();
+        info.seconds = seconds_since(t0);
         std::lock_guard<std::mutex> lk(g_place_mu);
         g_place_last = info;
         *out = ptr;
@@ -1756,50 +1771,61 @@ static int dev_alloc_default(size_t bytes, void **out)
         info.probe_s += seconds_since(tp);
         return r;
     };
+    auto take = [&](void *cand, double rate) {
+        if (!best || rate > best_rate) { if (best) losers.push_back(best); best = cand; best_rate = rate; }
+        else losers.push_back(cand);
+    };
     auto room_for_one_more = [&]() { return (size_t)(losers.size() + (best ? 1 : 0) + 1) * bytes <= std::max(budget(), bytes); };
-    // 1. one plain candidate (milliseconds): on a device whose allocator hands out scattered chunks it is good as it is
-    //    (round 5, fresh processes: 6.05 / 6.15 / 6.52 TB/s for 32 + 16 + 16 GiB in 0.3 s altogether; round 4: three of ten)
+    auto finish = [&](const char *kept) {
+        for (void *l : losers) (void)dev_free(l);
+        return done(best, kept, best_rate);
+    };
+    // A buffer BUILT to be good: 1 GiB chunks taken every K-th from K times as many.  16 chunks written at once stream at 6.0 TB/s when
+    // they are physical neighbours and 6.6 TB/s when 8 GiB apart; buffers built with K = 8, 5, 4 and 3 were good in every run
+    // (tools/kbench --vmm-spread, profiles/r4_placement_probe.txt, profiles/r5_allocator.txt).  Creating the pool costs ~30 ms per GiB
+    // inside hipMemCreate (the driver clears fresh memory: tools/vmm_cycle): 2 - 4 s for a 16 GiB buffer.
+    auto build = [&]() -> bool {
+        const size_t bud = budget(), held = (size_t)(losers.size() + (best ? 1 : 0)) * bytes;
+        const int K = default_chunk_mib() >= 256 && bud > held ? (int)std::min<size_t>((size_t)spread_want, (bud - held) / bytes) : 1;
+        void *cand = nullptr;
+        if (K < 3 || dev_alloc(bytes, default_chunk_mib(), &cand, K) != 0) { (void)hipGetLastError(); return false; }
+        info.spread = K;
+        info.create_s = g_alloc_times.create; info.map_s = g_alloc_times.map; info.release_s = g_alloc_times.release;
+        const double rate = probe(cand);
+        // a built buffer that is clearly of another class than the contiguous reference is (and raises) the device's yardstick
+        if (rate > 0 && (info.ref_rate == 0.0 || rate >= 1.2 * info.ref_rate) && rate > yard) {
+            yard = rate;
+            std::lock_guard<std::mutex> lk(g_place_mu);
+            g_place_good[dev] = rate;
+        }
+        take(cand, rate);
+        return true;
+    };
+    if (threshold() == 0.0) {
+        // 1a. nothing known about this device yet: build this buffer and learn the yardstick from it
+        if (build()) return finish("built from chunks K apart (first large allocation: the device's yardstick)");
+    }
+    // 1b. one plain candidate (milliseconds): on a device whose allocator hands out scattered chunks it is often good as it is
     {
         void *cand = nullptr;
         if (dev_alloc_recipe(bytes, &cand) == 0) {
             info.drawn++;
-            best = cand;
-            best_rate = probe(cand);
-            if (good(best_rate)) return done(best, "the first plain candidate", best_rate);
+            take(cand, probe(cand));
+            if (threshold() == 0.0) return finish("the first plain candidate (no room to build a yardstick)");
+            if (good(best_rate)) return finish("the first plain candidate");
         } else (void)hipGetLastError();
     }
-    // 2. a buffer BUILT to be good: 1 GiB chunks taken every K-th from K times as many.  16 chunks written at once stream at
-    //    6.0 TB/s when they are physical neighbours and 6.6 TB/s when 8 GiB apart; buffers built with K = 8, 5 and 3 were good in every
-    //    run (tools/kbench --vmm-spread, profiles/r4_placement_probe.txt, profiles/r5_allocator.txt).  Creating the pool costs ~30 ms per
-    //    GiB (the driver clears fresh memory: tools/vmm_cycle), 2 - 3 s for a 16 GiB buffer -- which is why it is not the first thing tried.
-    {
-        size_t bud = budget();
-        const size_t held = best ? bytes : 0;
-        const int K = default_chunk_mib() >= 256 && bud > held ? (int)std::min<size_t>((size_t)spread_want, (bud - held) / bytes) : 1;
-        void *cand = nullptr;
-        if (K >= 3 && dev_alloc(bytes, default_chunk_mib(), &cand, K) == 0) {
-            info.spread = K;
-            info.create_s = g_alloc_times.create; info.map_s = g_alloc_times.map; info.release_s = g_alloc_times.release;
-            const double rate = probe(cand);
-            if (rate > best_rate || rate == 0.0) { if (best) losers.push_back(best); best = cand; best_rate = rate; }
-            else losers.push_back(cand);
-            if (good(rate)) { for (void *l : losers) (void)dev_free(l); return done(best, "built from chunks K apart", best_rate); }
-        } else (void)hipGetLastError();
-    }
+    // 2. not good: build the buffer
+    if (build() && good(best_rate)) return finish("built from chunks K apart");
     // 3. more plain candidates, all alive (a freed candidate's pages would simply be handed out again), the fastest wins
-    for (int t = 1; t < tries; t++) {
+    for (int t = 1; t < tries && best; t++) {
         if (!room_for_one_more()) break;
         void *cand = nullptr;
         if (dev_alloc_recipe(bytes, &cand) != 0) { (void)hipGetLastError(); break; }
         info.drawn++;
-        const double rate = probe(cand);
-        const double prev = best_rate;
-        if (rate > best_rate) { if (best) losers.push_back(best); best = cand; best_rate = rate; }
-        else losers.push_back(cand);
-        if (good(rate)) break;
-        if (prev > 0 && rate > 0 && std::max(prev, rate) >= 1.12 * std::min(prev, rate)) break;      // both classes seen: the best is of the good one
+        take(cand, probe(cand));
+        if (good(best_rate)) break;
     }
-    for (void *l : losers) (void)dev_free(l);
     if (!best) {
         // nothing could be created with the search's footprint (another process took the memory in between, a tight device): the plain
         // recipe once more on its own, then hipMalloc -- where that succeeds, so does this call
@@ -1810,7 +1836,7 @@ static int dev_alloc_default(size_t bytes, void **out)
         if (rc != 0) return rc;
         return done(cand, "plain (the search found no room)", 0.0);
     }
-    return done(best, "the fastest candidate (none reached the threshold)", best_rate);
+    return finish(good(best_rate) ? "the fastest candidate" : "the fastest candidate (none reached the threshold)");
 }
 
 static int check_ready(dfft_plan *p)

@@ -104,8 +104,8 @@ def test_tune_variants_keeps_the_transform_exact(prec):
         d_back = torch.empty_like(d_in)
         trials = plan.tuneVariants(d_in, d_out, d_back)
         # the plan as built + four order settings + the chosen orders + one trial per configuration number of the 512- / 1024-point
-        # lengths (fp64: 0, 1, 2, 3, 8; fp32: 0, 3, 4, 5, 6, 7, 9) + the address-form trial + the final choice -- pinned or not: the trials do not depend on it
-        assert len(trials) == (13 if prec == "double" else 15) and all(t > 0 for t in trials)
+        # lengths (fp64: 0, 1, 2, 3, 8; fp32: 0, 1, 3, 4, 5, 6, 7, 9) + the address-form trial + the final choice -- pinned or not: the trials do not depend on it
+        assert len(trials) == (13 if prec == "double" else 16) and all(t > 0 for t in trials)
         plan.execC2C(d_out, d_in, dfft.FORWARD)
         got = d_out[:g.size].cpu().numpy().reshape(shape)
         assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < TOL_FWD[prec]
@@ -160,7 +160,18 @@ def test_default_backing_reports_what_it_did():
     info = dfft.last_placement_info()
     assert info["bytes"] == nbytes and info["fallback"] == 0 and info["seconds"] < 30
     assert info["spread_K"] in (0, 3, 4, 5) and info["spread_K"] + info["candidates_drawn"] >= 1, info
-    assert info["contiguous_reference_TBps"] > 1.0 and abs(info["good_threshold_TBps"] - 1.26 * info["contiguous_reference_TBps"]) < 0.01, info
+    assert info["contiguous_reference_TBps"] > 1.0, info
+    # the first large allocation of a process is built and becomes the device's yardstick (threshold 0: nothing known before it);
+    # later ones are judged against 0.92 x the yardstick
+    if info["good_threshold_TBps"] == 0:
+        assert info["spread_K"] >= 3 and "yardstick" in info["kept"], info
+    else:
+        assert info["good_threshold_TBps"] > 0.9 * 1.2 * info["contiguous_reference_TBps"], info
+    # a second buffer: the yardstick is known now
+    b2 = dfft.DeviceBuffer.alloc(nbytes)
+    info2 = dfft.last_placement_info()
+    assert info2["good_threshold_TBps"] > 0 and info2["candidates_drawn"] >= 1, info2
+    b2.free()
     assert info["probe_TBps"] > 1.0, info
     t = b.tensor(torch.float64)
     t.fill_(3.0)
