@@ -623,7 +623,7 @@ def main():
                 "exposed_ms": round(exposed, 3),
                 "hidden_frac": round(1.0 - exposed / exch_ms, 3) if exch_ms > 0 else None}
 
-    def per_gpu_kernels(P1v, P2v, steps, options=None):
+    def per_gpu_kernels(P1v, P2v, steps, options=None, real=False):
         """rank 0's plan of a P1v x P2v grid on THIS GPU with the exchange stubbed out (a callback transport that moves
         nothing): the kernels run with that rank's descriptors -- 1/P of the volume, its peer segments, its pipeline chunks --
         on whatever the buffers hold, so the times are the compute one GPU of the multi-GPU run does per step."""
@@ -633,20 +633,34 @@ def main():
         pl = kind(dfft.Configurations(), stub, precision=prec, rank=0)
         for k, v in (options or {}).items():
             pl.setOption(k, v)
-        pl.initFFT(dfft.GlobalSize(N, N, N), dfft.Partition(P1v, P2v), allocate=False, c2c=True)
+        pl.initFFT(dfft.GlobalSize(N, N, N), dfft.Partition(P1v, P2v), allocate=False, c2c=not real)
         pl.setStream(stream)
         pl.setWorkArea(None)
         isz_v = pl.getInSize()
         nv = isz_v[0] * isz_v[1] * isz_v[2]
-        v_in = d_in[:nv]
+        # real = the reference's own API: execR2C / execC2R (real input block [xs][ys][Nz], Hermitian half [Nx][yo][zs] out)
+        v_in = torch.view_as_real(d_in).reshape(-1)[:nv] if real else d_in[:nv]
         v_out = d_out[:pl.getDomainSize() // esz]
+        v_back = None if aliased else (torch.view_as_real(d_back).reshape(-1)[:nv] if real else d_back[:nv])
+
+        def fwd():
+            if real:
+                pl.execR2C(v_out, v_in)
+            else:
+                pl.execC2C(v_out, v_in, dfft.FORWARD)
+
+        def inv():
+            if real:
+                pl.execC2R(v_in, v_out)
+            else:
+                pl.execC2C(v_in, v_out, dfft.INVERSE)
         tuned = None
         if not args.no_tune_variants:
             # the plan's own tuner (dfft_tune_variants: workgroup order and kernel configuration per pass, by measurement) -- what
             # bench.py calls at N > 1 before the warm-up, so these are the kernels a rank of the 8-GPU run would launch
             try:
                 with torch.cuda.stream(side):
-                    tr = pl.tuneVariants(v_in, v_out, None if aliased else d_back[:nv])   # without a third buffer: forward passes only
+                    tr = pl.tuneVariants(v_in, v_out, v_back)   # without a third buffer: forward passes only
                 tuned = {"as_built_ms": round(tr[0], 3), "chosen_ms": round(tr[-1], 3), "trials": len(tr),
                          "chosen (variant, order, addr64) per pass": pl.getPassChoices()}
             except Exception as e:   # noqa: BLE001
@@ -655,16 +669,18 @@ def main():
         acc = {}
         for i in range(steps + 2):
             with torch.cuda.stream(side):
-                pl.execC2C(v_out, v_in, dfft.FORWARD)
+                fwd()
                 ph = pl.getPhaseTimes(dfft.FORWARD)
-                pl.execC2C(v_in, v_out, dfft.INVERSE)
+                inv()
                 ph = ph + pl.getPhaseTimes(dfft.INVERSE)
             if i >= 2:
                 for name, ms in ph:
                     if "FFT" in name:
                         acc[name] = acc.get(name, 0.0) + ms
         torch.cuda.synchronize()
-        vb = 2.0 * esz * float(N) ** 3 / nr
+        osz_v = pl.getOutSize()
+        # bytes one pass moves: the local volume read once and written once (R2C: the Hermitian half of this rank, [Nx][yo][zs])
+        vb = 2.0 * esz * float(osz_v[0] * osz_v[1] * osz_v[2]) if real else 2.0 * esz * float(N) ** 3 / nr
         passes = {name: {"ms": round(ms / steps, 3), "TBps": round(vb / (ms / steps * 1e-3) / 1e12, 3)} for name, ms in acc.items()}
         tot = sum(v["ms"] for v in passes.values())
         res = {"decomposition": f"slab P={P1v}" if P2v == 1 else f"pencil {P1v}x{P2v}", "rank": 0,
@@ -673,6 +689,8 @@ def main():
                "tune_variants": tuned, "xgmi_model_per_transform": xgmi_model(esz, N, nr, P1v, P2v)}
         if options:
             res["options"] = dict(options)
+        if real:
+            res["transform"] = "execR2C + execC2R (the reference's own API); bytes per pass = 2 x the rank's Hermitian half"
         del pl
         stub.destroy()
         return res
@@ -891,6 +909,10 @@ def main():
         per_gpu_8 = [per_gpu_kernels(2, 4, 5), per_gpu_kernels(8, 1, 5)]
         # the same plans with the spectrum kept x-contiguous (option spectral_layout = 1: neither x pass touches the point-major layout)
         per_gpu_8_spectral = [per_gpu_kernels(2, 4, 5, {"spectral_layout": 1}), per_gpu_kernels(8, 1, 5, {"spectral_layout": 1})]
+        # the reference's own API on the BASELINE grid (execR2C / execC2R, pencil 2 x 4), and what the pipeline depth costs the kernels:
+        # every chunk launch of a pass pays ~20 us of launch / drain, which the exchanges hide on real links
+        per_gpu_8_more = [per_gpu_kernels(2, 4, 5, None, real=True), per_gpu_kernels(2, 4, 5, {"spectral_layout": 1}, real=True),
+                          per_gpu_kernels(2, 4, 5, {"pipeline_chunks": 1}), per_gpu_kernels(2, 4, 5, {"pipeline_chunks": 1}, real=True)]
         fill(d_in)
 
     # the other decomposition (slab over all ranks next to the BASELINE pencil grid, or the reverse) in the same run
@@ -941,6 +963,9 @@ def main():
                         "device time of the kernels one GPU of the 8-GPU run launches per step (1/8 of the volume each)",
                 "plans": per_gpu_8,
                 "spectral_layout_plans": per_gpu_8_spectral,
+                "r2c_and_depth_plans": per_gpu_8_more,
+                "r2c_and_depth_what": "pencil 2x4: execR2C + execC2R with the reference layout and with spectral_layout = 1, then C2C and R2C with "
+                                      "ONE chunk per pass (pipeline_chunks = 1: the kernels without the per-chunk launch cost)",
                 "spectral_layout_what": "the same plans with dfft_set_option(plan, 'spectral_layout', 1): the spectrum block is [yo][zs][Nx] "
                                         "(x-contiguous; dfft_get_out_strides), forward x stores and inverse x loads natural lines -- for callers "
                                         "that go forward -> pointwise -> inverse; sizes, starts and exchange tables are the reference's"}

@@ -1672,12 +1672,12 @@ static double placement_probe(void *buf, size_t bytes)
     return best > 0 ? (double)bytes / (best * 1e-3) : 0.0;
 }
 
-// Default backing, placement-aware.  The first buffer of 1 GiB and more that a process allocates on a device is BUILT from chunks that
-// lie far apart (dev_alloc_default: every K-th of K times as many) and probed with a streaming write (3 passes: 8 ms for 16 GiB): that
-// is the good class by construction, and its rate becomes the device's yardstick.  Every later buffer first tries one plain candidate
-// (milliseconds) and keeps it if it streams at >= 0.92 x the yardstick; if not, it is built too; if even that is not good, more plain
-// candidates are drawn, up to DFFT_PLACEMENT_TRIES (default 6) in all -- every candidate stays alive while the next is tried: a freed
-// candidate's physical pages would simply be handed out again -- and the fastest is kept.
+// Default backing, placement-aware.  A buffer of 1 GiB and more is BUILT from chunks that lie far apart (dev_alloc_default: every K-th
+// of K times as many, as far as the memory budget below allows) and probed with a streaming write (3 passes: 8 ms for 16 GiB): the good
+// class by construction; the first one of a process gives the device its yardstick.  A built buffer at >= 0.92 x the yardstick is kept;
+// where there is no room for a pool, or the built buffer falls short, plain candidates are drawn, up to DFFT_PLACEMENT_TRIES (default 6)
+// -- every candidate stays alive while the next is tried: a freed candidate's physical pages would simply be handed out again -- and
+// the fastest of everything probed is kept.
 // Nothing is absolute: the yardstick is measured on the device at hand, and a physically contiguous buffer (hipMalloc, 2 GiB: the slow
 // case by construction, profiles/r4_placement_probe.txt) is probed once to check that the built buffer really is of another class
 // (>= 1.2 x: MI355X 4.5 - 4.6 TB/s against 6.5 - 7.0); DFFT_PLACEMENT_GOOD_TBPS sets an absolute threshold instead.
@@ -1801,22 +1801,23 @@ static int dev_alloc_default(size_t bytes, void **out)
         take(cand, rate);
         return true;
     };
-    if (threshold() == 0.0) {
-        // 1a. nothing known about this device yet: build this buffer and learn the yardstick from it
-        if (build()) return finish("built from chunks K apart (first large allocation: the device's yardstick)");
-    }
-    // 1b. one plain candidate (milliseconds): on a device whose allocator hands out scattered chunks it is often good as it is
+    // 1. build the buffer (2 - 4 s per 16 GiB, see above): the first one of a process also gives the device its yardstick.  Building
+    //    comes first because it gave the best scatter passes in every measurement (1024^3 fp64: 33.5 - 33.6 ms per forward + inverse
+    //    in six fresh processes with every buffer built, 34.1 - 34.6 with plain candidates accepted at 0.92 x the yardstick:
+    //    profiles/bench_r4d*.json, profiles/r5_allocator.txt); DFFT_PLACEMENT_SPREAD=1 skips it (milliseconds, plain candidates only)
+    const bool first = threshold() == 0.0;
+    if (build() && (first || good(best_rate)))
+        return finish(first ? "built from chunks K apart (first large allocation: the device's yardstick)" : "built from chunks K apart");
+    // 2. no room for a pool, or the built buffer is below the yardstick: a plain candidate (milliseconds)
     {
         void *cand = nullptr;
         if (dev_alloc_recipe(bytes, &cand) == 0) {
             info.drawn++;
             take(cand, probe(cand));
             if (threshold() == 0.0) return finish("the first plain candidate (no room to build a yardstick)");
-            if (good(best_rate)) return finish("the first plain candidate");
+            if (good(best_rate)) return finish("the fastest candidate");
         } else (void)hipGetLastError();
     }
-    // 2. not good: build the buffer
-    if (build() && good(best_rate)) return finish("built from chunks K apart");
     // 3. more plain candidates, all alive (a freed candidate's pages would simply be handed out again), the fastest wins
     for (int t = 1; t < tries && best; t++) {
         if (!room_for_one_more()) break;

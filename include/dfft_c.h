@@ -344,19 +344,19 @@ int dfft_axis_plan_info(int precision, size_t N, int two_level, size_t info[8]);
  * dfft_malloc: chunk_mib = 0 is hipMalloc; otherwise one virtual range backed by physical allocations of chunk_mib MiB
  * each (HIP virtual-memory API).  chunk_mib = DFFT_CHUNK_DEFAULT: the library's default backing, which is also what the library
  * uses for a work area it owns (dfft_init(allocate = 1), dfft_set_work_area(plan, NULL, NULL)): 1 GiB chunks (smaller ones and
- * finally hipMalloc if that fails) and, for buffers of 1 GiB and more, PLACEMENT.  The first such buffer of a process is built from
- * chunks that lie far apart (every K-th of K times as many, K = 5 unless DFFT_PLACEMENT_SPREAD says otherwise) and a streaming write is
- * timed on it (8 ms per 16 GiB): the good class by construction, whose rate becomes the device's yardstick.  Every later buffer first
- * tries one plain candidate (milliseconds) and keeps it at >= 0.92 x the yardstick; if not it is built too, and if even that is not
- * good, plain candidates are drawn, up to DFFT_PLACEMENT_TRIES (6) in all, all alive, and the fastest is kept.  Nothing is absolute: the
+ * finally hipMalloc if that fails) and, for buffers of 1 GiB and more, PLACEMENT.  Such a buffer is built from chunks that lie far
+ * apart (every K-th of K times as many, K = 5 unless DFFT_PLACEMENT_SPREAD says otherwise or memory is short) and a streaming write is
+ * timed on it (8 ms per 16 GiB): the good class by construction; the first one of a process gives the device its yardstick, and a
+ * built buffer at >= 0.92 x the yardstick is kept.  Where there is no room for the pool, or the built buffer falls short,
+ * plain candidates are drawn, up to DFFT_PLACEMENT_TRIES (6), all alive, and the fastest of everything probed is kept.  Nothing is absolute: the
  * yardstick is measured on the device at hand (MI355X: built buffers 6.5 - 7.0 TB/s, bad ones 5.2 - 5.8, a contiguous hipMalloc
  * reference 4.5 - 4.6; the plan's scatter passes follow: 5.5 vs 5.9 - 6.5 ms per pass at 1024^3 fp64, profiles/r4_placement_probe.txt,
  * profiles/r5_allocator.txt); DFFT_PLACEMENT_GOOD_TBPS sets an absolute threshold.  Everything alive during the search stays within
  * half of the free memory divided by DFFT_RANKS_PER_DEVICE (set it when several processes share a GPU), and whatever fails on the way
  * falls back to the plain recipe and then to hipMalloc: the call never fails where hipMalloc would succeed.  1024^3 fp64 forward +
  * inverse on buffers from this call: 33.5 - 33.6 ms, on hipMalloc buffers 37.0 - 38.3.  Local to the device (no plan, no collective):
- * safe on every rank of a multi-rank job.  Costs milliseconds when the plain candidate is good and 2 - 4 s when a 16 GiB buffer is built
- * (the driver clears fresh memory inside hipMemCreate at ~30 ms per GiB: tools/vmm_cycle).  Environment: DFFT_DEFAULT_CHUNK_MIB
+ * safe on every rank of a multi-rank job.  Costs 2 - 4 s per 16 GiB buffer (the driver clears fresh memory inside hipMemCreate at
+ * ~30 ms per GiB: tools/vmm_cycle), 0.3 s per 2 GiB; DFFT_PLACEMENT_SPREAD=1: milliseconds (plain candidates only, no yardstick).  Environment: DFFT_DEFAULT_CHUNK_MIB
  * (0 = hipMalloc), DFFT_PLACEMENT_TRIES (1 = no probe), DFFT_PLACEMENT_SPREAD, DFFT_RANKS_PER_DEVICE, DFFT_PLACEMENT_GOOD_TBPS.
  * dfft_last_placement_info writes what the last placement-aware allocation of the process did (a JSON object: K, candidates drawn,
  * probe / reference / threshold rates, seconds by phase, what was kept).  Free with dfft_free (which also takes pointers it did not
