@@ -481,9 +481,11 @@ static int relay_reserve(RelayBuf &b, size_t bytes, bool device, hipStream_t str
     relay_buf_free(b);
     bytes = (bytes + 4095) & ~(size_t)4095;
     if (device) {
-        // the library's default backing (csrc/dfft.hip dev_alloc_default: hipMalloc'ed buffers are the slow scatter / stream targets)
+        // the library's virtual-memory recipe (1 GiB physical chunks; csrc/dfft.hip dev_alloc) WITHOUT the placement search of the default
+        // backing: staging is written and read front to back by the transport's copies, not scattered into -- and a search that builds a
+        // pool of K x the buffer has no place inside an exchange
         void *ptr = nullptr;
-        if (int r = dfft_malloc(bytes, DFFT_CHUNK_DEFAULT, &ptr)) return r;
+        if (int r = dfft_malloc(bytes, 1024, &ptr)) return r;
         b.p = (char *)ptr;
     } else if (!(b.p = (char *)malloc(bytes))) { set_error("relay: out of host memory"); return 1; }
     b.cap = bytes;

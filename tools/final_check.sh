@@ -30,8 +30,14 @@ for f in ("${TAG}_pmc_traffic.json", "${TAG}_pmc_traffic_f32_2048.json", "${TAG}
     except Exception as e:
         print(f, "unreadable", e)
 PY
-timeout 1500 python -m pytest tests -x -q -m gpu --durations=40 > $OUT/${TAG}_pytest_gpu.txt 2>&1; tail -22 $OUT/${TAG}_pytest_gpu.txt
-timeout 500 python bench.py > $OUT/bench_${TAG}.json 2> $OUT/bench.err; tail -c 400 $OUT/bench_${TAG}.json; echo; tail -3 $OUT/bench.err
+# SUITE=full (default): the whole GPU suite; SUITE=<pytest -k expression>: only the tests that expression selects (a late change of one subsystem)
+if [ "${SUITE:-full}" = "full" ]; then
+  timeout 1500 python -m pytest tests -x -q -m gpu --durations=40 > $OUT/${TAG}_pytest_gpu.txt 2>&1; tail -22 $OUT/${TAG}_pytest_gpu.txt
+else
+  timeout 900 python -m pytest tests -x -q -m gpu -k "$SUITE" --durations=10 > $OUT/${TAG}_pytest_gpu_subset.txt 2>&1; tail -14 $OUT/${TAG}_pytest_gpu_subset.txt
+fi
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+T0=$(date +%s); timeout 500 python bench.py > $OUT/bench_${TAG}.json 2> $OUT/bench.err; echo "bench.py (default flags) took $(( $(date +%s) - T0 )) s"; tail -c 400 $OUT/bench_${TAG}.json; echo; tail -3 $OUT/bench.err
 timeout 300 python bench.py --size 2048 --precision float --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_${TAG}_f32_2048.json 2> $OUT/bench_f32_2048.err; tail -c 300 $OUT/bench_${TAG}_f32_2048.json; echo
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o bench -- python $R/bench.py --no-cpu-baseline --no-multi-rank-path --no-plain-leg > $OUT/bench_${TAG}_profiled.json 2> $OUT/prof_bench.log )
 find $OUT/prof_bench -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_bench_kernel_stats.csv \;
