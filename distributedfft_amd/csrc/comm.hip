@@ -481,11 +481,14 @@ static int relay_reserve(RelayBuf &b, size_t bytes, bool device, hipStream_t str
     relay_buf_free(b);
     bytes = (bytes + 4095) & ~(size_t)4095;
     if (device) {
-        // the library's virtual-memory recipe (1 GiB physical chunks; csrc/dfft.hip dev_alloc) WITHOUT the placement search of the default
-        // backing: staging is written and read front to back by the transport's copies, not scattered into -- and a search that builds a
-        // pool of K x the buffer has no place inside an exchange
+        // plain hipMalloc, on purpose.  Staging is written and read front to back by the transport's copies, not scattered into, so the
+        // placement of the default backing buys nothing here -- and a buffer that is reallocated while other host threads keep
+        // enqueueing work must not be a virtual-memory range: with staging from hipMemCreate / hipMemMap, unmapped and re-created when
+        // a larger exchange table came along, the round trips of 8 virtual ranks differed from the direct exchange in 9-12 of 12 runs
+        // (never with hipMalloc, never when the ranges were leaked instead of unmapped, poisoned staging made no difference: the
+        // relay's ordering is not the cause; tools/exp/r5_relay_stress.py, profiles/r5_relay_stress.txt)
         void *ptr = nullptr;
-        if (int r = dfft_malloc(bytes, 1024, &ptr)) return r;
+        if (int r = dfft_malloc(bytes, 0, &ptr)) return r;
         b.p = (char *)ptr;
     } else if (!(b.p = (char *)malloc(bytes))) { set_error("relay: out of host memory"); return 1; }
     b.cap = bytes;
@@ -643,6 +646,10 @@ int relay_alltoallv(dfft_comm *comm, RelayCache *cache, uint64_t tag, int myrank
         if (ready) HIP_TRY(hipStreamWaitEvent(s1, ready, 0));
         else { HIP_TRY(hipEventRecord(L.in, stream)); HIP_TRY(hipStreamWaitEvent(s1, L.in, 0)); }
     }
+    // debugging aid (DFFT_RELAY_POISON=1): the staging buffer is overwritten before hop 1 fills it, on hop 1's stream -- a hop 2 that
+    // forwarded a part before hop 1 had written it would then deliver the poison instead of whatever an earlier exchange left there
+    static const bool poison = [] { const char *e = getenv("DFFT_RELAY_POISON"); return e && atoi(e) != 0; }();
+    if (poison && device) HIP_TRY(hipMemsetAsync(st.p, 0xEE, M.staging, s1));
     // self block: a local copy, as in every transport
     if (rcount[me]) {
         if (device) HIP_TRY(hipMemcpyAsync(rb + rdispl[me], sb + sdispl[me], rcount[me], hipMemcpyDeviceToDevice, s1));

@@ -106,3 +106,16 @@ def test_relay_overlap_option_values():
         from distributedfft_amd._lib import check, lib
         v = C.c_long(0)
         check(lib().dfft_comm_get_counter(world._h, b"nonsense", C.byref(v)))
+
+
+def test_relay_repeated_runs_stay_bit_identical():
+    """fresh plans again and again on the grid whose exchange tables differ in size from chunk to chunk (so that the staging buffers
+    are re-allocated on the way): every run must equal the direct exchange bit for bit.  (Round 5: with staging from the virtual-memory
+    API, unmapped and re-created under eight enqueueing host threads, 9-12 of 12 round trips differed; staging is plain hipMalloc.)"""
+    shape, P1, P2, chunks = (66, 50, 38), 2, 4, 3
+    _, _, spec_d, backs_d = run_distributed(shape, P1, P2, "double", chunks=chunks)
+    for rep in range(6):
+        _, _, spec_r, backs_r = run_distributed(shape, P1, P2, "double", chunks=chunks, comm_options={"relay": 3, "relay_overlap": rep % 2})
+        for r in range(P1 * P2):
+            assert np.array_equal(spec_d[r], spec_r[r]), (rep, r)
+            assert np.array_equal(backs_d[r], backs_r[r]), (rep, r)
