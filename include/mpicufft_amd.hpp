@@ -167,6 +167,10 @@ public:
                 if (pidx == 0) check(dfft_rccl_unique_id(id));
                 MPI_Bcast(id, 128, MPI_BYTE, 0, world);
                 check(dfft_comm_create_rccl(id, pcnt, pidx, &comm_));
+                // pencil classes: the row- and the column-group exchange use disjoint xGMI links -- a duplicated communicator lets them be
+                // on the wire together, two more carry the relay's first hops (include/dfft_c.h "dup_channel"; collective: every rank
+                // of the world constructs the same class).  A librccl without ncclCommSplit keeps the single communicator.
+                if (kind == DFFT_PENCIL || kind == DFFT_PENCIL_OPT1) (void)dfft_comm_set_option(comm_, "dup_channel", 3);
             } else {                                   // host-staged MPI, ranks may share a GPU
                 staged_ = new DfftHostStagedMPI(world);
                 check(dfft_comm_create_callback(pcnt, pidx, &DfftHostStagedMPI::alltoallv, staged_, &comm_));
