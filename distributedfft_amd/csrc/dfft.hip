@@ -1674,7 +1674,7 @@ static double placement_probe(void *buf, size_t bytes)
 
 // Default backing, placement-aware.  A buffer of 1 GiB and more is BUILT from chunks that lie far apart (dev_alloc_default: every K-th
 // of K times as many, as far as the memory budget below allows) and probed with a streaming write (3 passes: 8 ms for 16 GiB): the good
-// class by construction; the first one of a process gives the device its yardstick.  A built buffer at >= 0.92 x the yardstick is kept;
+// class by construction; the first one of a process gives the device its yardstick.  A built buffer at >= 0.95 x the yardstick is kept;
 // where there is no room for a pool, or the built buffer falls short, plain candidates are drawn, up to DFFT_PLACEMENT_TRIES (default 6)
 // -- every candidate stays alive while the next is tried: a freed candidate's physical pages would simply be handed out again -- and
 // the fastest of everything probed is kept.
@@ -1737,8 +1737,8 @@ static int dev_alloc_default(size_t bytes, void **out)
     info.ref_rate = abs_good > 0 ? 0.0 : placement_reference_rate();
     info.ref_s = seconds_since(t0);
     // The yardstick is measured on THIS device: the rate of a buffer built from chunks far apart (the good class by construction),
-    // learned by the first large allocation of the process; a candidate is good at >= 0.92 x it (measured: bad 5.2 - 5.76 TB/s, built
-    // buffers 6.46 - 7.0 => bad <= 0.89 x; a small buffer that probes a few % low is rebuilt, which costs it 0.3 s).  The contiguous
+    // learned by the first large allocation of the process; a candidate is good at >= 0.95 x it (measured: bad 5.2 - 5.9 TB/s, built
+    // buffers 6.4 - 7.0; a small buffer that probes a few % low draws a few more candidates, milliseconds each).  The contiguous
     // reference only tells whether the built buffer really is of another class (>= 1.2 x), i.e. whether the yardstick means anything.
     double yard = 0.0;
     {
@@ -1746,7 +1746,7 @@ static int dev_alloc_default(size_t bytes, void **out)
         auto it = g_place_good.find(dev);
         if (it != g_place_good.end()) yard = it->second;
     }
-    auto threshold = [&]() { return abs_good > 0 ? abs_good : 0.92 * yard; };      // 0: nothing known yet
+    auto threshold = [&]() { return abs_good > 0 ? abs_good : 0.95 * yard; };      // 0: nothing known yet
     auto good = [&](double rate) { return rate == 0.0 || (threshold() > 0 && rate >= threshold()); };
     // what this call may hold alive at any time, this buffer included
     auto budget = [&]() -> size_t {
@@ -1802,30 +1802,29 @@ static int dev_alloc_default(size_t bytes, void **out)
         return true;
     };
     // 1. build the buffer (2 - 4 s per 16 GiB, see above): the first one of a process also gives the device its yardstick.  Building
-    //    comes first because it gave the best scatter passes in every measurement (1024^3 fp64: 33.5 - 33.6 ms per forward + inverse
-    //    in six fresh processes with every buffer built, 34.1 - 34.6 with plain candidates accepted at 0.92 x the yardstick:
-    //    profiles/bench_r4d*.json, profiles/r5_allocator.txt); DFFT_PLACEMENT_SPREAD=1 skips it (milliseconds, plain candidates only)
+    //    comes first because it gave the best scatter passes in every measurement (1024^3 fp64: 33.4 - 33.8 ms per forward + inverse
+    //    with every buffer built, 34.1 - 34.6 with plain candidates accepted first: profiles/bench_r4d*.json, profiles/r5_allocator.txt);
+    //    DFFT_PLACEMENT_SPREAD=1 skips it (milliseconds, plain candidates only)
     const bool first = threshold() == 0.0;
-    if (build() && (first || good(best_rate)))
+    const bool built = build();
+    // (a first built buffer that is not clearly of another class than the contiguous reference -- 1.3 x -- is no yardstick: candidates follow)
+    if (built && (first ? (info.ref_rate == 0.0 || best_rate >= 1.3 * info.ref_rate) : good(best_rate)))
         return finish(first ? "built from chunks K apart (first large allocation: the device's yardstick)" : "built from chunks K apart");
-    // 2. no room for a pool, or the built buffer is below the yardstick: a plain candidate (milliseconds)
-    {
-        void *cand = nullptr;
-        if (dev_alloc_recipe(bytes, &cand) == 0) {
-            info.drawn++;
-            take(cand, probe(cand));
-            if (threshold() == 0.0) return finish("the first plain candidate (no room to build a yardstick)");
-            if (good(best_rate)) return finish("the fastest candidate");
-        } else (void)hipGetLastError();
-    }
-    // 3. more plain candidates, all alive (a freed candidate's pages would simply be handed out again), the fastest wins
-    for (int t = 1; t < tries && best; t++) {
-        if (!room_for_one_more()) break;
+    // 2. no room for a pool, or the built buffer falls short: plain candidates (milliseconds each), all alive (a freed candidate's pages
+    //    would simply be handed out again), until one is good; the fastest of everything probed is kept
+    for (int t = 0; t < tries; t++) {
+        if (best && !room_for_one_more()) break;
         void *cand = nullptr;
         if (dev_alloc_recipe(bytes, &cand) != 0) { (void)hipGetLastError(); break; }
         info.drawn++;
         take(cand, probe(cand));
-        if (good(best_rate)) break;
+        if (threshold() > 0 ? good(best_rate) : !built) break;      // (no yardstick and no room to build one: the first candidate is it)
+    }
+    if (best && threshold() == 0.0 && best_rate > 0 && (info.ref_rate == 0.0 || best_rate >= 1.2 * info.ref_rate)) {
+        // nothing built was fit to be the yardstick: the best buffer seen is
+        yard = best_rate;
+        std::lock_guard<std::mutex> lk(g_place_mu);
+        g_place_good[dev] = best_rate;
     }
     if (!best) {
         // nothing could be created with the search's footprint (another process took the memory in between, a tight device): the plain
@@ -1837,7 +1836,8 @@ static int dev_alloc_default(size_t bytes, void **out)
         if (rc != 0) return rc;
         return done(cand, "plain (the search found no room)", 0.0);
     }
-    return finish(good(best_rate) ? "the fastest candidate" : "the fastest candidate (none reached the threshold)");
+    if (first && !built) return finish("the first plain candidate (no room to build a yardstick)");
+    return finish(threshold() > 0 && good(best_rate) ? "the fastest candidate" : "the fastest candidate (none reached the threshold)");
 }
 
 static int check_ready(dfft_plan *p)

@@ -347,7 +347,7 @@ int dfft_axis_plan_info(int precision, size_t N, int two_level, size_t info[8]);
  * finally hipMalloc if that fails) and, for buffers of 1 GiB and more, PLACEMENT.  Such a buffer is built from chunks that lie far
  * apart (every K-th of K times as many, K = 5 unless DFFT_PLACEMENT_SPREAD says otherwise or memory is short) and a streaming write is
  * timed on it (8 ms per 16 GiB): the good class by construction; the first one of a process gives the device its yardstick, and a
- * built buffer at >= 0.92 x the yardstick is kept.  Where there is no room for the pool, or the built buffer falls short,
+ * built buffer at >= 0.95 x the yardstick is kept.  Where there is no room for the pool, or the built buffer falls short,
  * plain candidates are drawn, up to DFFT_PLACEMENT_TRIES (6), all alive, and the fastest of everything probed is kept.  Nothing is absolute: the
  * yardstick is measured on the device at hand (MI355X: built buffers 6.5 - 7.0 TB/s, bad ones 5.2 - 5.8, a contiguous hipMalloc
  * reference 4.5 - 4.6; the plan's scatter passes follow: 5.5 vs 5.9 - 6.5 ms per pass at 1024^3 fp64, profiles/r4_placement_probe.txt,
