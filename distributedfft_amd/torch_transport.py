@@ -30,7 +30,9 @@ from . import api
 
 
 class TorchComm:
-    def __init__(self, dist, rank, world, P1, P2):
+    def __init__(self, dist, rank, world, P1, P2, list_callback=True):
+        """list_callback = False: no point-to-point schedule callback -- the library then runs a relay hop as group - 1 all-to-all-v
+        layers through `_alltoallv` (what a transport without a native schedule does; tests)"""
         self.dist, self.rank, self.world = dist, rank, world
         self.groups = {}
         # every rank creates every group, in the same order (torch.distributed requirement)
@@ -44,7 +46,8 @@ class TorchComm:
         self.groups.setdefault(tuple(range(world)), None)
         self.buffers = []
         self.comm = api.Comm.callback(world, rank, self._alltoallv)
-        self.comm.setListCallback(self._sendrecv_list)
+        if list_callback:
+            self.comm.setListCallback(self._sendrecv_list)
         self.calls = 0
         self.p2p_calls = 0
         self.list_calls = 0

@@ -88,7 +88,8 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     if len(sys.argv) > 4:
         return sequence_main(sys.argv[4], rank, world, shape)
-    tc = TorchComm(dist, rank, world, P1, P2)
+    layered = os.environ.get("DFFT_TEST_NO_LIST") == "1"      # no schedule callback: a relay hop runs as group - 1 all-to-all-v layers
+    tc = TorchComm(dist, rank, world, P1, P2, list_callback=not layered)
     relay = int(os.environ.get("DFFT_TEST_RELAY", "0"))
     if relay:       # two-hop relay of the group exchanges (include/dfft_c.h: dfft_comm_set_option "relay")
         tc.setOption("relay", relay)
@@ -161,11 +162,17 @@ def main():
         return 1, 0
     c2, l2 = ncalls(1, P1)
     c1, l1 = ncalls(2, P2)
-    assert tc.calls == c2 + 2 * c1 and tc.p2p_calls == 0 and tc.list_calls == l2 + 2 * l1, (tc.calls, tc.p2p_calls, tc.list_calls, c2, c1, l2, l1)
     cnt = tc.comm.counters()
     nrel = (1 if l2 else 0) + (2 if l1 else 0)
-    assert cnt["relayed"] == nrel and cnt["list"] == 2 * nrel and cnt["relay_meta"] == nrel, cnt
-    assert cnt["alltoallv"] == tc.calls, (cnt, tc.calls)
+    assert cnt["relayed"] == nrel and cnt["relay_meta"] == nrel, cnt
+    if not layered:
+        assert tc.calls == c2 + 2 * c1 and tc.p2p_calls == 0 and tc.list_calls == l2 + 2 * l1, (tc.calls, tc.p2p_calls, tc.list_calls, c2, c1, l2, l1)
+        assert cnt["list"] == 2 * nrel and cnt["alltoallv"] == tc.calls, (cnt, tc.calls)
+    else:
+        # every hop of a relayed exchange is group - 1 all-to-all-v layers whose pieces are not back to back (the transport's per-peer path)
+        layers = (2 * (P1 - 1) if l2 else 0) + (2 * 2 * (P2 - 1) if l1 else 0)
+        assert cnt["list"] == 0 and tc.list_calls == 0 and cnt["alltoallv"] == tc.calls == c2 + 2 * c1 + layers, (cnt, tc.calls, layers)
+        assert tc.p2p_calls == layers, (tc.p2p_calls, layers)
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank} ok err={err:.2e}")

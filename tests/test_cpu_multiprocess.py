@@ -34,6 +34,14 @@ def test_gloo_relayed_exchange_path(P1, P2, shape, relay):
     run_world(P1, P2, shape, "", {"DFFT_TEST_RELAY": str(relay)})
 
 
+@pytest.mark.parametrize("P1,P2,shape,relay", [(2, 2, "16x16x8", 3), (2, 3, "12x18x16", 1), (3, 2, "18x16x10", 2)])
+def test_gloo_relayed_exchange_on_a_transport_without_schedules(P1, P2, shape, relay):
+    """a transport that has no point-to-point schedule of its own (here: the torch transport with its list callback left out; in the
+    product: the host-staged MPI shim) runs every hop of the relay as group - 1 all-to-all-v layers (dfft_comm::sendrecv_list's
+    default): same bytes in the same places, counted by dfft_comm_get_counter"""
+    run_world(P1, P2, shape, "", {"DFFT_TEST_RELAY": str(relay), "DFFT_TEST_NO_LIST": "1"})
+
+
 def run_world(P1, P2, shape, seq, extra_env=None):
     world = P1 * P2
     port = free_port()
