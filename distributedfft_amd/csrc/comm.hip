@@ -488,7 +488,8 @@ static int relay_reserve(RelayBuf &b, size_t bytes, bool device, hipStream_t str
         // (never with hipMalloc, never when the ranges were leaked instead of unmapped, poisoned staging made no difference: the
         // relay's ordering is not the cause; tools/exp/r5_relay_stress.py, profiles/r5_relay_stress.txt)
         void *ptr = nullptr;
-        if (int r = dfft_malloc(bytes, 0, &ptr)) return r;
+        static const bool vmm = [] { const char *e = getenv("DFFT_RELAY_STAGING"); return e && std::string(e) == "vmm"; }();      // experiments only
+        if (int r = dfft_malloc(bytes, vmm ? 1024 : 0, &ptr)) return r;
         b.p = (char *)ptr;
     } else if (!(b.p = (char *)malloc(bytes))) { set_error("relay: out of host memory"); return 1; }
     b.cap = bytes;

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <complex>
 #include <functional>
@@ -1503,7 +1504,20 @@ static int dev_free(void *ptr)
     if (hop) HIP_TRY(hipSetDevice(rec.device));
     hipError_t e = hipDeviceSynchronize();
     for (size_t off = 0; off < rec.bytes && e == hipSuccess; off += rec.chunk) e = hipMemUnmap(static_cast<char *>(ptr) + off, rec.chunk);
-    if (e == hipSuccess) e = hipMemAddressFree(ptr, rec.bytes);
+    // The address range is RETIRED, not returned: the physical memory is gone with the unmap, the reservation stays.  A range that went
+    // back to the runtime and was handed out again (hipMemAddressFree, then a later hipMemAddressReserve at the same address) corrupted
+    // copies when other host threads were enqueueing work at the time -- the relay's staging as virtual memory under eight virtual
+    // ranks: round trips wrong in 8 of 8 runs with the range freed (synchronising once more before the free did not help), 0 of 8 with
+    // it kept (profiles/r5_relay_stress.txt).  Address space is plentiful (47 bits); DFFT_VMM_RETIRE_TIB (default 8) bounds what a
+    // process retires, beyond it ranges are freed as before (0 = always free).
+    static const size_t retire_cap = [] { const char *v = getenv("DFFT_VMM_RETIRE_TIB"); return (size_t)(v ? atol(v) : 8) << 40; }();
+    static std::atomic<size_t> retired{0};
+    bool keep = false;
+    if (e == hipSuccess && retire_cap) {
+        size_t cur = retired.load();
+        while (cur + rec.bytes <= retire_cap && !(keep = retired.compare_exchange_weak(cur, cur + rec.bytes))) {}
+    }
+    if (e == hipSuccess && !keep) e = hipMemAddressFree(ptr, rec.bytes);
     if (hop) (void)hipSetDevice(cur);
     if (e != hipSuccess) { set_error(std::string("dfft_free: ") + hipGetErrorString(e)); return (int)e; }
     return 0;
