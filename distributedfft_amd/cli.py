@@ -64,6 +64,9 @@ def parse(argv):
     ap.add_argument("--sequence", "-s", default="ZY_Then_X", choices=["ZY_Then_X", "Z_Then_YX", "Y_Then_ZX"],
                     help="slab only (tests/src/slab/main.cpp:138-140)")
     ap.add_argument("--complex", action="store_true", help="extension: complex-to-complex instead of R2C/C2R")
+    ap.add_argument("--spectral-layout", type=int, default=0, choices=[0, 1],
+                    help="extension (pencil and default slab classes): 1 = the spectrum block stays x-contiguous, [yo][zs][Nx] "
+                         "(dfft_set_option 'spectral_layout'); the testcases index it through the plan's strides")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="one-process-per-rank runs: torch.distributed backend (gloo: ranks may share a GPU)")
     ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "torch"], help="one-process-per-rank runs, backend nccl")
@@ -89,6 +92,8 @@ class Rank:
         if args.mode == "slab" and args.sequence == "Y_Then_ZX":
             kind = dfft.MPIcuFFT_Slab_Y_Then_ZX
         self.plan = kind(cfg, comm, precision=prec, rank=rank)
+        if getattr(args, "spectral_layout", 0):
+            self.plan.setOption("spectral_layout", args.spectral_layout)
         t0 = time.perf_counter()
         self.N = (args.input_dim_x, args.input_dim_y, args.input_dim_z)
         # one process per rank: the plan runs on a dedicated torch stream (the torch transport's collectives order
@@ -158,12 +163,15 @@ class Rank:
         rows.append(("Run complete", cum))
         self.timings.append(rows)
 
+    def spectrum(self):
+        """my spectrum block as an (Nx, yo, zs) view of `out`, whatever the plan's spectral layout (dfft_get_out_strides)"""
+        return self.plan.spectrumView(self.out)
+
     def laplacian_multiplier(self):
         """derivativeCoefficients (tests/src/pencil/random_dist_3D.cu:98-121) on my output block"""
         t = self.torch
         Nx, Ny, Nz = self.N
-        n = self.osz[0] * self.osz[1] * self.osz[2]
-        blk = self.out[:n].reshape(self.osz)
+        blk = self.spectrum()
 
         def wrapped(idx, N, half=False):
             k = t.where(idx < N // 2, idx, t.where(idx > N // 2, N - idx, t.zeros_like(idx)))
@@ -308,11 +316,10 @@ def run(argv=None):
         torch.cuda.synchronize()
         single.forward(full.contiguous(), 3)
         each(lambda rk: rk.forward(xs[rk.rank], 3))
-        ref = single.out[:single.osz[0] * single.osz[1] * single.osz[2]].reshape(single.osz)
+        ref = single.spectrum()
         tot = 0.0
         for rk in ranks:
-            n = rk.osz[0] * rk.osz[1] * rk.osz[2]
-            blk = rk.out[:n].reshape(rk.osz)
+            blk = rk.spectrum()
             tot += float((blk - ref[:, rk.ost[1]:rk.ost[1] + rk.osz[1], rk.ost[2]:rk.ost[2] + rk.osz[2]]).abs().sum())
         tot = gsum(tot)
         result = {"sum": tot}

@@ -39,6 +39,20 @@ def test_testcase4_laplacian_slab(tmp_path):
     assert r["max"] < 1e-9 * math.sqrt(32.0 ** 3) * 3
 
 
+def test_testcases_with_the_x_contiguous_spectrum(tmp_path, capsys):
+    """--spectral-layout 1 (extension): the testcases index the spectrum block through the plan's strides -- testcase 1 (distributed ==
+    single device), 3 (round trip) and 4 (Laplacian: forward, pointwise multiplication, inverse) on pencil 2 x 2 and slab 3"""
+    from distributedfft_amd import cli
+    base = ["-nx", "32", "-ny", "24", "-nz", "40", "-o", "1", "-d", "-b", str(tmp_path), "--spectral-layout", "1"]
+    r1 = cli.run(["pencil", "-p1", "2", "-p2", "2", "-t", "1"] + base)
+    assert r1["sum"] < 1e-5      # sum over 30720 points of |distributed - single device| on values up to 255 * 30720
+    r3 = cli.run(["pencil", "-p1", "2", "-p2", "2", "-t", "3", "-i", "2"] + base)
+    assert r3["max"] < 1e-6 and r3["avg"] < 1e-7
+    r4 = cli.run(["slab", "-p", "3", "-t", "4"] + base)
+    assert r4["max"] < 1e-9 * math.sqrt(32.0 * 24 * 40) * 3, r4
+    capsys.readouterr()
+
+
 def test_testcase1_distributed_vs_single_and_benchmarks(tmp_path, capsys):
     r = cli.run(["pencil", "-nx", "32", "-ny", "64", "-nz", "16", "-p1", "3", "-p2", "2", "-t", "1", "-d", "-b", str(tmp_path)])
     assert r["sum"] < 1e-6
