@@ -8,10 +8,10 @@
 // MPI_Wtime() between host-side synchronisations.
 #pragma once
 #include <mpi.h>
-#include <sys/stat.h>
 
 #include <algorithm>
 #include <fstream>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -32,35 +32,34 @@ public:
     void setFileName(std::string filename_) { filename = filename_; }
     const std::string &fileName() const { return filename; }
     double duration(std::string desc) const { return durations[index_of(desc)]; }
-    // src/timer.cpp:58-101: every worker contributes the same number of values; ranks of `comm` beyond pcnt contribute none
+    // Appends this iteration's block to the CSV on rank `p_gather` (the format of src/timer.cpp:81-100, byte for byte: pinned
+    // against the reference's own Timer built from its sources, oracle/_ref, tests/test_ref_timer.py).  The first `pcnt` ranks
+    // of `comm` are the workers (a test may run its FFT on fewer ranks than MPI_COMM_WORLD holds); each sends its row of
+    // sections to the writer as one message, the other ranks have nothing to do.
     void gather()
     {
-        int world_size = 1;
-        MPI_Comm_size(comm, &world_size);
-        const int send_size = (int)durations.size();
-        std::vector<int> recv_count(pcnt, send_size);
-        recv_count.resize(world_size, 0);
-        std::vector<int> recv_displ(world_size, 0);
-        for (int i = 1; i < world_size; i++) recv_displ[i] = recv_displ[i - 1] + recv_count[i - 1];
-        std::vector<double> all;
-        if (pidx == p_gather) all.resize((size_t)send_size * pcnt, 0);
-        MPI_Gatherv(durations.data(), send_size, MPI_DOUBLE, all.data(), recv_count.data(), recv_displ.data(), MPI_DOUBLE, p_gather, comm);
-        if (pidx != p_gather) return;
-        std::ofstream f;
-        struct stat st;
-        if (stat(filename.c_str(), &st) != 0) {
-            f.open(filename);
-            f << ",";
-            for (int i = 0; i < pcnt; i++) f << i << ",";
-        } else {
-            f.open(filename, std::ios_base::app);
+        const size_t nsec = durations.size();
+        if (pidx != p_gather) {
+            if (pidx < pcnt) MPI_Send(durations.data(), (int)nsec, MPI_DOUBLE, p_gather, kTag, comm);
+            return;
         }
-        f << "\n";
-        for (size_t i = 0; i < durations.size(); i++) {
-            f << descs[i] << ",";
-            for (int j = 0; j < pcnt; j++) f << all[(size_t)j * durations.size() + i] << ",";
-            f << "\n";
+        std::vector<std::vector<double>> column(pcnt, std::vector<double>(nsec, 0.0));   // column[worker][section]
+        for (int w = 0; w < pcnt; w++) {
+            if (w == pidx) column[w] = durations;
+            else MPI_Recv(column[w].data(), (int)nsec, MPI_DOUBLE, w, kTag, comm, MPI_STATUS_IGNORE);
         }
+        std::ostringstream block;                   // default ostream formatting of a double: what eval/ of the reference parses
+        if (!std::ifstream(filename).good()) {      // a new file starts with the rank header
+            block << ",";
+            for (int w = 0; w < pcnt; w++) block << w << ",";
+        }
+        block << "\n";
+        for (size_t s = 0; s < nsec; s++) {
+            block << descs[s] << ",";
+            for (int w = 0; w < pcnt; w++) block << column[w][s] << ",";
+            block << "\n";
+        }
+        std::ofstream(filename, std::ios_base::app) << block.str();
     }
 
 protected:
@@ -72,6 +71,7 @@ protected:
         if (it == descs.end()) throw std::runtime_error("Timer: unknown section \"" + desc + "\"");
         return (size_t)std::distance(descs.begin(), it);
     }
+    static constexpr int kTag = 0x7d1;
     MPI_Comm comm;
     int p_gather;
     int pcnt, pidx;

@@ -34,19 +34,19 @@
 
 namespace driver {
 
-inline std::string getValueOfParam(int argc, char *argv[], const std::string &longdesc, const std::string &shortdesc)
+inline std::string arg_value(int argc, char *argv[], const std::string &long_name, const std::string &short_name)
 {
     for (int i = 0; i + 1 < argc; i++)
-        if (longdesc == argv[i] || shortdesc == argv[i]) return argv[i + 1];
+        if (long_name == argv[i] || short_name == argv[i]) return argv[i + 1];
     return "";
 }
-inline bool checkFlag(int argc, char *argv[], const std::string &longdesc, const std::string &shortdesc)
+inline bool arg_present(int argc, char *argv[], const std::string &long_name, const std::string &short_name)
 {
     for (int i = 0; i < argc; i++)
-        if (longdesc == argv[i] || shortdesc == argv[i]) return true;
+        if (long_name == argv[i] || short_name == argv[i]) return true;
     return false;
 }
-inline size_t toSize(const std::string &s, bool req = false, const std::string &error = "")
+inline size_t as_size(const std::string &s, bool req = false, const std::string &error = "")
 {
     if (s.empty()) { if (req) throw std::runtime_error(error); return 0; }
     std::stringstream ss(s);
@@ -54,14 +54,14 @@ inline size_t toSize(const std::string &s, bool req = false, const std::string &
     ss >> v;
     return v;
 }
-inline int toInt(const std::string &s) { return (int)toSize(s); }
-inline CommunicationMethod parseCommMethod(const std::string &s)
+inline int as_int(const std::string &s) { return (int)as_size(s); }
+inline CommunicationMethod comm_method_named(const std::string &s)
 {
     if (s == "Peer2Peer" || s.empty()) return Peer2Peer;
     if (s == "All2All") return All2All;
     throw std::runtime_error("Invalid communication method.");
 }
-inline SendMethod parseSendMethod(const std::string &s)
+inline SendMethod send_method_named(const std::string &s)
 {
     if (s == "Sync" || s.empty()) return Sync;
     if (s == "Streams") return Streams;
@@ -77,20 +77,20 @@ struct Common {
 };
 inline void parseCommon(int argc, char *argv[], Common &p)
 {
-    p.Nx = toSize(getValueOfParam(argc, argv, "--input-dim-x", "-nx"), true, "Input parameter Nx is required.");
-    p.Ny = toSize(getValueOfParam(argc, argv, "--input-dim-y", "-ny"), true, "Input parameter Ny is required.");
-    p.Nz = toSize(getValueOfParam(argc, argv, "--input-dim-z", "-nz"), true, "Input parameter Nz is required.");
-    p.iterations = toInt(getValueOfParam(argc, argv, "--iterations", "-i"));
-    p.warmup_rounds = toInt(getValueOfParam(argc, argv, "--warmup-rounds", "-w"));
+    p.Nx = as_size(arg_value(argc, argv, "--input-dim-x", "-nx"), true, "Input parameter Nx is required.");
+    p.Ny = as_size(arg_value(argc, argv, "--input-dim-y", "-ny"), true, "Input parameter Ny is required.");
+    p.Nz = as_size(arg_value(argc, argv, "--input-dim-z", "-nz"), true, "Input parameter Nz is required.");
+    p.iterations = as_int(arg_value(argc, argv, "--iterations", "-i"));
+    p.warmup_rounds = as_int(arg_value(argc, argv, "--warmup-rounds", "-w"));
     if (p.iterations == 0 && p.warmup_rounds == 0) p.iterations = 1;
     p.iterations += p.warmup_rounds;
-    p.cuda_aware = checkFlag(argc, argv, "--cuda_aware", "-c");
-    p.double_prec = checkFlag(argc, argv, "--double_prec", "-d");
-    p.benchmark_dir = getValueOfParam(argc, argv, "--benchmark_dir", "-b");
+    p.cuda_aware = arg_present(argc, argv, "--cuda_aware", "-c");
+    p.double_prec = arg_present(argc, argv, "--double_prec", "-d");
+    p.benchmark_dir = arg_value(argc, argv, "--benchmark_dir", "-b");
     if (p.benchmark_dir.empty()) p.benchmark_dir = "../benchmarks";
-    p.testcase = toInt(getValueOfParam(argc, argv, "--testcase", "-t"));
+    p.testcase = as_int(arg_value(argc, argv, "--testcase", "-t"));
     if (p.testcase < 0 || p.testcase > 4) throw std::runtime_error("Invalid testcase.");
-    p.opt = toInt(getValueOfParam(argc, argv, "--opt", "-o"));
+    p.opt = as_int(arg_value(argc, argv, "--opt", "-o"));
     if (p.opt < 0 || p.opt > 1) throw std::runtime_error("Invalid option.");
 }
 

@@ -62,15 +62,15 @@ int main(int argc, char *argv[])
     try {
         PencilParams p;
         parseCommon(argc, argv, p);
-        p.P1 = toSize(getValueOfParam(argc, argv, "--partition1", "-p1"), true, "Input parameter P1 is required.");
-        p.P2 = toSize(getValueOfParam(argc, argv, "--partition2", "-p2"), true, "Input parameter P2 is required.");
-        p.fft_dim = toInt(getValueOfParam(argc, argv, "--fft-dim", "-f"));
+        p.P1 = as_size(arg_value(argc, argv, "--partition1", "-p1"), true, "Input parameter P1 is required.");
+        p.P2 = as_size(arg_value(argc, argv, "--partition2", "-p2"), true, "Input parameter P2 is required.");
+        p.fft_dim = as_int(arg_value(argc, argv, "--fft-dim", "-f"));
         if (p.fft_dim == 0) p.fft_dim = 3;
         else if (p.fft_dim < 0 || p.fft_dim > 3) throw std::runtime_error("Invalid FFT dimension.");
-        p.comm_method1 = parseCommMethod(getValueOfParam(argc, argv, "--comm-method1", "-comm1"));
-        p.comm_method2 = parseCommMethod(getValueOfParam(argc, argv, "--comm-method2", "-comm2"));
-        p.send_method1 = parseSendMethod(getValueOfParam(argc, argv, "--send-method1", "-snd1"));
-        p.send_method2 = parseSendMethod(getValueOfParam(argc, argv, "--send-method2", "-snd2"));
+        p.comm_method1 = comm_method_named(arg_value(argc, argv, "--comm-method1", "-comm1"));
+        p.comm_method2 = comm_method_named(arg_value(argc, argv, "--comm-method2", "-comm2"));
+        p.send_method1 = send_method_named(arg_value(argc, argv, "--send-method1", "-snd1"));
+        p.send_method2 = send_method_named(arg_value(argc, argv, "--send-method2", "-snd2"));
         World w(p.cuda_aware);
         const int need = (int)(p.P1 * p.P2) + (p.testcase == 1 ? 1 : 0);
         if (w.size != need) throw std::runtime_error("P1*P2 (+1 for testcase 1) must equal the number of MPI ranks.");

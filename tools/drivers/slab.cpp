@@ -66,10 +66,10 @@ int main(int argc, char *argv[])
     try {
         SlabParams p;
         parseCommon(argc, argv, p);
-        p.sequence = getValueOfParam(argc, argv, "--sequence", "-s");
+        p.sequence = arg_value(argc, argv, "--sequence", "-s");
         if (!p.sequence.empty() && p.sequence != "ZY_Then_X" && p.sequence != "Z_Then_YX" && p.sequence != "Y_Then_ZX") throw std::runtime_error("Invalid sequence.");
-        p.comm_method = parseCommMethod(getValueOfParam(argc, argv, "--comm-method", "-comm"));
-        p.send_method = parseSendMethod(getValueOfParam(argc, argv, "--send-method", "-snd"));
+        p.comm_method = comm_method_named(arg_value(argc, argv, "--comm-method", "-comm"));
+        p.send_method = send_method_named(arg_value(argc, argv, "--send-method", "-snd"));
         World w(p.cuda_aware);
         return p.double_prec ? run<double>(p, w) : run<float>(p, w);
     } catch (std::runtime_error &e) {
