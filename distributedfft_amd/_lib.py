@@ -4,7 +4,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdfft_amd.so")
+# DFFT_AMD_LIBRARY names another build of the SAME library (the A/B build of `make -C csrc exp`: tools/kbench_exp, the
+# fp32-twiddle proof of tests/parity_metric.py); there is still no fallback: what it names must exist and export every symbol
+LIB_PATH = os.environ.get("DFFT_AMD_LIBRARY") or os.path.join(_HERE, "libdfft_amd.so")
 
 ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                            C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int),

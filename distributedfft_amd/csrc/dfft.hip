@@ -83,11 +83,19 @@ static int make_twiddles(int prec, size_t N, void **dev)
     const long double PI = 3.141592653589793238462643383279502884L;
     const size_t esz = prec == DFFT_F64 ? 16 : 8;
     std::vector<char> host(esz * N);
+#ifdef DFFT_EXPERIMENTS
+    // A/B build only (make exp): DFFT_EXP_F32_TWIDDLES=1 rounds the fp64 table through fp32 -- the defect the per-entry forward
+    // bound of tests/parity_metric.py has to catch (profiles/r6_f32_twiddle_proof.txt); the shipped library has no such switch
+    static const bool f32_tw = [] { const char *e = getenv("DFFT_EXP_F32_TWIDDLES"); return e && atoi(e) != 0; }();
+#else
+    constexpr bool f32_tw = false;
+#endif
     for (size_t j = 0; j < N; j++) {
         long double a = -2.0L * PI * (long double)j / (long double)N;
         if (prec == DFFT_F64) {
             double *d = reinterpret_cast<double *>(host.data()) + 2 * j;
             d[0] = (double)cosl(a); d[1] = (double)sinl(a);
+            if (f32_tw) { d[0] = (double)(float)d[0]; d[1] = (double)(float)d[1]; }
         } else {
             float *d = reinterpret_cast<float *>(host.data()) + 2 * j;
             d[0] = (float)cosl(a); d[1] = (float)sinl(a);
@@ -315,6 +323,7 @@ struct Pipeline {
     std::vector<hipEvent_t> ev;               // reusable events
     hipStream_t comm_stream = nullptr;
     hipStream_t comm_stream2 = nullptr;       // second exchange of a pencil plan (disjoint links: may overlap the first)
+    hipStream_t compute_stream2 = nullptr;    // option compute_streams = 2: the odd pipeline chunks of a pass run here (enqueue_forward)
 };
 
 struct TimedSpan { hipEvent_t a = nullptr, b = nullptr; int phase = 0; bool used = false; };
@@ -344,6 +353,9 @@ struct Options {
     int spectral = 0;        // 1: the spectrum is kept x-contiguous, [yo][zs][Nx] (lines along kx natural), instead of the reference's
                              // [Nx][yo][zs]: the forward x pass stores natural lines and the inverse x pass loads them -- neither
                              // touches the point-major layout whose strided read is the slowest pass of every multi-rank plan
+    int compute_streams = 1; // 2: the pipeline chunks of a pass alternate over two compute streams, so that the drain of chunk c
+                             // overlaps the ramp of chunk c + 1 (a chunk launch of 0.1-0.2 ms pays ~20 us of launch / drain / ramp when
+                             // the chunks queue up behind each other on one stream)
     int order[6] = {-1, -1, -1, -1, -1, -1};     // workgroup->tile order per pass: fz fy fx ix iy iz; a_fastest + 2*xcd_swizzle
     int variant[6] = {-1, -1, -1, -1, -1, -1};   // kernel configuration per pass, same order (-1 = the plan's choice)
 };
@@ -947,9 +959,10 @@ static int launch_long_bluestein(int prec, const Axis &ax, const PassArgs &P, in
 }
 
 // complex axis pass on axis `axis` (0 = z, 1 = y, 2 = x)
-static int launch(dfft_plan *p, const Launch &L, int variant, int axis, const char *in, char *out, bool real_lines = false)
+static int launch(dfft_plan *p, const Launch &L, int variant, int axis, const char *in, char *out, bool real_lines = false, hipStream_t stream = nullptr)
 {
     if (L.args.ntiles == 0) return 0;
+    if (!stream) stream = p->stream;
     const Axis &ax = p->ax[axis];
     PassArgs A = L.args;
     A.in = in + L.in_off; A.out = out + L.out_off; A.tw = ax.tw; A.debug = p->opt.debug;
@@ -957,31 +970,32 @@ static int launch(dfft_plan *p, const Launch &L, int variant, int axis, const ch
     if (real_lines && p->yreal_native && axis == 1) {      // packed real kernel on strided lines (Y_Then_ZX)
         A.tw2 = p->tw_zr;
         const int M = (int)(p->Ny / 2);
-        const int r = p->prec == DFFT_F64 ? launch_real_f64(M, 1, 0, A, p->stream) : launch_real_f32(M, 1, 0, A, p->stream);
+        const int r = p->prec == DFFT_F64 ? launch_real_f64(M, 1, 0, A, stream) : launch_real_f32(M, 1, 0, A, stream);
         if (r != 0) return fail(r == -1 ? ERR_UNSUPPORTED : r, "real y pass launch failed for length " + std::to_string(p->Ny));
         return 0;
     }
-    if (!ax.bluestein) return launch_pass(p->prec, (int)ax.N, variant, A, p->stream);
+    if (!ax.bluestein) return launch_pass(p->prec, (int)ax.N, variant, A, stream);
     if (ax.longb) {
         if (long_bytes(A, p->TL, ax.M, p->esz) > p->lv_bytes) return fail(ERR_STATE, "long Bluestein pass: scratch region too small");
-        return launch_long_bluestein(p->prec, ax, A, real_lines ? 1 : 0, real_lines ? ax.N / 2 + 1 : ax.N, static_cast<char *>(p->work_d) + p->lv_off, p->TL, p->stream);
+        return launch_long_bluestein(p->prec, ax, A, real_lines ? 1 : 0, real_lines ? ax.N / 2 + 1 : ax.N, static_cast<char *>(p->work_d) + p->lv_off, p->TL, stream);
     }
     if (ax.two) {
         if (two_level_bytes(A, p->TL, ax.N, p->esz) > p->lv_bytes) return fail(ERR_STATE, "two-level pass: scratch region too small");
-        return launch_two_level(p->prec, ax, A, real_lines ? 1 : 0, real_lines ? ax.N / 2 + 1 : ax.N, static_cast<char *>(p->work_d) + p->lv_off, p->TL, p->stream);
+        return launch_two_level(p->prec, ax, A, real_lines ? 1 : 0, real_lines ? ax.N / 2 + 1 : ax.N, static_cast<char *>(p->work_d) + p->lv_off, p->TL, stream);
     }
     A.NK = (uint32_t)ax.N; A.real_mode = 0;
     if (real_lines) { A.real_mode = 1; A.NK = (uint32_t)(ax.N / 2 + 1); }     // real in, Hermitian half out
-    int r = launch_generic(p->prec, ax, A, p->stream);
+    int r = launch_generic(p->prec, ax, A, stream);
     if (r != 0) return fail(r == -1 ? ERR_UNSUPPORTED : r, "Bluestein pass launch failed for length " + std::to_string(ax.N));
     return 0;
 }
 
 // z pass of an R2C plan.  Power-of-two Nz: M = Nz/2 point complex FFT + split (mode 1) / merge
 // (mode 2); any other Nz: Bluestein on the real line (real_mode 1 / 2).
-static int launch_real(dfft_plan *p, const Launch &L, int mode, const char *in, char *out)
+static int launch_real(dfft_plan *p, const Launch &L, int mode, const char *in, char *out, hipStream_t stream = nullptr)
 {
     if (L.args.ntiles == 0) return 0;
+    if (!stream) stream = p->stream;
     const Axis &ax = p->ax[0];
     PassArgs A = L.args;
     A.in = in + L.in_off; A.out = out + L.out_off; A.tw = ax.tw; A.tw2 = p->tw_zr; A.debug = p->opt.debug;
@@ -989,19 +1003,19 @@ static int launch_real(dfft_plan *p, const Launch &L, int mode, const char *in, 
     int r;
     if (p->zreal_native) {
         const int M = (int)(p->Nz / 2);
-        r = p->prec == DFFT_F64 ? launch_real_f64(M, mode, p->opt.real_variant, A, p->stream)
-                                : launch_real_f32(M, mode, p->opt.real_variant, A, p->stream);
+        r = p->prec == DFFT_F64 ? launch_real_f64(M, mode, p->opt.real_variant, A, stream)
+                                : launch_real_f32(M, mode, p->opt.real_variant, A, stream);
     } else if (!ax.bluestein) {
         return fail(ERR_UNSUPPORTED, "real z pass without a native or Bluestein plan");      // (dfft_init rules this out)
     } else if (ax.longb) {
         if (long_bytes(A, p->TL, ax.M, p->esz) > p->lv_bytes) return fail(ERR_STATE, "long Bluestein pass: scratch region too small");
-        return launch_long_bluestein(p->prec, ax, A, mode, p->Nzc, static_cast<char *>(p->work_d) + p->lv_off, p->TL, p->stream);
+        return launch_long_bluestein(p->prec, ax, A, mode, p->Nzc, static_cast<char *>(p->work_d) + p->lv_off, p->TL, stream);
     } else if (ax.two) {
         if (two_level_bytes(A, p->TL, ax.N, p->esz) > p->lv_bytes) return fail(ERR_STATE, "two-level pass: scratch region too small");
-        return launch_two_level(p->prec, ax, A, mode, p->Nzc, static_cast<char *>(p->work_d) + p->lv_off, p->TL, p->stream);
+        return launch_two_level(p->prec, ax, A, mode, p->Nzc, static_cast<char *>(p->work_d) + p->lv_off, p->TL, stream);
     } else {
         A.NK = (uint32_t)p->Nzc; A.real_mode = mode;
-        r = launch_generic(p->prec, ax, A, p->stream);
+        r = launch_generic(p->prec, ax, A, stream);
     }
     if (r == -1) return fail(ERR_UNSUPPORTED, "unsupported real line length " + std::to_string(p->Nz));
     if (r != 0) return fail(r, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)r));
@@ -1131,12 +1145,19 @@ static int enqueue_forward(dfft_plan *p, void *out, const void *in)
     // exchange 2 of a pencil plan runs on its own stream (row and column groups use disjoint links)
     hipStream_t Sm2 = (pl.comm_stream2 && p->comm && p->comm->concurrent_channels()) ? pl.comm_stream2 : Sm;
     p->nspans = 0; p->last_dir = DFFT_FORWARD;
-    // event ids: [0,C) z done, [C,2C) ex1 done, [2C,3C) y done, [3C,4C) ex2 done, 4C = entry fence
-    if (p->comm && p->nranks > 1) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); if (Sm2 != Sm) EV_WAIT(4 * C, Sm2); }   // comm streams start after prior work
+    // two compute streams (option compute_streams): chunk c of a pass runs on SC(c); a chunk depends on the same chunk of the pass
+    // (or exchange) before it, which sits on the same stream or arrives through that chunk's event
+    hipStream_t Sc2 = (p->opt.compute_streams > 1 && C > 1 && !p->lv_bytes) ? pl.compute_stream2 : nullptr;     // (two-level passes share one scratch)
+    auto SC = [&](int c) { return (Sc2 && (c & 1)) ? Sc2 : Sc; };
+    // event ids: [0,C) z done, [C,2C) ex1 done, [2C,3C) y done, [3C,4C) ex2 done, 4C = entry fence, 4C+1.. = joins of the compute streams
+    if ((p->comm && p->nranks > 1) || Sc2) EV_RECORD(4 * C, Sc);
+    if (p->comm && p->nranks > 1) { EV_WAIT(4 * C, Sm); if (Sm2 != Sm) EV_WAIT(4 * C, Sm2); }   // comm streams start after prior work
+    if (Sc2) EV_WAIT(4 * C, Sc2);
     auto zpass = [&](int c) -> int {
+        hipStream_t Sc = SC(c);
         TRY(span_begin(p, 0, Sc));
-        if (p->c2c) TRY(launch(p, pl.fz[c], p->vfwd[0], 0, I, zdst));
-        else TRY(launch_real(p, pl.fz[c], 1, I, zdst));
+        if (p->c2c) TRY(launch(p, pl.fz[c], p->vfwd[0], 0, I, zdst, false, Sc));
+        else TRY(launch_real(p, pl.fz[c], 1, I, zdst, Sc));
         TRY(span_end(p, Sc));
         if (p->P2 > 1) {
             EV_RECORD(c, Sc);
@@ -1149,9 +1170,10 @@ static int enqueue_forward(dfft_plan *p, void *out, const void *in)
         return 0;
     };
     auto ypass = [&](int c) -> int {
+        hipStream_t Sc = SC(c);
         if (p->P2 > 1) EV_WAIT(C + c, Sc);
         TRY(span_begin(p, 2, Sc));
-        TRY(launch(p, pl.fy[c], p->vfwd[1], 1, ysrc, ydst));
+        TRY(launch(p, pl.fy[c], p->vfwd[1], 1, ysrc, ydst, false, Sc));
         TRY(span_end(p, Sc));
         if (p->P1 > 1) {
             EV_RECORD(2 * C + c, Sc);
@@ -1174,6 +1196,7 @@ static int enqueue_forward(dfft_plan *p, void *out, const void *in)
     }
     if (p->P1 > 1) EV_WAIT(3 * C + C - 1, Sc);     // the comm stream is in order: last chunk covers all
     else if (p->P2 > 1) { /* y passes already waited for every ex1 chunk */ }
+    if (Sc2) { EV_RECORD(4 * C + 1, Sc2); EV_WAIT(4 * C + 1, Sc); }      // the x pass (and the caller's stream) follow the odd chunks too
     TRY(span_begin(p, 4, Sc));
     TRY(launch(p, pl.fx, p->vfwd[2], 2, xsrc, A));
     TRY(span_end(p, Sc));
@@ -1214,10 +1237,24 @@ static int enqueue_inverse(dfft_plan *p, void *out, void *in)
         TRY(span_end(p, Sc));
         return 0;
     }
-    if (p->comm && p->nranks > 1) { EV_RECORD(4 * C, Sc); EV_WAIT(4 * C, Sm); if (Sm2 != Sm) EV_WAIT(4 * C, Sm2); }
+    hipStream_t Sc2 = (p->opt.compute_streams > 1 && C > 1 && !p->lv_bytes) ? pl.compute_stream2 : nullptr;     // (two-level passes share one scratch)
+    auto SC = [&](int c) { return (Sc2 && (c & 1)) ? Sc2 : Sc; };
+    // both compute streams have finished what they were given so far (event ids 4C+1 ..: see enqueue_forward)
+    int joins = 0;
+    auto cross_join = [&]() -> int {
+        if (!Sc2) return 0;
+        const int a = 4 * C + 1 + 2 * joins++;
+        EV_RECORD(a, Sc2); EV_RECORD(a + 1, Sc);
+        EV_WAIT(a, Sc); EV_WAIT(a + 1, Sc2);
+        return 0;
+    };
+    if ((p->comm && p->nranks > 1) || Sc2) EV_RECORD(4 * C, Sc);
+    if (p->comm && p->nranks > 1) { EV_WAIT(4 * C, Sm); if (Sm2 != Sm) EV_WAIT(4 * C, Sm2); }
+    if (Sc2) EV_WAIT(4 * C, Sc2);
     for (int c = 0; c < C; c++) {
+        hipStream_t Sc = SC(c);
         TRY(span_begin(p, 0, Sc));
-        TRY(launch(p, pl.ix[c], p->vinv[2], 2, I, xdst));
+        TRY(launch(p, pl.ix[c], p->vinv[2], 2, I, xdst, false, Sc));
         TRY(span_end(p, Sc));
         if (p->P1 > 1) {
             EV_RECORD(c, Sc);
@@ -1230,10 +1267,12 @@ static int enqueue_inverse(dfft_plan *p, void *out, void *in)
     }
     // y^-1 needs complete ky lines: every chunk of exchange 2 must have landed.  It also
     // overwrites I, which every x^-1 chunk has read by now (same stream).
-    if (p->P1 > 1) EV_WAIT(C + C - 1, Sc);
+    TRY(cross_join());      // ... on either stream
+    if (p->P1 > 1) { EV_WAIT(C + C - 1, Sc); if (Sc2) EV_WAIT(C + C - 1, Sc2); }
     for (int c = 0; c < C; c++) {
+        hipStream_t Sc = SC(c);
         TRY(span_begin(p, 2, Sc));
-        TRY(launch(p, pl.iy[c], p->vinv[1], 1, ysrc, ydst));
+        TRY(launch(p, pl.iy[c], p->vinv[1], 1, ysrc, ydst, false, Sc));
         TRY(span_end(p, Sc));
         if (p->P2 > 1) {
             EV_RECORD(2 * C + c, Sc);
@@ -1244,13 +1283,16 @@ static int enqueue_inverse(dfft_plan *p, void *out, void *in)
             EV_RECORD(3 * C + c, Sm);
         }
     }
+    if (p->P2 == 1) TRY(cross_join());      // no exchange 1 between y^-1 and z^-1: the chunks of the two passes need not coincide
     for (int c = 0; c < C; c++) {
+        hipStream_t Sc = SC(c);
         if (p->P2 > 1) EV_WAIT(3 * C + c, Sc);
         TRY(span_begin(p, 4, Sc));
-        if (p->c2c) TRY(launch(p, pl.iz[c], p->vinv[0], 0, zsrc, O));
-        else TRY(launch_real(p, pl.iz[c], 2, zsrc, O));
+        if (p->c2c) TRY(launch(p, pl.iz[c], p->vinv[0], 0, zsrc, O, false, Sc));
+        else TRY(launch_real(p, pl.iz[c], 2, zsrc, O, Sc));
         TRY(span_end(p, Sc));
     }
+    if (Sc2) { const int a = 4 * C + 1 + 2 * joins; EV_RECORD(a, Sc2); EV_WAIT(a, Sc); }      // the caller's stream follows the odd chunks
     return 0;
 }
 
@@ -2016,6 +2058,7 @@ static int *option_slot(Options &o, const std::string &k)
     if (k == "native_mixed") return &o.native_mixed;
     if (k == "graph") return &o.graph;
     if (k == "spectral_layout") return &o.spectral;
+    if (k == "compute_streams") return &o.compute_streams;
     for (int i = 0; i < 6; i++) {
         if (k == std::string("variant_") + kPassNames[i]) return &o.variant[i];
         if (k == std::string("order_") + kPassNames[i]) return &o.order[i];
@@ -2052,6 +2095,7 @@ int dfft_plan_destroy(dfft_plan *p)
     for (auto &e : p->pl.ev) if (e) (void)hipEventDestroy(e);
     if (p->pl.comm_stream) (void)hipStreamDestroy(p->pl.comm_stream);
     if (p->pl.comm_stream2) (void)hipStreamDestroy(p->pl.comm_stream2);
+    if (p->pl.compute_stream2) (void)hipStreamDestroy(p->pl.compute_stream2);
     if (p->stream_owned && p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
     return 0;
@@ -2349,6 +2393,8 @@ static int ensure_device_state(dfft_plan *p)
     if (p->comm && !p->pl.comm_stream) HIP_TRY(hipStreamCreateWithFlags(&p->pl.comm_stream, hipStreamNonBlocking));
     if (p->comm && p->P1 > 1 && p->P2 > 1 && !p->pl.comm_stream2)
         HIP_TRY(hipStreamCreateWithFlags(&p->pl.comm_stream2, hipStreamNonBlocking));
+    if (p->opt.compute_streams > 1 && p->pl.C > 1 && !p->pl.compute_stream2)
+        HIP_TRY(hipStreamCreateWithFlags(&p->pl.compute_stream2, hipStreamNonBlocking));
     return 0;
 }
 

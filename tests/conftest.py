@@ -27,27 +27,29 @@ def pytest_configure(config):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
 
 
-# The GPU suite has to stay well inside the driver's step limit (round 4: 617 s of 1200 s, and every round adds tests).  These
-# functions sweep long parametrisations of ONE code path (lengths, shapes, pipeline depths): the default run keeps every third
-# instance -- each path, precision and rank grid still appears -- and the others carry the marker `slow`:
+# The GPU suite has to stay well inside the driver's step limit (round 5: 566 s of 1200 s).  ONE function sweeps a long cross product
+# of a single code path -- the forced z, x, y single-rank order: 16 shapes x 5 private-layout settings x 2 precisions = 160 instances --
+# and only that one is thinned, by an explicit rule on its parameters (round-5 advice: not by collection order): the default layout
+# setting (1, 128) runs every shape in both precisions; each other setting runs one shape per kernel family (ragged power of two,
+# mixed radix, Bluestein, sub-tile workgroups, a 2048-point axis).  The rest carries the marker `slow`:
 #     python -m pytest tests -m gpu            (what the driver runs)        python -m pytest tests -m "gpu and slow"   (the rest)
-THINNED = {
-    "test_single_order_zxy_forced_vs_oracle", "test_relayed_exchange_is_bit_identical_to_the_direct_one",
-    "test_fft1d_two_level_forced_vs_oracle", "test_single_rank_long_axes_vs_oracle", "test_single_rank_forced_two_level_vs_oracle",
-    "test_fft1d_long_lines_vs_oracle", "test_single_rank_long_bluestein_axes_vs_oracle", "test_slab_sequences_forced_two_level",
-    "test_fft1d_long_bluestein_lines_vs_oracle", "test_distributed_forced_two_level_vs_oracle",
-}
+# Everything else that round 5 thinned (relay bit-identity, two-level and long-Bluestein sweeps) is back in the default run.
+ZXY_FAMILY_SHAPES = {(32, 64, 24), (12, 20, 24), (17, 33, 9), (4096, 4, 16), (16, 2048, 24)}
+
+
+def _zxy_is_slow(params):
+    return (params["layout"], params["pad"]) != (1, 128) and tuple(params["shape"]) not in ZXY_FAMILY_SHAPES
+
+
+THINNED = {"test_single_order_zxy_forced_vs_oracle": _zxy_is_slow}
 
 
 def pytest_collection_modifyitems(config, items):
-    seen = {}
     for it in items:
         name = getattr(it, "originalname", None) or it.name.split("[")[0]
-        if name in THINNED:
-            k = seen.get(name, 0)
-            seen[name] = k + 1
-            if k % 3:
-                it.add_marker(pytest.mark.slow)
+        rule = THINNED.get(name)
+        if rule is not None and hasattr(it, "callspec") and rule(it.callspec.params):
+            it.add_marker(pytest.mark.slow)
     expr = config.getoption("-m") or ""
     if "slow" in expr or os.environ.get("DFFT_TEST_SLOW") == "1":
         return

@@ -21,12 +21,21 @@ torch = pytest.importorskip("torch")
 import distributedfft_amd as dfft  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
+from parity_metric import CENTER, check_forward, entry_rel, forward_bound, record  # noqa: E402
+
 CDT = {"double": torch.complex128, "float": torch.complex64}
 RDT = {"double": torch.float64, "float": torch.float32}
 
 
-def make_world(shape, P1, P2, prec, c2c=True, seed=1234):
-    """plans + device buffers for P1*P2 virtual ranks; input generated on the device"""
+def host_rms(a):
+    """sqrt(mean |a|^2) of a (large) host array without temporaries"""
+    v = a.reshape(-1)
+    return math.sqrt(float(np.vdot(v, v).real) / v.size)
+
+
+def make_world(shape, P1, P2, prec, c2c=True, seed=1234, center=False):
+    """plans + device buffers for P1*P2 virtual ranks; input generated on the device: uniform[0, 255) like the reference's
+    (tests/src/pencil/base.cu:45-53), or the same centred on zero (center=True: parity_metric.py)"""
     P = P1 * P2
     world = dfft.Comm.local(P) if P > 1 else None
     esz = 16 if prec == "double" else 8
@@ -39,9 +48,9 @@ def make_world(shape, P1, P2, prec, c2c=True, seed=1234):
         g = torch.Generator(device="cuda")
         g.manual_seed(seed + r)
         if c2c:
-            x = torch.view_as_complex(torch.rand((n, 2), dtype=RDT[prec], device="cuda", generator=g) * 255)
+            x = torch.view_as_complex(torch.rand((n, 2), dtype=RDT[prec], device="cuda", generator=g) * 255 - (CENTER if center else 0.0))
         else:
-            x = torch.rand(n, dtype=RDT[prec], device="cuda", generator=g) * 255
+            x = torch.rand(n, dtype=RDT[prec], device="cuda", generator=g) * 255 - (CENTER if center else 0.0)
         out = torch.zeros(pl.getDomainSize() // esz, dtype=CDT[prec], device="cuda")
         ranks.append(dict(plan=pl, x=x.reshape(size), out=out, back=torch.zeros_like(x).reshape(size)))
     torch.cuda.synchronize()
@@ -82,9 +91,10 @@ def owner_entry(ranks, k):
     raise AssertionError("no owner")
 
 
-def test_c2_256_single_gpu_every_point_vs_oracle():
+@pytest.mark.parametrize("center", [False, True])
+def test_c2_256_single_gpu_every_point_vs_oracle(center):
     shape = (256, 256, 256)
-    g = orc.fill_block(shape, (0, 0, 0), shape, 2, seed=2)
+    g = orc.fill_block(shape, (0, 0, 0), shape, 2, seed=2) - (CENTER * (1 + 1j) if center else 0)
     plan = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), precision="double")
     plan.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(1, 1), True, c2c=True)
     d_in = torch.from_numpy(g).cuda()
@@ -94,15 +104,17 @@ def test_c2_256_single_gpu_every_point_vs_oracle():
     want = orc.fft3d_c2c(g, -1)
     got = d_out[:g.size].cpu().numpy().reshape(shape)
     assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-11
+    check_forward(got, want, "double", g.size, label=f"C2 256^3 fp64 one rank, every point, centred={center}")
     back = torch.zeros_like(d_in)
     torch.cuda.synchronize()
     plan.execC2C(back, d_out, dfft.INVERSE)
     assert np.max(np.abs(back.cpu().numpy() / g.size - g)) / 255 < 1e-10
 
 
-def test_c3_512_slab_two_ranks_every_point_vs_oracle():
+@pytest.mark.parametrize("center", [False, True])
+def test_c3_512_slab_two_ranks_every_point_vs_oracle(center):
     shape = (512, 512, 512)
-    ranks = make_world(shape, 2, 1, "double")
+    ranks = make_world(shape, 2, 1, "double", center=center)
     g = np.empty(shape, dtype=np.complex128)
     for rk in ranks:
         s, o = rk["plan"].getInSize(), rk["plan"].getInStart()
@@ -110,10 +122,13 @@ def test_c3_512_slab_two_ranks_every_point_vs_oracle():
     run_all(ranks, lambda rk: rk["plan"].execC2C(rk["out"], rk["x"], dfft.FORWARD))
     want = orc.fft3d_c2c(g, -1)
     scale = np.max(np.abs(want))
-    for rk in ranks:
+    want_rms = host_rms(want)
+    for r, rk in enumerate(ranks):
         s, o = rk["plan"].getOutSize(), rk["plan"].getOutStart()
         got = spectrum_block(rk).cpu().numpy()
         assert np.max(np.abs(got - want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]])) / scale < 1e-11
+        check_forward(got, want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]], "double", want.size, want_rms=want_rms,
+                      label=f"C3 512^3 fp64 slab 2, rank {r}, every point, centred={center}")
     run_all(ranks, lambda rk: rk["plan"].execC2C(rk["back"], rk["out"], dfft.INVERSE))
     for rk in ranks:
         assert float((rk["back"] / float(np.prod(shape)) - rk["x"]).abs().max()) / 255 < 1e-10
@@ -126,14 +141,18 @@ def test_c4_1024_fp64_properties(P1, P2):
     n3 = float(np.prod(shape))
     ranks = make_world(shape, P1, P2, "double")
     run_all(ranks, lambda rk: rk["plan"].execC2C(rk["out"], rk["x"], dfft.FORWARD))
-    # known answers: direct DFT of a few entries (incl. DC, Nyquist corners and generic points)
+    # known answers: direct DFT of a few entries (incl. DC, Nyquist corners and generic points); per entry: against the rms of
+    # the spectrum, sqrt(sum |x|^2) by Parseval (the direct sum in fp64 is itself good to ~1e-15 * sqrt(N^3) relative to that)
     scale = abs(owner_entry(ranks, (0, 0, 0)))
+    ex = sum(float((rk["x"].abs() ** 2).sum()) for rk in ranks)
+    spec_rms = math.sqrt(ex)
     for k in [(0, 0, 0), (512, 512, 512), (1, 2, 3), (1023, 1, 640), (300, 777, 129), (17, 1000, 1023)]:
         want = direct_dft_entry(ranks, shape, k)
         got = owner_entry(ranks, k)
         assert abs(got - want) / scale < 1e-11, (k, got, want)
+        assert entry_rel(got, want, spec_rms) < forward_bound("double", n3), (k, got, want)
+        record(f"C4 1024^3 fp64 {P1}x{P2} entry {k} vs direct DFT", "double", int(n3), entry_rel(got, want, spec_rms), forward_bound("double", n3), abs(got - want) / scale)
     # Parseval: sum |X|^2 = N^3 sum |x|^2
-    ex = sum(float((rk["x"].abs() ** 2).sum()) for rk in ranks)
     eX = sum(float((spectrum_block(rk).abs() ** 2).sum()) for rk in ranks)
     assert abs(eX / (n3 * ex) - 1.0) < 1e-12
     # round trip (reference testcase 3)
@@ -151,8 +170,11 @@ def test_1024_r2c_c2r_round_trip_and_hermitian_half():
     assert [rk["plan"].getOutSize()[2] for rk in ranks[:4]] == [129, 128, 128, 128]
     run_all(ranks, lambda rk: rk["plan"].execR2C(rk["out"], rk["x"]))
     scale = abs(owner_entry(ranks, (0, 0, 0)))
+    spec_rms = math.sqrt(sum(float((rk["x"] ** 2).sum()) for rk in ranks))
     for k in [(0, 0, 0), (5, 9, 512), (1000, 3, 128), (77, 600, 300)]:
-        assert abs(owner_entry(ranks, k) - direct_dft_entry(ranks, shape, k)) / scale < 1e-11
+        got, want = owner_entry(ranks, k), direct_dft_entry(ranks, shape, k)
+        assert abs(got - want) / scale < 1e-11
+        assert entry_rel(got, want, spec_rms) < forward_bound("double", n3), (k, got, want)
     run_all(ranks, lambda rk: rk["plan"].execC2R(rk["back"], rk["out"]))
     for rk in ranks:
         assert float((rk["back"] / n3 - rk["x"]).abs().max()) / 255.0 < 1e-10
@@ -166,8 +188,11 @@ def test_c5_fp32_axis_2048_and_1024_cube(shape, P1, P2):
     ranks = make_world(shape, P1, P2, "float")
     run_all(ranks, lambda rk: rk["plan"].execC2C(rk["out"], rk["x"], dfft.FORWARD))
     scale = abs(owner_entry(ranks, (0, 0, 0)))
+    spec_rms = math.sqrt(sum(float((rk["x"].abs().to(torch.float64) ** 2).sum()) for rk in ranks))
     for k in [(0, 0, 0), (1, 2, 3), (shape[0] - 1, shape[1] // 2, shape[2] // 3)]:
-        assert abs(owner_entry(ranks, k) - direct_dft_entry(ranks, shape, k)) / scale < 1e-4
+        got, want = owner_entry(ranks, k), direct_dft_entry(ranks, shape, k)
+        assert abs(got - want) / scale < 1e-4
+        assert entry_rel(got, want, spec_rms) < forward_bound("float", n3), (k, got, want)
     run_all(ranks, lambda rk: rk["plan"].execC2C(rk["back"], rk["out"], dfft.INVERSE))
     for rk in ranks:
         assert float((rk["back"] / n3 - rk["x"]).abs().max()) / 255.0 < 5e-5

@@ -14,6 +14,8 @@ torch = pytest.importorskip("torch")
 import distributedfft_amd as dfft  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
+from parity_metric import CENTER, check_forward, rms  # noqa: E402
+
 TOL_FWD = {"double": 1e-11, "float": 1e-4}
 TOL_RT = {"double": 1e-10, "float": 5e-5}
 CDT = {"double": torch.complex128, "float": torch.complex64}
@@ -32,19 +34,24 @@ def test_fft1d_batched_vs_oracle(N, prec):
     lines-per-workgroup), both directions"""
     batch = 37 if N >= 256 else 531
     rng = np.random.default_rng(N)
-    x = rng.uniform(0, 255, (batch, N)) + 1j * rng.uniform(0, 255, (batch, N))
-    d_in = torch.from_numpy(x.astype(NPDT[prec])).cuda()
-    d_out = torch.zeros_like(d_in)
-    for direction in (dfft.FORWARD, dfft.INVERSE):
-        torch.cuda.synchronize()
-        dfft.fft1d_batched(d_out, d_in, N, batch, direction, prec)
-        torch.cuda.synchronize()
-        want = orc.fft1d(x.astype(NPDT[prec]), direction)
-        assert rel(d_out.cpu().numpy(), want) < TOL_FWD[prec]
+    x0 = rng.uniform(0, 255, (batch, N)) + 1j * rng.uniform(0, 255, (batch, N))
+    for x in (x0, x0 - CENTER * (1 + 1j)):        # the reference's distribution, and the same centred (zero mean)
+        d_in = torch.from_numpy(x.astype(NPDT[prec])).cuda()
+        d_out = torch.zeros_like(d_in)
+        for direction in (dfft.FORWARD, dfft.INVERSE):
+            torch.cuda.synchronize()
+            dfft.fft1d_batched(d_out, d_in, N, batch, direction, prec)
+            torch.cuda.synchronize()
+            want = orc.fft1d(x.astype(NPDT[prec]), direction)
+            assert rel(d_out.cpu().numpy(), want) < TOL_FWD[prec]
+            check_forward(d_out.cpu().numpy(), want, prec, N, label=f"fft1d N={N} dir={direction} mean={x.real.mean():.0f}" if N in (8, 1024, 8192) else None)
 
 
-def run_single(shape, prec, seed=5):
-    g = orc.fill_block(shape, (0, 0, 0), shape, 2, seed=seed).astype(NPDT[prec])
+def run_single(shape, prec, seed=5, center=False):
+    g = orc.fill_block(shape, (0, 0, 0), shape, 2, seed=seed)
+    if center:
+        g = g - CENTER * (1 + 1j)
+    g = g.astype(NPDT[prec])
     plan = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), precision=prec)
     plan.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(1, 1), True, c2c=True)
     esz = 16 if prec == "double" else 8
@@ -66,10 +73,12 @@ def run_single(shape, prec, seed=5):
                                    (4096, 4, 6), (3, 8192, 20), (5, 4, 4096), (16, 20, 8192)])
 def test_single_rank_3d_vs_oracle(shape, prec):
     """fft3d branch (one rank): three local axis passes == oracle 3-D transform"""
-    g, got, back = run_single(shape, prec)
-    want = orc.fft3d_c2c(g.astype(np.complex128), -1)
-    assert rel(got, want) < TOL_FWD[prec]
-    assert rel(back / g.size, g) < TOL_RT[prec]
+    for center in (False, True):
+        g, got, back = run_single(shape, prec, center=center)
+        want = orc.fft3d_c2c(g.astype(np.complex128), -1)
+        assert rel(got, want) < TOL_FWD[prec]
+        check_forward(got, want, prec, g.size, label=f"single rank {shape} centred={center}" if shape in ((128, 128, 128), (16, 20, 8192)) else None)
+        assert rel(back / g.size, g) < TOL_RT[prec]
 
 
 def test_golden_fixture_single_rank():
@@ -79,7 +88,7 @@ def test_golden_fixture_single_rank():
     assert rel(got, d["c2c_8x8x8"]) < 1e-11
 
 
-def run_distributed(shape, P1, P2, prec, seed=7, chunks=None, options=None, comm_options=None):
+def run_distributed(shape, P1, P2, prec, seed=7, chunks=None, options=None, comm_options=None, center=False):
     """P1*P2 virtual ranks on one GPU (one host thread per rank, like MPI ranks sharing a
     device: tests/src/pencil/random_dist_3D.cu:175-177)."""
     P = P1 * P2
@@ -96,7 +105,10 @@ def run_distributed(shape, P1, P2, prec, seed=7, chunks=None, options=None, comm
             pl.setOption(k, v)
         pl.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(P1, P2), True, c2c=True)
         size, start = pl.getInSize(), pl.getInStart()
-        blk = orc.fill_block(shape, start, size, 2, seed=seed).astype(NPDT[prec])
+        blk = orc.fill_block(shape, start, size, 2, seed=seed)
+        if center:
+            blk = blk - CENTER * (1 + 1j)
+        blk = blk.astype(NPDT[prec])
         plans.append(pl)
         ins.append(torch.from_numpy(blk).cuda())
         outs.append(torch.zeros(pl.getDomainSize() // esz, dtype=CDT[prec], device="cuda"))
@@ -123,20 +135,24 @@ DIST = [((4096, 16, 8), 2, 2), ((8, 8192, 48), 3, 2), ((16, 16, 16), 2, 2), ((32
 def test_distributed_vs_oracle(shape, P1, P2, prec):
     """reference testcase 1 (distributed == single device) and testcase 3 (round trip), with
     even and uneven partitions, pencil and slab (P2 == 1)."""
-    plans, ins, spec, backs = run_distributed(shape, P1, P2, prec)
-    g = orc.fill_block(shape, (0, 0, 0), shape, 2, seed=7).astype(NPDT[prec]).astype(np.complex128)
-    want = orc.fft3d_c2c(g, -1)
     opl = orc.PencilPlan(*shape, P1, P2, True)
     n3 = float(np.prod(shape))
-    for r, pl in enumerate(plans):
-        s, o = pl.getOutSize(), pl.getOutStart()
-        assert (s, o) == opl.out_block(r)
-        ref = want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]]
-        assert rel(spec[r], ref) < TOL_FWD[prec] * (np.max(np.abs(want)) / max(np.max(np.abs(ref)), 1e-300))
-        assert rel(backs[r] / n3, ins[r]) < TOL_RT[prec]
-        for which in (1, 2):   # byte tables == the reference's formulas (via the oracle restatement)
-            esz = 16 if prec == "double" else 8
-            assert pl.getExchangeTables(which) == [[v * esz for v in t] for t in opl.exchange_tables(r, which)]
+    for center in (False, True):
+        plans, ins, spec, backs = run_distributed(shape, P1, P2, prec, center=center)
+        g = orc.fill_block(shape, (0, 0, 0), shape, 2, seed=7) - (CENTER * (1 + 1j) if center else 0)
+        want = orc.fft3d_c2c(g.astype(NPDT[prec]).astype(np.complex128), -1)
+        want_rms = rms(want)
+        for r, pl in enumerate(plans):
+            s, o = pl.getOutSize(), pl.getOutStart()
+            assert (s, o) == opl.out_block(r)
+            ref = want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]]
+            assert rel(spec[r], ref) < TOL_FWD[prec] * (np.max(np.abs(want)) / max(np.max(np.abs(ref)), 1e-300))
+            check_forward(spec[r], ref, prec, g.size, want_rms=want_rms,
+                          label=f"distributed {shape} {P1}x{P2} rank {r} centred={center}" if r == 0 and shape in ((128, 64, 32), (64, 64, 64)) else None)
+            assert rel(backs[r] / n3, ins[r]) < TOL_RT[prec]
+            for which in (1, 2):   # byte tables == the reference's formulas (via the oracle restatement)
+                esz = 16 if prec == "double" else 8
+                assert pl.getExchangeTables(which) == [[v * esz for v in t] for t in opl.exchange_tables(r, which)]
 
 
 # ------------------------------------------------------------------------------------------
@@ -196,16 +212,21 @@ REAL = [((8, 8, 8), 1, 1), ((16, 16, 16), 1, 1), ((32, 16, 64), 1, 1), ((128, 12
 def test_r2c_c2r_vs_oracle(shape, P1, P2, prec):
     """execR2C output == oracle rfftn block (Hermitian half, uneven Nz/2+1 split) and
     C2R(R2C(x)) == Nx*Ny*Nz*x (reference testcase 3, random_dist_3D.cu:641-666)"""
-    plans, ins, spec, backs = run_distributed_real(shape, P1, P2, prec)
-    g = orc.fill_block(shape, (0, 0, 0), shape, 1, seed=13).astype(NPR[prec]).astype(np.float64)
-    want = orc.fft3d_r2c(g)
     n3 = float(np.prod(shape))
-    scale = np.max(np.abs(want))
-    for r, pl in enumerate(plans):
-        s, o = pl.getOutSize(), pl.getOutStart()
-        ref = want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]]
-        assert np.max(np.abs(spec[r] - ref)) / scale < TOL_FWD[prec]
-        assert rel(backs[r] / n3, ins[r]) < TOL_RT[prec]
+    for center in (False, True):
+        g0 = orc.fill_block(shape, (0, 0, 0), shape, 1, seed=13) - (CENTER if center else 0.0)
+        plans, ins, spec, backs = run_distributed_real(shape, P1, P2, prec, field=g0 if center else None)
+        g = g0.astype(NPR[prec]).astype(np.float64)
+        want = orc.fft3d_r2c(g)
+        scale = np.max(np.abs(want))
+        want_rms = rms(want)
+        for r, pl in enumerate(plans):
+            s, o = pl.getOutSize(), pl.getOutStart()
+            ref = want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]]
+            assert np.max(np.abs(spec[r] - ref)) / scale < TOL_FWD[prec]
+            check_forward(spec[r], ref, prec, g.size, want_rms=want_rms,
+                          label=f"R2C {shape} {P1}x{P2} rank {r} centred={center}" if r == 0 and shape in ((128, 64, 32), (4, 512, 4096)) else None)
+            assert rel(backs[r] / n3, ins[r]) < TOL_RT[prec]
 
 
 @pytest.mark.parametrize("shape,P1,P2", [((32, 32, 32), 1, 1), ((32, 32, 32), 2, 4), ((64, 32, 16), 2, 2)])
@@ -611,3 +632,32 @@ def test_address_table_modes_agree(mode, monkeypatch):
     for r, pl in enumerate(plans):
         s, o = pl.getOutSize(), pl.getOutStart()
         assert np.max(np.abs(spec[r] - wantr[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]])) / np.max(np.abs(wantr)) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------
+# option compute_streams = 2: the pipeline chunks of a pass alternate over two compute streams
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("chunks", [2, 3, 4, 8])
+@pytest.mark.parametrize("shape,P1,P2", [((32, 32, 32), 2, 4), ((16, 16, 16), 3, 2), ((64, 32, 16), 8, 1), ((16, 32, 16), 1, 4), ((128, 64, 32), 2, 4)])
+def test_two_compute_streams_are_bit_identical_to_one(shape, P1, P2, chunks):
+    """the same kernels on the same data in another stream assignment: spectrum and round trip must not change by one bit
+    (a missing dependency between the two compute streams shows up as a difference or as a wrong result against the oracle)"""
+    ref = run_distributed(shape, P1, P2, "double", chunks=chunks)
+    want = orc.fft3d_c2c(orc.fill_block(shape, (0, 0, 0), shape, 2, seed=7), -1)
+    for _ in range(3):          # scheduling varies from run to run
+        two = run_distributed(shape, P1, P2, "double", chunks=chunks, options={"compute_streams": 2})
+        assert two[0][0].getOption("compute_streams") == 2
+        for r in range(P1 * P2):
+            assert np.array_equal(two[2][r], ref[2][r]) and np.array_equal(two[3][r], ref[3][r])
+    for r, pl in enumerate(ref[0]):
+        s, o = pl.getOutSize(), pl.getOutStart()
+        check_forward(ref[2][r], want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]], "double", want.size, want_rms=rms(want))
+
+
+@pytest.mark.parametrize("shape,P1,P2", [((32, 32, 32), 2, 4), ((64, 32, 16), 4, 1), ((16, 32, 64), 1, 4)])
+def test_two_compute_streams_r2c_bit_identical(shape, P1, P2):
+    ref = run_distributed_real(shape, P1, P2, "double")
+    for _ in range(3):
+        two = run_distributed_real(shape, P1, P2, "double", options={"compute_streams": 2})
+        for r in range(P1 * P2):
+            assert np.array_equal(two[2][r], ref[2][r]) and np.array_equal(two[3][r], ref[3][r])

@@ -25,7 +25,8 @@ torch = pytest.importorskip("torch")
 import distributedfft_amd as dfft  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
-from test_gpu_fullsize import direct_dft_entry, make_world, owner_entry, run_all, spectrum_block  # noqa: E402
+from parity_metric import CENTER, entry_rel, forward_bound, record  # noqa: E402
+from test_gpu_fullsize import direct_dft_entry, host_rms, make_world, owner_entry, run_all, spectrum_block  # noqa: E402
 from test_gpu_parity import (CDT, NPDT, NPR, TOL_FWD, TOL_RT, rel, run_distributed, run_distributed_real,  # noqa: E402
                              run_single)
 
@@ -61,7 +62,7 @@ def test_c4_1024_fp64_every_point_vs_oracle(P1, P2, c2c):
         pytest.skip(f"needs 110 GiB of free HBM (8 virtual ranks), {gpu_free_gib():.0f} GiB free")
     shape = (1024, 1024, 1024)
     n3 = float(np.prod(shape))
-    ranks = make_world(shape, P1, P2, "double", c2c=c2c)
+    ranks = make_world(shape, P1, P2, "double", c2c=c2c, center=True)       # zero-mean input: max|X| is no DC term (parity_metric.py)
     g = np.empty(shape, dtype=np.complex128 if c2c else np.float64)
     for rk in ranks:
         s, o = rk["plan"].getInSize(), rk["plan"].getInStart()
@@ -74,14 +75,21 @@ def test_c4_1024_fp64_every_point_vs_oracle(P1, P2, c2c):
         run_all(ranks, lambda rk: rk["plan"].execR2C(rk["out"], rk["x"]))
         want = orc.fft3d_r2c(g)
         del g
-    scale = float(np.abs(want[0, 0, 0]))        # the DC term is the largest entry of a non-negative input
-    worst = 0.0
+    want_rms = host_rms(want)
+    scale, worst, per_entry = 0.0, 0.0, 0.0
     for rk in ranks:
         s, o = rk["plan"].getOutSize(), rk["plan"].getOutStart()
         ref = torch.from_numpy(np.ascontiguousarray(want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]])).cuda()
-        worst = max(worst, float((spectrum_block(rk) - ref).abs().max()) / scale)
-        del ref
-    assert worst < 1e-11, worst
+        err = (spectrum_block(rk) - ref).abs()
+        mag = ref.abs()
+        worst = max(worst, float(err.max()))
+        scale = max(scale, float(mag.max()))
+        per_entry = max(per_entry, float((err / mag.clamp_(min=want_rms)).max()))
+        del ref, err, mag
+    assert worst / scale < 1e-11, worst / scale                       # scaled by max|X|
+    bound = forward_bound("double", n3)
+    record(f"C4 1024^3 fp64 {P1}x{P2} {'C2C' if c2c else 'R2C'}, every point, centred input", "double", int(n3), per_entry, bound, worst / scale)
+    assert per_entry <= bound, per_entry          # per entry: max |err| / max(|X[k]|, rms(X)) <= 1e-13 log2(N^3)
     del want
     if c2c:
         run_all(ranks, lambda rk: rk["plan"].execC2C(rk["back"], rk["out"], dfft.INVERSE))
@@ -144,9 +152,13 @@ def test_c5_2048_fp32_full_size_single_gpu():
     plan.execC2C(out, x, dfft.FORWARD)
     spec = out[:n].reshape(N, N, N)
     scale = abs(complex(want[0].item()))
+    spec_rms = math.sqrt(float(energy))           # Parseval: rms of the spectrum * sqrt(n) ... = sqrt(sum |x|^2) per entry
     for j, k in enumerate(ks):
         got = complex(spec[k].item())
         assert abs(got - complex(want[j].item())) / scale < 1e-4, (k, got, complex(want[j].item()))
+        e = entry_rel(got, complex(want[j].item()), spec_rms)
+        assert e < forward_bound("float", n), (k, e)
+        record(f"C5 2048^3 fp32 one rank entry {k} vs direct DFT", "float", n, e, forward_bound("float", n), abs(got - complex(want[j].item())) / scale)
     eX = torch.zeros((), dtype=torch.float64, device="cuda")
     for i in range(0, N, planes):
         blk = spec[i:i + planes].to(torch.complex128)
@@ -198,7 +210,8 @@ def test_c5_shaped_2048x2048x1024_fp32_pencil_2x4_every_point():
     run_all(ranks, lambda rk: rk["plan"].execC2C(rk["out"], rk["x"], dfft.FORWARD))
     orc.lib().orc_fft3d_c2c(g.ctypes.data_as(C.c_void_p), *shape, -1)       # in place: g is the spectrum now
     scale = float(np.abs(g[0, 0, 0]))        # the DC term is the largest entry of a non-negative input
-    worst = 0.0
+    want_rms = host_rms(g)
+    worst, per_entry = 0.0, 0.0
     step = 256
     for rk in ranks:
         s, o = rk["plan"].getOutSize(), rk["plan"].getOutStart()
@@ -206,9 +219,13 @@ def test_c5_shaped_2048x2048x1024_fp32_pencil_2x4_every_point():
         got = spectrum_block(rk)
         for k0 in range(0, s[0], step):
             ref = torch.from_numpy(np.ascontiguousarray(g[k0:k0 + step, o[1]:o[1] + s[1], o[2]:o[2] + s[2]])).cuda()
-            worst = max(worst, float((got[k0:k0 + step].to(torch.complex128) - ref).abs().max()) / scale)
-            del ref
+            err = (got[k0:k0 + step].to(torch.complex128) - ref).abs()
+            worst = max(worst, float(err.max()) / scale)
+            per_entry = max(per_entry, float((err / ref.abs().clamp_(min=want_rms)).max()))
+            del ref, err
     assert worst < 1e-4, worst       # fp32 forward tolerance
+    record("C5-shaped 2048x2048x1024 fp32 2x4, every point", "float", int(n3), per_entry, forward_bound("float", n3), worst)
+    assert per_entry <= forward_bound("float", n3), per_entry     # per entry (parity_metric.py)
     del g
     run_all(ranks, lambda rk: rk["plan"].execC2C(rk["x"], rk["out"], dfft.INVERSE))       # in = back aliased
     for r, rk in enumerate(ranks):

@@ -112,6 +112,9 @@ struct Args {
     size_t Nx = 1024, Ny = 1024, Nz = 1024;
     std::string prec = "f64", mode = "c2c", label;
     int iters = 5, check = 0;
+    int wall_only = 0;    // --wall-only: no phase timing (its events serialise nothing but cost host time): `iters` forward + inverse pairs
+                          // enqueued back to back, one device synchronisation at the end -- the figure to compare pipeline depths and
+                          // compute_streams by, because spans of chunks that overlap on two streams cannot be summed
     int latency = 0;      // --latency: no phase timing; host wall clock of the blocking exec calls (what a caller waits for)
     std::vector<std::pair<std::string, long>> opts;
     size_t line = 0, batch = 0;
@@ -200,6 +203,7 @@ static Args parse(int argc, char **argv)
         else if (k == "--iters") a.iters = atoi(next());
         else if (k == "--check") a.check = 1;
         else if (k == "--latency") a.latency = 1;
+        else if (k == "--wall-only") a.wall_only = 1;
         else if (k == "--label") a.label = next();
         else if (k == "--line") a.line = (size_t)atoll(next());
         else if (k == "--batch") a.batch = (size_t)atoll(next());
@@ -425,6 +429,19 @@ template <typename R> static int run_plan(const Args &a)
         for (auto &kv : a.opts) optstr += " " + kv.first + "=" + std::to_string(kv.second);
         printf("LATENCY %s %zux%zux%zu %s %s%s | forward %.1f us  inverse %.1f us (host wall clock of the blocking exec, %d iterations)\n",
                a.label.c_str(), a.Nx, a.Ny, a.Nz, a.prec.c_str(), a.mode.c_str(), optstr.c_str(), tf / a.iters, tb / a.iters, a.iters);
+        return 0;
+    }
+    if (a.wall_only) {
+        fwd(); inv();
+        HIPCHK(hipDeviceSynchronize());
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int it = 0; it < a.iters; it++) { fwd(); inv(); }
+        HIPCHK(hipDeviceSynchronize());
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / a.iters;
+        std::string optstr;
+        for (auto &kv : a.opts) optstr += " " + kv.first + "=" + std::to_string(kv.second);
+        printf("WALL %s %zux%zux%zu %s %s%s rank %d of %dx%d chunks=%d | %.3f ms per forward + inverse (%d pairs back to back, no phase events)\n",
+               a.label.c_str(), a.Nx, a.Ny, a.Nz, a.prec.c_str(), a.mode.c_str(), optstr.c_str(), a.rank, a.P1, a.P2, dfft_get_pipeline_chunks(plan), ms, a.iters);
         return 0;
     }
     DCHK(dfft_enable_phase_timing(plan, 1));
