@@ -626,45 +626,66 @@ def main():
     def per_gpu_kernels(P1v, P2v, steps, options=None, real=False):
         """rank 0's plan of a P1v x P2v grid on THIS GPU with the exchange stubbed out (a callback transport that moves
         nothing): the kernels run with that rank's descriptors -- 1/P of the volume, its peer segments, its pipeline chunks --
-        on whatever the buffers hold, so the times are the compute one GPU of the multi-GPU run does per step."""
+        on whatever the buffers hold, so the times are the compute one GPU of the multi-GPU run does per step.
+        Two plans: one with the chunks of a pass serialised on ONE compute stream (option compute_streams = 1), whose per-pass
+        device spans can be summed (`per_pass`, `kernels_ms_per_step`), and the plan as a rank would run it (two compute streams
+        from three chunks on: chunk spans overlap, so only the whole step is timed: `step_ms`, next to `step_ms_one_stream`)."""
         nr = P1v * P2v
-        stub = dfft.Comm.callback(nr, 0, lambda *a: None)
         kind = dfft.MPIcuFFT_Slab_Opt1 if P2v == 1 else dfft.MPIcuFFT_Pencil_Opt1
-        pl = kind(dfft.Configurations(), stub, precision=prec, rank=0)
-        for k, v in (options or {}).items():
-            pl.setOption(k, v)
-        pl.initFFT(dfft.GlobalSize(N, N, N), dfft.Partition(P1v, P2v), allocate=False, c2c=not real)
-        pl.setStream(stream)
-        pl.setWorkArea(None)
-        isz_v = pl.getInSize()
-        nv = isz_v[0] * isz_v[1] * isz_v[2]
-        # real = the reference's own API: execR2C / execC2R (real input block [xs][ys][Nz], Hermitian half [Nx][yo][zs] out)
-        v_in = torch.view_as_real(d_in).reshape(-1)[:nv] if real else d_in[:nv]
-        v_out = d_out[:pl.getDomainSize() // esz]
-        v_back = None if aliased else (torch.view_as_real(d_back).reshape(-1)[:nv] if real else d_back[:nv])
 
-        def fwd():
-            if real:
-                pl.execR2C(v_out, v_in)
-            else:
-                pl.execC2C(v_out, v_in, dfft.FORWARD)
+        def build(extra):
+            stub = dfft.Comm.callback(nr, 0, lambda *a: None)
+            pl = kind(dfft.Configurations(), stub, precision=prec, rank=0)
+            for k, v in {**(options or {}), **extra}.items():
+                pl.setOption(k, v)
+            pl.initFFT(dfft.GlobalSize(N, N, N), dfft.Partition(P1v, P2v), allocate=False, c2c=not real)
+            pl.setStream(stream)
+            pl.setWorkArea(None)
+            isz_v = pl.getInSize()
+            nv = isz_v[0] * isz_v[1] * isz_v[2]
+            # real = the reference's own API: execR2C / execC2R (real input block [xs][ys][Nz], Hermitian half [Nx][yo][zs] out)
+            v_in = torch.view_as_real(d_in).reshape(-1)[:nv] if real else d_in[:nv]
+            v_out = d_out[:pl.getDomainSize() // esz]
+            v_back = None if aliased else (torch.view_as_real(d_back).reshape(-1)[:nv] if real else d_back[:nv])
 
-        def inv():
-            if real:
-                pl.execC2R(v_in, v_out)
-            else:
-                pl.execC2C(v_in, v_out, dfft.INVERSE)
-        tuned = None
-        if not args.no_tune_variants:
-            # the plan's own tuner (dfft_tune_variants: workgroup order and kernel configuration per pass, by measurement) -- what
-            # bench.py calls at N > 1 before the warm-up, so these are the kernels a rank of the 8-GPU run would launch
-            try:
-                with torch.cuda.stream(side):
-                    tr = pl.tuneVariants(v_in, v_out, v_back)   # without a third buffer: forward passes only
-                tuned = {"as_built_ms": round(tr[0], 3), "chosen_ms": round(tr[-1], 3), "trials": len(tr),
-                         "chosen (variant, order, addr64) per pass": pl.getPassChoices()}
-            except Exception as e:   # noqa: BLE001
-                tuned = {"error": str(e)}
+            def fwd():
+                if real:
+                    pl.execR2C(v_out, v_in)
+                else:
+                    pl.execC2C(v_out, v_in, dfft.FORWARD)
+
+            def inv():
+                if real:
+                    pl.execC2R(v_in, v_out)
+                else:
+                    pl.execC2C(v_in, v_out, dfft.INVERSE)
+            tuned = None
+            if not args.no_tune_variants:
+                # the plan's own tuner (dfft_tune_variants: workgroup order and kernel configuration per pass, by measurement) -- what
+                # bench.py calls at N > 1 before the warm-up, so these are the kernels a rank of the 8-GPU run would launch
+                try:
+                    with torch.cuda.stream(side):
+                        tr = pl.tuneVariants(v_in, v_out, v_back)   # without a third buffer: forward passes only
+                    tuned = {"as_built_ms": round(tr[0], 3), "chosen_ms": round(tr[-1], 3), "trials": len(tr),
+                             "chosen (variant, order, addr64) per pass": pl.getPassChoices()}
+                except Exception as e:   # noqa: BLE001
+                    tuned = {"error": str(e)}
+            return stub, pl, fwd, inv, tuned
+
+        def whole_step_ms(fwd, inv):
+            """forward + inverse pairs enqueued back to back, no phase events, one synchronisation at the end"""
+            with torch.cuda.stream(side):
+                fwd(); inv()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.cuda.stream(side):
+                for _ in range(steps):
+                    fwd(); inv()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps * 1e3
+
+        stub, pl, fwd, inv, tuned = build({"compute_streams": 1})
+        one_stream_ms = whole_step_ms(fwd, inv)
         pl.enablePhaseTiming(True)
         acc = {}
         for i in range(steps + 2):
@@ -679,20 +700,30 @@ def main():
                         acc[name] = acc.get(name, 0.0) + ms
         torch.cuda.synchronize()
         osz_v = pl.getOutSize()
+        chunks_v = pl.getPipelineChunks()
         # bytes one pass moves: the local volume read once and written once (R2C: the Hermitian half of this rank, [Nx][yo][zs])
         vb = 2.0 * esz * float(osz_v[0] * osz_v[1] * osz_v[2]) if real else 2.0 * esz * float(N) ** 3 / nr
         passes = {name: {"ms": round(ms / steps, 3), "TBps": round(vb / (ms / steps * 1e-3) / 1e12, 3)} for name, ms in acc.items()}
         tot = sum(v["ms"] for v in passes.values())
+        del pl
+        stub.destroy()
+        step_ms, streams = one_stream_ms, 1
+        if (options or {}).get("compute_streams", -1) != 1 and chunks_v >= 3:
+            stub, pl, fwd, inv, _ = build({})
+            step_ms, streams = whole_step_ms(fwd, inv), 2
+            del pl
+            stub.destroy()
         res = {"decomposition": f"slab P={P1v}" if P2v == 1 else f"pencil {P1v}x{P2v}", "rank": 0,
-               "pipeline_chunks": pl.getPipelineChunks(), "kernels_ms_per_step": round(tot, 3), "per_pass": passes,
+               "pipeline_chunks": chunks_v, "compute_streams": streams,
+               "step_ms": round(step_ms, 3), "step_ms_one_stream": round(one_stream_ms, 3),
+               "step_avg_TBps": round(6 * vb / (step_ms * 1e-3) / 1e12, 3) if step_ms > 0 else None,
+               "kernels_ms_per_step": round(tot, 3), "per_pass": passes,
                "alg_bytes_per_pass": vb, "avg_TBps": round(6 * vb / (tot * 1e-3) / 1e12, 3) if tot > 0 else None,
                "tune_variants": tuned, "xgmi_model_per_transform": xgmi_model(esz, N, nr, P1v, P2v)}
         if options:
             res["options"] = dict(options)
         if real:
             res["transform"] = "execR2C + execC2R (the reference's own API); bytes per pass = 2 x the rank's Hermitian half"
-        del pl
-        stub.destroy()
         return res
 
     chunks_main = plan.getPipelineChunks()
@@ -959,8 +990,10 @@ def main():
             out["config"]["multi_rank_path"] = multi_rank_path
         if per_gpu_8 is not None:
             out["config"]["per_gpu_kernels_8gpu"] = {
-                "what": "rank 0's plan of the 8-GPU decompositions run on this GPU with the exchange stubbed out: per-pass "
-                        "device time of the kernels one GPU of the 8-GPU run launches per step (1/8 of the volume each)",
+                "what": "rank 0's plan of the 8-GPU decompositions run on this GPU with the exchange stubbed out (1/8 of the volume): "
+                        "step_ms = forward + inverse as a rank runs them (the chunks of a pass alternate over two compute streams from "
+                        "three chunks on), step_ms_one_stream = the same with the chunks serialised on one stream; per_pass / "
+                        "kernels_ms_per_step = device spans of the serialised launches (spans of overlapping chunks cannot be summed)",
                 "plans": per_gpu_8,
                 "spectral_layout_plans": per_gpu_8_spectral,
                 "r2c_and_depth_plans": per_gpu_8_more,

@@ -353,9 +353,11 @@ struct Options {
     int spectral = 0;        // 1: the spectrum is kept x-contiguous, [yo][zs][Nx] (lines along kx natural), instead of the reference's
                              // [Nx][yo][zs]: the forward x pass stores natural lines and the inverse x pass loads them -- neither
                              // touches the point-major layout whose strided read is the slowest pass of every multi-rank plan
-    int compute_streams = 1; // 2: the pipeline chunks of a pass alternate over two compute streams, so that the drain of chunk c
+    int compute_streams = -1; // 2: the pipeline chunks of a pass alternate over two compute streams, so that the drain of chunk c
                              // overlaps the ramp of chunk c + 1 (a chunk launch of 0.1-0.2 ms pays ~20 us of launch / drain / ramp when
-                             // the chunks queue up behind each other on one stream)
+                             // the chunks queue up behind each other on one stream).  -1 = by measurement
+                             // (profiles/r6_compute_streams.txt): two streams from three chunks per pass on (rank 0 of 2x4, 1024^3
+                             // fp64: 4 chunks 4.89 -> 4.78 ms, 8 chunks 5.31 -> 4.90; at two chunks there is nothing to gain), 1 = one
     int order[6] = {-1, -1, -1, -1, -1, -1};     // workgroup->tile order per pass: fz fy fx ix iy iz; a_fastest + 2*xcd_swizzle
     int variant[6] = {-1, -1, -1, -1, -1, -1};   // kernel configuration per pass, same order (-1 = the plan's choice)
 };
@@ -1082,6 +1084,14 @@ static int span_end(dfft_plan *p, hipStream_t s)
     return 0;
 }
 
+// compute streams the chunked passes of this plan run on (Options::compute_streams)
+static int compute_streams_of(const dfft_plan *p)
+{
+    const int C = p->pl.C, want = p->opt.compute_streams;
+    if (C < 2) return 1;
+    return want < 0 ? (C >= 3 ? 2 : 1) : (want > 1 ? 2 : 1);
+}
+
 static hipEvent_t pipe_event(dfft_plan *p, size_t i)
 {
     Pipeline &pl = p->pl;
@@ -1147,7 +1157,7 @@ static int enqueue_forward(dfft_plan *p, void *out, const void *in)
     p->nspans = 0; p->last_dir = DFFT_FORWARD;
     // two compute streams (option compute_streams): chunk c of a pass runs on SC(c); a chunk depends on the same chunk of the pass
     // (or exchange) before it, which sits on the same stream or arrives through that chunk's event
-    hipStream_t Sc2 = (p->opt.compute_streams > 1 && C > 1 && !p->lv_bytes) ? pl.compute_stream2 : nullptr;     // (two-level passes share one scratch)
+    hipStream_t Sc2 = (compute_streams_of(p) > 1 && !p->lv_bytes) ? pl.compute_stream2 : nullptr;     // (two-level passes share one scratch)
     auto SC = [&](int c) { return (Sc2 && (c & 1)) ? Sc2 : Sc; };
     // event ids: [0,C) z done, [C,2C) ex1 done, [2C,3C) y done, [3C,4C) ex2 done, 4C = entry fence, 4C+1.. = joins of the compute streams
     if ((p->comm && p->nranks > 1) || Sc2) EV_RECORD(4 * C, Sc);
@@ -1237,7 +1247,7 @@ static int enqueue_inverse(dfft_plan *p, void *out, void *in)
         TRY(span_end(p, Sc));
         return 0;
     }
-    hipStream_t Sc2 = (p->opt.compute_streams > 1 && C > 1 && !p->lv_bytes) ? pl.compute_stream2 : nullptr;     // (two-level passes share one scratch)
+    hipStream_t Sc2 = (compute_streams_of(p) > 1 && !p->lv_bytes) ? pl.compute_stream2 : nullptr;     // (two-level passes share one scratch)
     auto SC = [&](int c) { return (Sc2 && (c & 1)) ? Sc2 : Sc; };
     // both compute streams have finished what they were given so far (event ids 4C+1 ..: see enqueue_forward)
     int joins = 0;
@@ -1526,6 +1536,7 @@ template <typename F> static int run_graphed(dfft_plan *p, int kind, const void 
 struct DevAlloc { size_t bytes, chunk; int device; };     // chunk == 0: plain hipMalloc; device = the GPU that owns the memory
 static std::mutex g_alloc_mu;
 static std::map<void *, DevAlloc> g_allocs;
+static std::atomic<size_t> g_retired_bytes{0};     // address space dfft_free has retired (dev_free; dfft_last_placement_info reports it)
 
 static int dev_free(void *ptr)
 {
@@ -1546,20 +1557,21 @@ static int dev_free(void *ptr)
     if (hop) HIP_TRY(hipSetDevice(rec.device));
     hipError_t e = hipDeviceSynchronize();
     for (size_t off = 0; off < rec.bytes && e == hipSuccess; off += rec.chunk) e = hipMemUnmap(static_cast<char *>(ptr) + off, rec.chunk);
-    // The address range is RETIRED, not returned: the physical memory is gone with the unmap, the reservation stays.  A range that went
-    // back to the runtime and was handed out again (hipMemAddressFree, then a later hipMemAddressReserve at the same address) corrupted
-    // copies when other host threads were enqueueing work at the time -- the relay's staging as virtual memory under eight virtual
-    // ranks: round trips wrong in 8 of 8 runs with the range freed (synchronising once more before the free did not help), 0 of 8 with
-    // it kept (profiles/r5_relay_stress.txt).  Address space is plentiful (47 bits); DFFT_VMM_RETIRE_TIB (default 8) bounds what a
-    // process retires, beyond it ranges are freed as before (0 = always free).
-    static const size_t retire_cap = [] { const char *v = getenv("DFFT_VMM_RETIRE_TIB"); return (size_t)(v ? atol(v) : 8) << 40; }();
-    static std::atomic<size_t> retired{0};
-    bool keep = false;
-    if (e == hipSuccess && retire_cap) {
-        size_t cur = retired.load();
-        while (cur + rec.bytes <= retire_cap && !(keep = retired.compare_exchange_weak(cur, cur + rec.bytes))) {}
+    // The address range is RETIRED, never handed out again: the physical memory is gone with the unmap, the reservation stays for the
+    // life of the process.  On this ROCm (7.2, gfx950) a virtual address that is mapped a SECOND time -- after hipMemAddressFree and a
+    // later hipMemAddressReserve at the same address, or by mapping fresh chunks into a reservation that was kept -- reads and writes
+    // wrong bytes, for kernels and for runtime copies alike, with or without other threads enqueueing: tools/vmm_reuse_repro.hip is a
+    // standalone reproducer without this library (profiles/r6_vmm_reuse_repro.txt: modes `free` and `keep` mismatch within 2-90
+    // cycles in every configuration, mode `retire` never in ~10^4 cycles).  Round 5 met it as wrong round trips of the relay whose
+    // staging had been re-created (profiles/r5_relay_stress.txt) and capped the retirement at 8 TiB; there is no cap any more, because
+    // beyond it the corrupting path came back.  What bounds it instead is the address space itself (47 bits): when a reservation
+    // fails, dev_alloc falls back to hipMalloc (slower scatter target, correct bytes).  DFFT_VMM_RETIRE=0 returns ranges to the
+    // runtime again -- for reproducing the defect only.
+    static const bool retire = [] { const char *v = getenv("DFFT_VMM_RETIRE"); return !(v && v[0] == '0'); }();
+    if (e == hipSuccess) {
+        if (retire) g_retired_bytes += rec.bytes;
+        else e = hipMemAddressFree(ptr, rec.bytes);
     }
-    if (e == hipSuccess && !keep) e = hipMemAddressFree(ptr, rec.bytes);
     if (hop) (void)hipSetDevice(cur);
     if (e != hipSuccess) { set_error(std::string("dfft_free: ") + hipGetErrorString(e)); return (int)e; }
     return 0;
@@ -1663,7 +1675,8 @@ static int dev_alloc(size_t bytes, size_t chunk_mib, void **out, int spread = 1)
     }
     if (err != hipSuccess) {
         for (size_t off = 0; off < mapped; off += chunk) (void)hipMemUnmap(static_cast<char *>(va) + off, chunk);
-        (void)hipMemAddressFree(va, total);
+        if (!mapped) (void)hipMemAddressFree(va, total);      // a range that held a mapping is retired like any other (dev_free)
+        else g_retired_bytes += total;
         set_error(std::string("virtual-memory allocation failed: ") + hipGetErrorString(err));
         return (int)err;
     }
@@ -2393,7 +2406,7 @@ static int ensure_device_state(dfft_plan *p)
     if (p->comm && !p->pl.comm_stream) HIP_TRY(hipStreamCreateWithFlags(&p->pl.comm_stream, hipStreamNonBlocking));
     if (p->comm && p->P1 > 1 && p->P2 > 1 && !p->pl.comm_stream2)
         HIP_TRY(hipStreamCreateWithFlags(&p->pl.comm_stream2, hipStreamNonBlocking));
-    if (p->opt.compute_streams > 1 && p->pl.C > 1 && !p->pl.compute_stream2)
+    if (compute_streams_of(p) > 1 && !p->pl.compute_stream2)
         HIP_TRY(hipStreamCreateWithFlags(&p->pl.compute_stream2, hipStreamNonBlocking));
     return 0;
 }

@@ -14,7 +14,15 @@ values are ~1e-15, profiles/r6_parity_table.txt; fp32-rounded twiddles give ~1e-
 fp32 against the fp64 oracle: 2e-7 * log2(n).  The old assertion stays beside it wherever it was.
 
 Zero-mean inputs (uniform - 127.5, and the sine field of the reference's testcase 4, random_dist_3D.cu:748-762) are
-added next to the reference's distribution: CENTER is what `center=True` subtracts."""
+added next to the reference's distribution: CENTER is what `center=True` subtracts.
+
+fp32 and the NON-NEGATIVE distribution: the per-entry bound is asserted on the zero-mean inputs only.  With a mean of 127.5 the
+z pass leaves 127.5 Nz in every kz = 0 entry, and the y and x passes on the planes through the DC point cancel numbers of that
+size down to the noise: the rounding they leave is eps32 times the DC MASS (180 N^(3/2) per plane line), not eps32 times the
+entry -- any fp32 FFT has it, and relative to rms(X) it reads 1e-5 ... 6e-4 (measured: profiles/r6_parity_table.txt, the rows
+`float ... centred=False`; the same kernels on the centred input: <= 1.3e-6).  There the old bound (scaled by max|X| = the DC term,
+which IS the scale of that error) stays the assertion and the per-entry figure is recorded only.  fp64 has 9 more digits and
+passes the per-entry bound on both inputs."""
 import math
 import os
 
@@ -54,12 +62,15 @@ def record(label, prec, npoints, value, bound, old=None):
                     + (f"  (max|err|/max|X| = {old:.3e})" if old is not None else "") + "\n")
 
 
-def check_forward(got, want, prec, npoints, label=None, want_rms=None, factor=1.0):
-    """the per-entry forward bound; returns the measured value"""
+def check_forward(got, want, prec, npoints, label=None, want_rms=None, factor=1.0, zero_mean=True):
+    """the per-entry forward bound; returns the measured value.  zero_mean=False (the reference's non-negative distribution):
+    asserted at fp64, recorded only at fp32 (see the module docstring)"""
     v = rms_rel(got, want, want_rms)
     b = forward_bound(prec, npoints) * factor
     if label:
         old = float(np.max(np.abs(np.asarray(got) - np.asarray(want)))) / max(float(np.max(np.abs(want))), 1e-300)
         record(label, prec, npoints, v, b, old)
+    if prec == "float" and not zero_mean:
+        return v
     assert v <= b, f"forward error per entry {v:.3e} > {b:.1e} (max|got - want| / rms(want), {prec}, {npoints} points{', ' + label if label else ''})"
     return v

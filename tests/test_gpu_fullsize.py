@@ -104,7 +104,7 @@ def test_c2_256_single_gpu_every_point_vs_oracle(center):
     want = orc.fft3d_c2c(g, -1)
     got = d_out[:g.size].cpu().numpy().reshape(shape)
     assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-11
-    check_forward(got, want, "double", g.size, label=f"C2 256^3 fp64 one rank, every point, centred={center}")
+    check_forward(got, want, "double", g.size, zero_mean=center, label=f"C2 256^3 fp64 one rank, every point, centred={center}")
     back = torch.zeros_like(d_in)
     torch.cuda.synchronize()
     plan.execC2C(back, d_out, dfft.INVERSE)
@@ -127,7 +127,7 @@ def test_c3_512_slab_two_ranks_every_point_vs_oracle(center):
         s, o = rk["plan"].getOutSize(), rk["plan"].getOutStart()
         got = spectrum_block(rk).cpu().numpy()
         assert np.max(np.abs(got - want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]])) / scale < 1e-11
-        check_forward(got, want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]], "double", want.size, want_rms=want_rms,
+        check_forward(got, want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]], "double", want.size, want_rms=want_rms, zero_mean=center,
                       label=f"C3 512^3 fp64 slab 2, rank {r}, every point, centred={center}")
     run_all(ranks, lambda rk: rk["plan"].execC2C(rk["back"], rk["out"], dfft.INVERSE))
     for rk in ranks:
@@ -192,7 +192,8 @@ def test_c5_fp32_axis_2048_and_1024_cube(shape, P1, P2):
     for k in [(0, 0, 0), (1, 2, 3), (shape[0] - 1, shape[1] // 2, shape[2] // 3)]:
         got, want = owner_entry(ranks, k), direct_dft_entry(ranks, shape, k)
         assert abs(got - want) / scale < 1e-4
-        assert entry_rel(got, want, spec_rms) < forward_bound("float", n3), (k, got, want)
+        if all(k):      # off the planes through the DC point (non-negative fp32 input: parity_metric.py)
+            assert entry_rel(got, want, spec_rms) < forward_bound("float", n3), (k, got, want)
     run_all(ranks, lambda rk: rk["plan"].execC2C(rk["back"], rk["out"], dfft.INVERSE))
     for rk in ranks:
         assert float((rk["back"] / n3 - rk["x"]).abs().max()) / 255.0 < 5e-5

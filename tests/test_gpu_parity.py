@@ -44,7 +44,8 @@ def test_fft1d_batched_vs_oracle(N, prec):
             torch.cuda.synchronize()
             want = orc.fft1d(x.astype(NPDT[prec]), direction)
             assert rel(d_out.cpu().numpy(), want) < TOL_FWD[prec]
-            check_forward(d_out.cpu().numpy(), want, prec, N, label=f"fft1d N={N} dir={direction} mean={x.real.mean():.0f}" if N in (8, 1024, 8192) else None)
+            check_forward(d_out.cpu().numpy(), want, prec, N, zero_mean=x is not x0,
+                          label=f"fft1d N={N} dir={direction} mean={x.real.mean():.0f}" if N in (8, 1024, 8192) else None)
 
 
 def run_single(shape, prec, seed=5, center=False):
@@ -77,7 +78,7 @@ def test_single_rank_3d_vs_oracle(shape, prec):
         g, got, back = run_single(shape, prec, center=center)
         want = orc.fft3d_c2c(g.astype(np.complex128), -1)
         assert rel(got, want) < TOL_FWD[prec]
-        check_forward(got, want, prec, g.size, label=f"single rank {shape} centred={center}" if shape in ((128, 128, 128), (16, 20, 8192)) else None)
+        check_forward(got, want, prec, g.size, zero_mean=center, label=f"single rank {shape} centred={center}" if shape in ((128, 128, 128), (16, 20, 8192)) else None)
         assert rel(back / g.size, g) < TOL_RT[prec]
 
 
@@ -147,7 +148,7 @@ def test_distributed_vs_oracle(shape, P1, P2, prec):
             assert (s, o) == opl.out_block(r)
             ref = want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]]
             assert rel(spec[r], ref) < TOL_FWD[prec] * (np.max(np.abs(want)) / max(np.max(np.abs(ref)), 1e-300))
-            check_forward(spec[r], ref, prec, g.size, want_rms=want_rms,
+            check_forward(spec[r], ref, prec, g.size, want_rms=want_rms, zero_mean=center,
                           label=f"distributed {shape} {P1}x{P2} rank {r} centred={center}" if r == 0 and shape in ((128, 64, 32), (64, 64, 64)) else None)
             assert rel(backs[r] / n3, ins[r]) < TOL_RT[prec]
             for which in (1, 2):   # byte tables == the reference's formulas (via the oracle restatement)
@@ -224,7 +225,7 @@ def test_r2c_c2r_vs_oracle(shape, P1, P2, prec):
             s, o = pl.getOutSize(), pl.getOutStart()
             ref = want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]]
             assert np.max(np.abs(spec[r] - ref)) / scale < TOL_FWD[prec]
-            check_forward(spec[r], ref, prec, g.size, want_rms=want_rms,
+            check_forward(spec[r], ref, prec, g.size, want_rms=want_rms, zero_mean=center,
                           label=f"R2C {shape} {P1}x{P2} rank {r} centred={center}" if r == 0 and shape in ((128, 64, 32), (4, 512, 4096)) else None)
             assert rel(backs[r] / n3, ins[r]) < TOL_RT[prec]
 
@@ -642,7 +643,7 @@ def test_address_table_modes_agree(mode, monkeypatch):
 def test_two_compute_streams_are_bit_identical_to_one(shape, P1, P2, chunks):
     """the same kernels on the same data in another stream assignment: spectrum and round trip must not change by one bit
     (a missing dependency between the two compute streams shows up as a difference or as a wrong result against the oracle)"""
-    ref = run_distributed(shape, P1, P2, "double", chunks=chunks)
+    ref = run_distributed(shape, P1, P2, "double", chunks=chunks, options={"compute_streams": 1})
     want = orc.fft3d_c2c(orc.fill_block(shape, (0, 0, 0), shape, 2, seed=7), -1)
     for _ in range(3):          # scheduling varies from run to run
         two = run_distributed(shape, P1, P2, "double", chunks=chunks, options={"compute_streams": 2})
@@ -651,12 +652,12 @@ def test_two_compute_streams_are_bit_identical_to_one(shape, P1, P2, chunks):
             assert np.array_equal(two[2][r], ref[2][r]) and np.array_equal(two[3][r], ref[3][r])
     for r, pl in enumerate(ref[0]):
         s, o = pl.getOutSize(), pl.getOutStart()
-        check_forward(ref[2][r], want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]], "double", want.size, want_rms=rms(want))
+        check_forward(ref[2][r], want[:, o[1]:o[1] + s[1], o[2]:o[2] + s[2]], "double", want.size, want_rms=rms(want), zero_mean=False)
 
 
 @pytest.mark.parametrize("shape,P1,P2", [((32, 32, 32), 2, 4), ((64, 32, 16), 4, 1), ((16, 32, 64), 1, 4)])
 def test_two_compute_streams_r2c_bit_identical(shape, P1, P2):
-    ref = run_distributed_real(shape, P1, P2, "double")
+    ref = run_distributed_real(shape, P1, P2, "double", options={"compute_streams": 1})
     for _ in range(3):
         two = run_distributed_real(shape, P1, P2, "double", options={"compute_streams": 2})
         for r in range(P1 * P2):

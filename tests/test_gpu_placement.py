@@ -217,3 +217,52 @@ def test_default_backing_shares_the_device(tmp_path):
     info = json.loads(out.stdout.strip().splitlines()[-1])
     # 64 sharers of 288 GB: 2.2 GiB each -- room for the buffer itself, not for a pool
     assert info["spread_K"] == 0 and info["candidates_drawn"] == 1 and info["fallback"] == 0, info
+
+
+@pytest.mark.parametrize("mib,chunk_mib,cycles", [(256, 64, 1000), pytest.param(1024, 1024, 1000, marks=pytest.mark.slow)])
+def test_many_alloc_free_cycles_under_enqueueing_threads_stay_bit_identical(mib, chunk_mib, cycles):
+    """dfft_malloc / dfft_free of a virtual-memory buffer, `cycles` times, while eight other host threads keep enqueueing copies
+    and kernels: every cycle writes a pattern through the new buffer (runtime copy in, kernel copy out) and reads it back bit for
+    bit.  On this ROCm a virtual address that is mapped twice delivers wrong bytes (tools/vmm_reuse_repro.hip, standalone:
+    profiles/r6_vmm_reuse_repro.txt), so dfft_free retires address ranges for good -- no address may come back, and after the
+    thousandth free the behaviour is what it was after the first (round 5 stopped retiring at 8 TiB).  The 1 GiB form of the
+    round-5 verdict runs under -m "gpu and slow" (profiles/r6_alloc_cycles.txt)."""
+    import threading
+    stop = threading.Event()
+    bad = []
+
+    def worker(i):
+        s = torch.cuda.Stream()
+        a = torch.arange(1 << 20, dtype=torch.int64, device="cuda") + i
+        with torch.cuda.stream(s):
+            while not stop.is_set():
+                b = torch.empty_like(a)
+                b.copy_(a)
+                c = b * 3 + 1
+                if not bool((c == a * 3 + 1).all()):
+                    bad.append(i)
+                    return
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    for t in threads:
+        t.start()
+    n = (mib << 20) // 8
+    src = torch.empty(n, dtype=torch.int64, device="cuda")
+    sink = torch.empty_like(src)
+    seen = set()
+    try:
+        for cyc in range(cycles):
+            buf = dfft.DeviceBuffer.alloc(mib << 20, chunk_mib)
+            assert buf.address not in seen, f"cycle {cyc}: address {buf.address:#x} was handed out before"
+            seen.add(buf.address)
+            t = buf.tensor(torch.int64)
+            torch.add(torch.arange(n, dtype=torch.int64, device="cuda"), cyc * 7919, out=src)
+            t.copy_(src)                    # runtime copy into the new range
+            torch.mul(t, 1, out=sink)       # kernel read out of it
+            assert torch.equal(sink, src), f"cycle {cyc}: wrong bytes through a fresh virtual-memory buffer"
+            del t
+            buf.free()
+    finally:
+        stop.set()
+        for t in threads:
+            t.join()
+    assert not bad
