@@ -48,6 +48,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 HBM_COPY_PEAK_GBS = 6290.0   # same guide: what a plain device-to-device copy reaches (read + write bytes / time)
 XGMI_LINK_GBS = 153.0   # same guide: per link and direction
+FP64_VECTOR_PEAK_TFLOPS = 73.4   # measured on an MI355X: tools/fp64_peak (profiles/r6_fp64_peak.txt); public specification 78.6
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # public specification (packed FMA); not measured here
 RELAY_TIMEOUT_S = 180   # watchdog of the relayed leg at N > 1 (it has never run on more than one GPU)
 
 
@@ -705,13 +707,13 @@ def main():
         vb = 2.0 * esz * float(osz_v[0] * osz_v[1] * osz_v[2]) if real else 2.0 * esz * float(N) ** 3 / nr
         passes = {name: {"ms": round(ms / steps, 3), "TBps": round(vb / (ms / steps * 1e-3) / 1e12, 3)} for name, ms in acc.items()}
         tot = sum(v["ms"] for v in passes.values())
-        del pl
+        del fwd, inv, pl          # (the closures hold the plan: its work area goes with the last reference)
         stub.destroy()
         step_ms, streams = one_stream_ms, 1
         if (options or {}).get("compute_streams", -1) != 1 and chunks_v >= 3:
             stub, pl, fwd, inv, _ = build({})
             step_ms, streams = whole_step_ms(fwd, inv), 2
-            del pl
+            del fwd, inv, pl
             stub.destroy()
         res = {"decomposition": f"slab P={P1v}" if P2v == 1 else f"pencil {P1v}x{P2v}", "rank": 0,
                "pipeline_chunks": chunks_v, "compute_streams": streams,
@@ -742,6 +744,20 @@ def main():
                 "kernel": "dfft::fft_pass_kernel", "avg_launch_ms": round(avg_ms, 4),
                 "launches_timed": kern_launches, "alg_bytes_per_launch": vol_bytes,
                 "launches_per_pass": chunks_main if ngpus > 1 else 1}
+
+    # the same launch against the COMPUTE roof (north_star: "FLOP/s for the butterfly pass against the gfx950 roofline"): one axis pass
+    # is 5 N^3 log2 N flops by the metric's own convention; FP64 vector peak measured on an MI355X with tools/fp64_peak
+    # (profiles/r6_fp64_peak.txt: 73.4 TFLOP/s; public specification 78.6 = 256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz; the in-image
+    # guide lists no FP64 figure).  The pass sits at ~13 % of it: bandwidth-bound by a factor of six, as the intensity says
+    # (5 log2 N / 32 B = 1.56 flop/B at N = 1024 fp64 -> 9.8 TFLOP/s at the 6.29 TB/s copy rate).
+    flops_launch = 5.0 * float(N) ** 3 * math.log2(N) / ngpus
+    peak_tf = FP64_VECTOR_PEAK_TFLOPS if prec == "double" else FP32_VECTOR_PEAK_TFLOPS
+    ach_tf = flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    roofline["compute"] = {"flops_per_launch": flops_launch, "achieved_TFLOPs": round(ach_tf, 2), "peak_TFLOPs": peak_tf,
+                           "frac": round(ach_tf / peak_tf, 4),
+                           "peak_source": ("measured: tools/fp64_peak, profiles/r6_fp64_peak.txt (specification 78.6)" if prec == "double"
+                                           else "specification: FP32 vector 157.3 TFLOP/s (packed / dual-issue FMA)"),
+                           "flop_per_byte": round(flops_launch / vol_bytes, 3)}
 
     # HBM bytes per launch: NOT measured by this run.  It is the figure of the committed PMC profile of this kernel
     # on this workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 read correction applied)

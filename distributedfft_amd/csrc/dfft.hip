@@ -2153,6 +2153,13 @@ int dfft_init(dfft_plan *p, size_t Nx, size_t Ny, size_t Nz, int P1, int P2, int
         if (!zok || !yok || !axis_plan(p->prec, Nx, axx, mixed, tl))
             return fail(ERR_UNSUPPORTED, "unsupported axis length (every length from 2 to 2^23 has a plan; beyond that only lengths N1*N2 <= 2^24 whose "
                                          "factors are each a power of two up to 8192 or any length up to 4096)");
+        // an axis outside the power-of-two kernels of this library runs kernels of libdfft_amd_any.so (any_loader.hip): no fallback
+        for (const Axis *a : {&az, &ay, &axx}) {
+            std::string why;
+            if ((a->bluestein || !is_pow2(a->N)) && !any_available(&why))
+                return fail(ERR_UNSUPPORTED, "an axis of " + std::to_string(a->N) + " points needs the kernels of libdfft_amd_any.so (every length that is "
+                                             "not a power of two up to 8192): " + why);
+        }
         for (auto &a : p->ax) axis_free(a);
         p->ax[0] = az; p->ax[1] = ay; p->ax[2] = axx;
         p->zreal_native = zr_native;
@@ -2751,6 +2758,8 @@ int dfft_fft1d_batched_ex(int precision, size_t N, size_t batch, void *out, cons
         ax = Axis();
         axP = -1;
         if (!(force == 1 ? axis_plan_bluestein(precision, N, ax) : axis_plan(precision, N, ax, true, force == 2))) { ax = Axis(); return fail(ERR_UNSUPPORTED, "unsupported line length"); }
+        std::string why;
+        if ((ax.bluestein || !is_pow2(ax.N)) && !any_available(&why)) { ax = Axis(); return fail(ERR_UNSUPPORTED, "this line length needs the kernels of libdfft_amd_any.so: " + why); }
         if (int r = axis_upload(precision, ax)) { axis_free(ax); ax = Axis(); return r; }
         axP = precision;
         axB = force;

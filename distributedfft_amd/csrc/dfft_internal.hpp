@@ -48,6 +48,10 @@ bool pass_info_f32(int N, int variant, PassInfo *pi);
 int launch_shfl_f32(int N, int dpp, const PassArgs &A, hipStream_t stream);      // LDS-free shuffle pass (A/B only)
 #endif
 
+// libdfft_amd_any.so (any_loader.hip): the kernels of every length that is not a power of two up to 8192 -- mixed radix, Bluestein,
+// two-level lines -- loaded at the first plan that needs them.  The launchers of those kernels answer -1 / false while it is missing.
+bool any_available(std::string *why);
+
 void set_error(const std::string &msg);
 
 }  // namespace dfft

@@ -516,3 +516,55 @@ def test_pass_choices_follow_the_role_rules():
     assert choices("float", 2048, 1, 1, options={"single_order": 0})["fy"] == 6
     # a pinned pass stays pinned
     assert choices("double", 1024, 2, 4, options={"variant_ix": 2})["ix"] == 2
+
+
+# ------------------------------------------------------------------------------------------
+# the two libraries: libdfft_amd.so (powers of two up to 8192: every BASELINE configuration) and libdfft_amd_any.so (every other
+# length), which the core opens at the first plan that needs it (csrc/any_loader.hip, csrc/any_exports.hip)
+# ------------------------------------------------------------------------------------------
+ANY_SYMBOLS = ["dfft_any_launch_mixed_f64", "dfft_any_launch_mixed_f32", "dfft_any_mixed_info_f64", "dfft_any_mixed_info_f32",
+               "dfft_any_launch_rmixed_f64", "dfft_any_launch_rmixed_f32", "dfft_any_rmixed_info_f64", "dfft_any_rmixed_info_f32",
+               "dfft_any_launch_bluestein_f64", "dfft_any_launch_bluestein_f32"]
+
+
+def test_second_library_exports_what_the_core_looks_up():
+    import ctypes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "distributedfft_amd", "libdfft_amd_any.so")
+    assert os.path.exists(path), "libdfft_amd_any.so is not built: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = ctypes.CDLL(path)
+    for name in ANY_SYMBOLS:
+        assert hasattr(lib, name), name
+    # every name the loader asks for is one of these (the two files cannot drift apart unnoticed)
+    src = open(os.path.join(root, "distributedfft_amd", "csrc", "any_loader.hip")).read()
+    import re
+    assert sorted(set(re.findall(r'sym\("(dfft_any_\w+)"\)', src))) == sorted(ANY_SYMBOLS)
+
+
+def test_plans_outside_the_core_fail_loudly_without_the_second_library():
+    """DFFT_ANY_LIBRARY names a file that does not exist: powers of two plan as always, any other length refuses to initialise and
+    says which library is missing -- no fallback, no crash at the first launch"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import distributedfft_amd as dfft\n"
+        "pl = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations())\n"
+        "pl.initFFT(dfft.GlobalSize(64, 32, 16), dfft.Pencil_Partition(1, 1), False)\n"
+        "print('pow2 ok', pl.getDomainSize())\n"
+        "for shape in ((12, 16, 16), (16, 17, 16), (16, 16, 10000), (16384, 4, 4)):\n"
+        "    try:\n"
+        "        pl.initFFT(dfft.GlobalSize(*shape), dfft.Pencil_Partition(1, 1), False, c2c=True)\n"
+        "        print('UNEXPECTED', shape)\n"
+        "    except dfft.DfftError as e:\n"
+        "        print('refused', shape, 'libdfft_amd_any.so' in str(e) and 'cannot load' in str(e))\n")
+    env = dict(os.environ, DFFT_ANY_LIBRARY="/nonexistent/libdfft_amd_any.so", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().split("\n")
+    assert lines[0].startswith("pow2 ok")
+    assert [ln for ln in lines[1:]] == [f"refused {s} True" for s in ((12, 16, 16), (16, 17, 16), (16, 16, 10000), (16384, 4, 4))], out.stdout
+    # and with the library in place the same lengths plan
+    env.pop("DFFT_ANY_LIBRARY")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.stdout.count("UNEXPECTED") == 4, out.stdout + out.stderr

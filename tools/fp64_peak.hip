@@ -1,4 +1,4 @@
-// tools/fp64_peak.hip -- measured FP64 / FP32 vector FMA rate of the device: the COMPUTE roof the butterfly arithmetic of the axis
+// tools/fp64_peak.hip -- measured FP64 vector FMA rate of the device: the COMPUTE roof the butterfly arithmetic of the axis
 // passes is priced against in bench.py (roofline.compute).  The in-image guide lists no FP64 figure (MI355X_MICROARCH.md); the
 // public specification is 78.6 TFLOP/s FP64 vector = 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz, so it is measured here:
 // every thread runs 16 independent chains of fused multiply-adds from registers, 2 flops per FMA and lane.
@@ -57,6 +57,5 @@ int main()
     int clk = 0;
     CHK(hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0));
     printf("device clock rate attribute: %.2f GHz\n", clk / 1e6);
-    if (int r = measure<double>("FP64")) return r;
-    return measure<float>("FP32");
+    return measure<double>("FP64");
 }
