@@ -1536,7 +1536,40 @@ template <typename F> static int run_graphed(dfft_plan *p, int kind, const void 
 struct DevAlloc { size_t bytes, chunk; int device; };     // chunk == 0: plain hipMalloc; device = the GPU that owns the memory
 static std::mutex g_alloc_mu;
 static std::map<void *, DevAlloc> g_allocs;
-static std::atomic<size_t> g_retired_bytes{0};     // address space dfft_free has retired (dev_free; dfft_last_placement_info reports it)
+
+// A virtual address must not be MAPPED TWICE on this ROCm (7.2, gfx950).  A range that was unmapped and whose address is mapped
+// again -- after hipMemAddressFree and a later hipMemAddressReserve that returns the same address (what the runtime does by itself),
+// or by mapping fresh chunks into a reservation that was kept -- reads and writes wrong bytes, through kernels and through runtime
+// copies alike, with or without other threads enqueueing: tools/vmm_reuse_repro.hip reproduces it without this library in 2-90 map /
+// unmap cycles (profiles/r6_vmm_reuse_repro.txt; round 5 met it as wrong round trips of the relay, profiles/r5_relay_stress.txt).
+// Keeping every reservation forever ("retiring", round 5) is no way out either: the physical memory of an unmapped range only
+// returns to the device with hipMemAddressFree (profiles/r6_vmm_cost.txt: 1000 cycles of 64 MiB cost 62.5 GiB).  What works
+// (the reproducer's mode `hint`, profiles/r6_vmm_hint.txt: 10^4 cycles, memory level, no mismatch in any configuration): ranges ARE
+// returned, and every reservation names the address it wants -- the next one of a region of the address space that this library
+// walks through once, [DFFT_VMM_BASE_TIB = 4 TiB, 80 TiB): between the heap and the mmap area of an x86-64 process, 76 TiB = 4800
+// buffers of 16 GiB.  The runtime honours the hint (an address it does not is given back and the next one is tried); when the region
+// is used up the reservation fails and the default backing falls back to hipMalloc: slower scatter target, correct bytes.
+static std::atomic<uintptr_t> g_next_va{0};
+static hipError_t reserve_fresh(void **va, size_t total, size_t align)
+{
+    static const uintptr_t base = [] { const char *e = getenv("DFFT_VMM_BASE_TIB"); const long v = e ? atol(e) : 4; return (uintptr_t)(v < 1 ? 1 : v > 64 ? 64 : v) << 40; }();
+    const uintptr_t end = (uintptr_t)80 << 40;
+    const uintptr_t al = align > ((uintptr_t)2 << 20) ? (uintptr_t)align : ((uintptr_t)2 << 20);      // a power of two (the chunk, or the granularity)
+    const uintptr_t span = ((uintptr_t)total + al - 1) / al * al;
+    uintptr_t zero = 0;
+    g_next_va.compare_exchange_strong(zero, base);
+    for (int attempt = 0; attempt < 16; attempt++) {
+        const uintptr_t a = (g_next_va.fetch_add(span + al) + al - 1) / al * al;      // (one alignment unit of slack: a gap between neighbours)
+        if (a + span > end) return hipErrorOutOfMemory;
+        *va = nullptr;
+        const hipError_t e = hipMemAddressReserve(va, total, align, reinterpret_cast<void *>(a), 0);
+        if (e != hipSuccess) return e;
+        if (*va == reinterpret_cast<void *>(a)) return hipSuccess;
+        (void)hipMemAddressFree(*va, total);             // the runtime chose another address (something lives at the hint): not ours to trust
+    }
+    *va = nullptr;
+    return hipErrorOutOfMemory;
+}
 
 static int dev_free(void *ptr)
 {
@@ -1557,21 +1590,10 @@ static int dev_free(void *ptr)
     if (hop) HIP_TRY(hipSetDevice(rec.device));
     hipError_t e = hipDeviceSynchronize();
     for (size_t off = 0; off < rec.bytes && e == hipSuccess; off += rec.chunk) e = hipMemUnmap(static_cast<char *>(ptr) + off, rec.chunk);
-    // The address range is RETIRED, never handed out again: the physical memory is gone with the unmap, the reservation stays for the
-    // life of the process.  On this ROCm (7.2, gfx950) a virtual address that is mapped a SECOND time -- after hipMemAddressFree and a
-    // later hipMemAddressReserve at the same address, or by mapping fresh chunks into a reservation that was kept -- reads and writes
-    // wrong bytes, for kernels and for runtime copies alike, with or without other threads enqueueing: tools/vmm_reuse_repro.hip is a
-    // standalone reproducer without this library (profiles/r6_vmm_reuse_repro.txt: modes `free` and `keep` mismatch within 2-90
-    // cycles in every configuration, mode `retire` never in ~10^4 cycles).  Round 5 met it as wrong round trips of the relay whose
-    // staging had been re-created (profiles/r5_relay_stress.txt) and capped the retirement at 8 TiB; there is no cap any more, because
-    // beyond it the corrupting path came back.  What bounds it instead is the address space itself (47 bits): when a reservation
-    // fails, dev_alloc falls back to hipMalloc (slower scatter target, correct bytes).  DFFT_VMM_RETIRE=0 returns ranges to the
-    // runtime again -- for reproducing the defect only.
-    static const bool retire = [] { const char *v = getenv("DFFT_VMM_RETIRE"); return !(v && v[0] == '0'); }();
-    if (e == hipSuccess) {
-        if (retire) g_retired_bytes += rec.bytes;
-        else e = hipMemAddressFree(ptr, rec.bytes);
-    }
+    // The range goes back to the runtime (only hipMemAddressFree returns the PHYSICAL memory of an unmapped range on this ROCm: a
+    // range that is unmapped but kept costs its full size until the process ends, profiles/r6_vmm_cost.txt) -- and its addresses are
+    // never used again by this library: every reservation asks for a fresh address (reserve_fresh below).
+    if (e == hipSuccess) e = hipMemAddressFree(ptr, rec.bytes);
     if (hop) (void)hipSetDevice(cur);
     if (e != hipSuccess) { set_error(std::string("dfft_free: ") + hipGetErrorString(e)); return (int)e; }
     return 0;
@@ -1617,7 +1639,7 @@ static int dev_alloc(size_t bytes, size_t chunk_mib, void **out, int spread = 1)
     void *va = nullptr;
     // alignment: the chunk when it is a power of two (physical chunks then sit on their natural boundaries), else the granularity
     const size_t align = (chunk & (chunk - 1)) == 0 ? chunk : gran;
-    HIP_TRY(hipMemAddressReserve(&va, total, align, nullptr, 0));
+    HIP_TRY(reserve_fresh(&va, total, align));
     size_t mapped = 0;
     hipError_t err = hipSuccess;
     if (spread > 1) {
@@ -1675,8 +1697,7 @@ static int dev_alloc(size_t bytes, size_t chunk_mib, void **out, int spread = 1)
     }
     if (err != hipSuccess) {
         for (size_t off = 0; off < mapped; off += chunk) (void)hipMemUnmap(static_cast<char *>(va) + off, chunk);
-        if (!mapped) (void)hipMemAddressFree(va, total);      // a range that held a mapping is retired like any other (dev_free)
-        else g_retired_bytes += total;
+        (void)hipMemAddressFree(va, total);
         set_error(std::string("virtual-memory allocation failed: ") + hipGetErrorString(err));
         return (int)err;
     }

@@ -358,12 +358,13 @@ int dfft_axis_plan_info(int precision, size_t N, int two_level, size_t info[8]);
  * safe on every rank of a multi-rank job.  Costs 2 - 4 s per 16 GiB buffer (the driver clears fresh memory inside hipMemCreate at
  * ~30 ms per GiB: tools/vmm_cycle), 0.3 s per 2 GiB; DFFT_PLACEMENT_SPREAD=1: milliseconds (plain candidates only, no yardstick).  Environment: DFFT_DEFAULT_CHUNK_MIB
  * (0 = hipMalloc), DFFT_PLACEMENT_TRIES (1 = no probe), DFFT_PLACEMENT_SPREAD, DFFT_RANKS_PER_DEVICE, DFFT_PLACEMENT_GOOD_TBPS.
- * dfft_free of a virtual-memory buffer releases the physical memory and RETIRES the address range for the life of the process: on
- * this ROCm a virtual address that is mapped a second time (hipMemAddressFree + a later hipMemAddressReserve at the same address, or
- * fresh chunks mapped into a kept reservation) reads and writes wrong bytes -- tools/vmm_reuse_repro.hip reproduces it without this
- * library, with kernels and with runtime copies, in 2 - 90 map / unmap cycles (profiles/r6_vmm_reuse_repro.txt); ranges that are never
- * reused stay clean.  No cap: the 47-bit address space bounds it (a 16 GiB buffer can be freed ~8000 times), and when a reservation
- * fails the default backing falls back to hipMalloc.  (DFFT_VMM_RETIRE=0: ranges go back to the runtime, to reproduce the defect.)
+ * Addresses: on this ROCm a virtual address that is mapped a SECOND time (after hipMemAddressFree and a later reservation at the
+ * same address, or fresh chunks mapped into a kept reservation) reads and writes wrong bytes -- tools/vmm_reuse_repro.hip reproduces
+ * it without this library, with kernels and with runtime copies, in 2 - 90 map / unmap cycles (profiles/r6_vmm_reuse_repro.txt) --
+ * and a range that is unmapped but not freed keeps its physical memory (profiles/r6_vmm_cost.txt).  So dfft_free unmaps AND returns
+ * the range, and dfft_malloc reserves every range at an address it names itself and never names twice: the library walks once
+ * through [DFFT_VMM_BASE_TIB = 4 TiB, 80 TiB) of the process's address space (profiles/r6_vmm_hint.txt: 10^4 cycles, device memory
+ * level, not one wrong byte).  When that region is used up the default backing is hipMalloc.
  * dfft_last_placement_info writes what the last placement-aware allocation of the process did (a JSON object: K, candidates drawn,
  * probe / reference / threshold rates, seconds by phase, what was kept).  Free with dfft_free (which also takes pointers it did not
  * allocate: hipFree; it synchronises the owning device first, like hipFree). */

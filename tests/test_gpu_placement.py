@@ -224,9 +224,11 @@ def test_many_alloc_free_cycles_under_enqueueing_threads_stay_bit_identical(mib,
     """dfft_malloc / dfft_free of a virtual-memory buffer, `cycles` times, while eight other host threads keep enqueueing copies
     and kernels: every cycle writes a pattern through the new buffer (runtime copy in, kernel copy out) and reads it back bit for
     bit.  On this ROCm a virtual address that is mapped twice delivers wrong bytes (tools/vmm_reuse_repro.hip, standalone:
-    profiles/r6_vmm_reuse_repro.txt), so dfft_free retires address ranges for good -- no address may come back, and after the
-    thousandth free the behaviour is what it was after the first (round 5 stopped retiring at 8 TiB).  The 1 GiB form of the
-    round-5 verdict runs under -m "gpu and slow" (profiles/r6_alloc_cycles.txt)."""
+    profiles/r6_vmm_reuse_repro.txt) and a range that is kept reserved keeps its physical memory (profiles/r6_vmm_cost.txt), so
+    dfft_free returns the range and dfft_malloc reserves at addresses it never names twice: no address may come back, the device's
+    free memory must stay level, and after the thousandth free the behaviour is what it was after the first (round 5 retired
+    ranges -- leaking their memory -- up to 8 TiB and reused addresses beyond).  The 1 GiB form of the round-5 verdict runs under
+    -m "gpu and slow" (profiles/r6_alloc_cycles.txt)."""
     import threading
     stop = threading.Event()
     bad = []
@@ -249,6 +251,8 @@ def test_many_alloc_free_cycles_under_enqueueing_threads_stay_bit_identical(mib,
     src = torch.empty(n, dtype=torch.int64, device="cuda")
     sink = torch.empty_like(src)
     seen = set()
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
     try:
         for cyc in range(cycles):
             buf = dfft.DeviceBuffer.alloc(mib << 20, chunk_mib)
@@ -266,3 +270,6 @@ def test_many_alloc_free_cycles_under_enqueueing_threads_stay_bit_identical(mib,
         for t in threads:
             t.join()
     assert not bad
+    torch.cuda.synchronize()
+    leaked = free_before - torch.cuda.mem_get_info()[0]
+    assert leaked < (mib << 20) + (256 << 20), f"{leaked / 2 ** 30:.1f} GiB of device memory did not come back after {cycles} dfft_free calls"

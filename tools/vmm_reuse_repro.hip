@@ -8,6 +8,12 @@
 //                   --mode free    then hipMemAddressFree           (the runtime may hand the same address out again)
 //                   --mode keep    the reservation is kept and the NEXT cycle maps fresh physical chunks into it
 //                   --mode retire  the reservation is kept and never used again (a new range per cycle)
+//                   --mode hint    hipMemAddressFree like `free`, but every reservation asks for an address that was never used before
+//                                  (the `addr` argument of hipMemAddressReserve, advancing from --hint-base-tib): memory goes back to the
+//                                  device AND no address is mapped twice -- if the runtime honours the hint
+//                   --mode arena   one large reservation (--arena-gib), every cycle maps into the next unused part of it: no
+//                                  address is used twice and the runtime sees ONE reservation (what the library's allocator does)
+//   --report N  prints the mean seconds per cycle of every N cycles (does the cost of a cycle grow with the ranges retired so far?)
 //       [use] = the pattern of the cycle is written into a hipMalloc source by a kernel, copied source -> range -> sink with
 //               hipMemcpyAsync (--use copy, like the staging) or by kernels (--use kernel), and the sink is checked by a kernel
 //   N worker threads: each on its own stream and its own hipMalloc buffers: fill kernel, hipMemcpyAsync, check kernel, forever
@@ -53,7 +59,10 @@ struct Opt {
     std::string mode = "free", use = "copy";
     int threads = 8, pull = 0, grow = 1;
     double seconds = 20;
-    size_t mib = 64, chunk_mib = 2;
+    size_t mib = 64, chunk_mib = 2, arena_gib = 256;
+    int report = 0;
+    size_t hint_base_tib = 32;
+    int release_late = 0;      // --release-late 1: hipMemRelease of a chunk's handle AFTER its hipMemUnmap instead of right after hipMemMap
 };
 static Opt O;
 
@@ -99,6 +108,7 @@ static void worker(int id)
 
 struct CyclerResult { unsigned long long cycles = 0, reused = 0, bad = 0, first_bad_cycle = 0; };
 static CyclerResult g_res;
+static unsigned long long g_hint_missed = 0;
 
 static void cycler()
 {
@@ -124,23 +134,40 @@ static void cycler()
     std::set<void *> seen;
     void *kept = nullptr;
     size_t kept_bytes = 0;
+    char *arena = nullptr;
+    size_t arena_used = 0;
+    const size_t arena_bytes = O.arena_gib << 30;
+    if (O.mode == "arena") { void *a = nullptr; CHK(hipMemAddressReserve(&a, arena_bytes, chunk, nullptr, 0)); arena = (char *)a; }
     const double t_end = now() + O.seconds;
+    double t_rep = now();
     for (uint64_t cyc = 1; now() < t_end && !g_hip_failed; cyc++) {
+        if (O.report && cyc % O.report == 0) { const double t = now(); printf("  cycles %llu..%llu: %.3f ms per cycle\n", (unsigned long long)(cyc - O.report), (unsigned long long)cyc, (t - t_rep) / O.report * 1e3); t_rep = t; }
         // sizes grow and shrink like a staging buffer that meets a larger exchange table (grow = 0: one size)
         size_t bytes = (O.mib << 20) * (O.grow ? 1 + cyc % 2 : 1);
         bytes = (bytes + chunk - 1) / chunk * chunk;
         void *va = nullptr;
-        if (O.mode == "keep" && kept && kept_bytes >= bytes) va = kept;
+        if (O.mode == "arena") {
+            if (arena_used + bytes > arena_bytes) break;      // the arena is used up
+            va = arena + arena_used;
+            arena_used += bytes;
+        } else if (O.mode == "hint") {
+            static char *next_hint = nullptr;
+            if (!next_hint) next_hint = reinterpret_cast<char *>(O.hint_base_tib << 40);
+            CHK(hipMemAddressReserve(&va, bytes, chunk, next_hint, 0));
+            if (va != next_hint) g_hint_missed++;
+            next_hint += (bytes + ((size_t)1 << 30) - 1) >> 30 << 30;      // the next hint: a fresh GiB-aligned address
+        } else if (O.mode == "keep" && kept && kept_bytes >= bytes) va = kept;
         else {
             CHK(hipMemAddressReserve(&va, O.mode == "keep" ? max_bytes / chunk * chunk + chunk : bytes, chunk, nullptr, 0));
             if (O.mode == "keep") { kept = va; kept_bytes = max_bytes / chunk * chunk + chunk; }
         }
         if (!seen.insert(va).second) g_res.reused++;
+        std::vector<hipMemGenericAllocationHandle_t> handles;
         for (size_t off = 0; off < bytes; off += chunk) {
             hipMemGenericAllocationHandle_t h;
             CHK(hipMemCreate(&h, chunk, &prop, 0));
             CHK(hipMemMap((char *)va + off, chunk, 0, h, 0));
-            CHK(hipMemRelease(h));
+            if (O.release_late) handles.push_back(h); else CHK(hipMemRelease(h));
         }
         CHK(hipMemSetAccess(va, bytes, &acc, 1));
         const size_t n = bytes / 8;
@@ -166,7 +193,9 @@ static void cycler()
         g_res.bad = h;
         CHK(hipDeviceSynchronize());      // like dfft_free: nothing in flight anywhere may lose its mapping
         for (size_t off = 0; off < bytes; off += chunk) CHK(hipMemUnmap((char *)va + off, chunk));
-        if (O.mode == "free") CHK(hipMemAddressFree(va, bytes));
+        for (auto h : handles) CHK(hipMemRelease(h));
+        if (O.mode == "free" || O.mode == "hint") CHK(hipMemAddressFree(va, bytes));
+        if (O.report && cyc % O.report == 0) { size_t fr = 0, tot = 0; CHK(hipMemGetInfo(&fr, &tot)); printf("  after cycle %llu: %.1f GiB of %.1f free\n", (unsigned long long)cyc, fr / 1073741824.0, tot / 1073741824.0); }
         g_res.cycles = cyc;
     }
 }
@@ -179,6 +208,10 @@ int main(int argc, char **argv)
         else if (k == "--pull") O.pull = atoi(v.c_str()); else if (k == "--grow") O.grow = atoi(v.c_str());
         else if (k == "--seconds") O.seconds = atof(v.c_str()); else if (k == "--mib") O.mib = (size_t)atol(v.c_str());
         else if (k == "--chunk-mib") O.chunk_mib = (size_t)atol(v.c_str());
+        else if (k == "--arena-gib") O.arena_gib = (size_t)atol(v.c_str());
+        else if (k == "--report") O.report = atoi(v.c_str());
+        else if (k == "--release-late") O.release_late = atoi(v.c_str());
+        else if (k == "--hint-base-tib") O.hint_base_tib = (size_t)atol(v.c_str());
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
     std::vector<std::thread> th;
@@ -191,6 +224,7 @@ int main(int argc, char **argv)
            "cycler mismatches %llu (first in cycle %llu), worker iterations %llu pulls %llu mismatches %llu%s\n",
            O.mode.c_str(), O.use.c_str(), O.threads, O.pull, O.grow, O.mib, O.chunk_mib, O.seconds, g_res.cycles, g_res.reused, g_res.bad, g_res.first_bad_cycle,
            (unsigned long long)g_worker_iters, (unsigned long long)g_pulls, (unsigned long long)g_worker_bad, g_hip_failed ? "  [A HIP CALL FAILED]" : "");
+    if (O.mode == "hint") printf("   hints not honoured: %llu of %llu\n", g_hint_missed, g_res.cycles);
     if (g_hip_failed) return 2;
     return g_res.bad || g_worker_bad ? 1 : 0;
 }
