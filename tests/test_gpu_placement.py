@@ -252,7 +252,7 @@ def test_many_alloc_free_cycles_under_enqueueing_threads_stay_bit_identical(mib,
     sink = torch.empty_like(src)
     seen = set()
     torch.cuda.synchronize()
-    free_before = torch.cuda.mem_get_info()[0]
+    free_before, cached_before = torch.cuda.mem_get_info()[0], torch.cuda.memory_reserved()
     try:
         for cyc in range(cycles):
             buf = dfft.DeviceBuffer.alloc(mib << 20, chunk_mib)
@@ -271,5 +271,6 @@ def test_many_alloc_free_cycles_under_enqueueing_threads_stay_bit_identical(mib,
             t.join()
     assert not bad
     torch.cuda.synchronize()
-    leaked = free_before - torch.cuda.mem_get_info()[0]
-    assert leaked < (mib << 20) + (256 << 20), f"{leaked / 2 ** 30:.1f} GiB of device memory did not come back after {cycles} dfft_free calls"
+    # what left the device's free memory and is not in torch's caching allocator (the temporaries of this test live there)
+    leaked = (free_before - torch.cuda.mem_get_info()[0]) - (torch.cuda.memory_reserved() - cached_before)
+    assert leaked < (256 << 20), f"{leaked / 2 ** 30:.1f} GiB of device memory did not come back after {cycles} dfft_free calls"

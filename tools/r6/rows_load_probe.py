@@ -37,9 +37,23 @@ for chunks in (4, 1):
                 acc[("full", k)] = acc.get(("full", k), 0.0) + v / 10
             for k, v in part.items():
                 acc[("d=2", k)] = acc.get(("d=2", k), 0.0) + v / 10
+    import time
+    pl.enablePhaseTiming(False)
+    walls = {}
+    for name, fn in (("full inverse", lambda: pl.execC2R(back, out)), ("d = 2 inverse (rows-load y^-1 + z^-1)", lambda: pl.execC2R(back, out, 2))):
+        pl.execR2C(out, x)
+        fn(); fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        walls[name] = (time.perf_counter() - t0) / 20 * 1e3
     print(f"chunks = {pl.getPipelineChunks()}")
+    for k, v in walls.items():
+        print(f"  wall {k}: {v:.3f} ms per blocking call")
     for k, v in acc.items():
-        if v > 0 and "FFT" in k[1]:
+        if v > 0:
             print(f"  {k[0]:5s} {k[1]:12s} {v:7.3f} ms")
     del pl
     stub.destroy()
