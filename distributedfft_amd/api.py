@@ -210,13 +210,20 @@ class Comm:
 
     def counters(self):
         """what went through the transport since the communicator was made (dfft_comm_get_counter): all-to-all-v operations, native
-        point-to-point schedules (one per hop of a relayed exchange), relayed exchanges, table gathers of the relay"""
+        point-to-point schedules (one per hop of a relayed exchange), relayed exchanges, table gathers of the relay, and its one-word
+        agreements (one per exchange table and stream at first use: every rank could set up its staging)"""
         out = {}
-        for k in ("alltoallv", "list", "relayed", "relay_meta"):
+        for k in ("alltoallv", "list", "relayed", "relay_meta", "relay_agree"):
             v = C.c_long(0)
             check(lib().dfft_comm_get_counter(self._h, k.encode(), C.byref(v)))
             out[k] = v.value
         return out
+
+    def getCounter(self, name):
+        """one counter (dfft_comm_get_counter); "layered" is non-zero while the library runs a schedule as all-to-all-v layers"""
+        v = C.c_long(0)
+        check(lib().dfft_comm_get_counter(self._h, name.encode(), C.byref(v)))
+        return v.value
 
     @staticmethod
     def rccl_unique_id():

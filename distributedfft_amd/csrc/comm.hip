@@ -423,6 +423,10 @@ struct RelayMeta {
     std::vector<Piece> sendA, recvA, sendB, recvB;
     size_t staging = 0;
     bool built = false;
+    // lanes (stream, channel) on which this table's local resources -- staging for both parities, side stream, events -- exist and ALL
+    // ranks said so (relay_agree); direct = some rank could not set up: every rank sends this table directly, for good
+    std::map<std::pair<void *, int>, bool> agreed;
+    bool direct = false;
 };
 struct RelayBuf { char *p = nullptr; size_t cap = 0; bool device = false; };
 // per (stream, channel) of the exchanges that use the relay: staging (two buffers when the hops of neighbouring chunks overlap), the
@@ -548,6 +552,35 @@ static int relay_gather_meta(dfft_comm *comm, RelayCache *cache, RelayMeta &M, i
     return 0;
 }
 
+// One word per rank, all to all, blocking (once per exchange table and lane): the largest status any rank reports.  Everything that can
+// fail LOCALLY in a relayed exchange (staging, streams, events) is done before this call, so that a rank that could not set up does not
+// walk away from a collective the others are already inside (round-5 advice) -- all ranks learn it and send the table directly instead.
+static int relay_agree(dfft_comm *comm, RelayCache *cache, int myrank, bool device, hipStream_t stream, int channel, uint64_t mine, uint64_t *worst)
+{
+    const int n = comm->nranks;
+    const size_t rec = sizeof(uint64_t);
+    if (cache->msend.cap < rec * n || cache->mrecv.cap < rec * n) { dfft::set_error("relay: table buffers are missing"); return 1; }      // (reserved by the gather)
+    std::vector<uint64_t> rep(n, mine), all(n, 0);
+    std::vector<size_t> cnt(n, rec), dsp(n);
+    std::vector<int> world(n);
+    for (int y = 0; y < n; y++) { dsp[y] = (size_t)y * rec; world[y] = y; }
+    if (device) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(cache->msend.p, rep.data(), rec * n, hipMemcpyHostToDevice));
+    } else memcpy(cache->msend.p, rep.data(), rec * n);
+    comm->counters.alltoallv++;
+    comm->counters.relay_agree++;
+    if (int r = comm->alltoallv(myrank, cache->msend.p, cnt.data(), dsp.data(), cache->mrecv.p, cnt.data(), dsp.data(), world.data(), n,
+                                myrank, stream, channel)) return r;
+    if (device) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(all.data(), cache->mrecv.p, rec * n, hipMemcpyDeviceToHost));
+    } else memcpy(all.data(), cache->mrecv.p, rec * n);
+    *worst = 0;
+    for (uint64_t v : all) if (v > *worst) *worst = v;
+    return 0;
+}
+
 // this rank's pieces of both hops, from the gathered tables and its own exchange table (offsets relative to the send / receive
 // buffer of the call and to the staging buffer)
 static int relay_build(RelayMeta &M, int n, int myrank, const size_t *scount, const size_t *sdispl, const size_t *rcount, const size_t *rdispl,
@@ -631,16 +664,46 @@ int relay_alltoallv(dfft_comm *comm, RelayCache *cache, uint64_t tag, int myrank
     RelayLane &L = cache->lanes[std::make_pair((void *)stream, channel)];
     // hop 1 on a side stream, so that it overlaps hop 2 of the previous call on this lane (the previous pipeline chunk)?
     const bool overlap = device && comm->relay_overlap && comm->concurrent_hops(channel);
+    // First use of this table on this lane: everything that can fail locally, then one word of agreement.  (Receive regions of
+    // neighbouring chunks must be disjoint when a `ready` event is passed: hop 1 of chunk c + 1 fills the receive buffer after `ready`
+    // only, under hop 2 of chunk c -- true for the chunk-outermost tables of a plan.)
+    const auto lane_key = std::make_pair((void *)stream, channel);
+    if (!M.direct && !M.agreed.count(lane_key)) {
+        int local = 0;
+        auto setup = [&]() -> int {
+            // (test hook: DFFT_RELAY_TEST_FAIL_RANK makes this step fail on one rank -- tests/test_gpu_relay.py checks that every rank
+            // then sends the table directly instead of waiting for it in a collective)
+            if (const char *e = getenv("DFFT_RELAY_TEST_FAIL_RANK"))
+                if (atoi(e) == myrank) { dfft::set_error("relay: staging setup failed (injected by DFFT_RELAY_TEST_FAIL_RANK)"); return 1; }
+            for (int q = 0; q < (overlap ? 2 : 1); q++)
+                if (int r = relay_reserve(L.staging[q], M.staging, device, stream)) return r;
+            if (overlap && !L.side) {
+                HIP_TRY(hipStreamCreateWithFlags(&L.side, hipStreamNonBlocking));
+                for (hipEvent_t *e : {&L.in, &L.hop1, &L.hop2[0], &L.hop2[1]}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+            }
+            return 0;
+        };
+        local = setup() != 0;
+        std::string local_why;
+        if (local) { local_why = dfft_last_error(); (void)hipGetLastError(); }
+        uint64_t worst = 0;
+        if (int r = relay_agree(comm, cache, myrank, device, stream, channel, (uint64_t)local, &worst)) return r;
+        if (worst) {
+            M.direct = true;
+            fprintf(stderr, "[dfft] relay: rank %d: %s -- this exchange table is sent directly on every rank\n", myrank,
+                    local ? ("local setup failed (" + local_why + ")").c_str() : "another rank could not set up its staging");
+        } else M.agreed[lane_key] = true;
+    }
+    if (M.direct) {
+        comm->counters.alltoallv++;
+        return comm->alltoallv(myrank, send, scount, sdispl, recv, rcount, rdispl, group, ngroup, me, stream, channel);
+    }
     const int par = overlap ? L.parity : 0;
     if (overlap) L.parity ^= 1;
     RelayBuf &st = L.staging[par];
-    if (int r = relay_reserve(st, M.staging, device, stream)) return r;
+    if (st.cap < M.staging) { set_error("relay: staging smaller than the agreed size"); return 1; }      // (cannot happen: reserved above)
     hipStream_t s1 = stream;
     if (overlap) {
-        if (!L.side) {
-            HIP_TRY(hipStreamCreateWithFlags(&L.side, hipStreamNonBlocking));
-            for (hipEvent_t *e : {&L.in, &L.hop1, &L.hop2[0], &L.hop2[1]}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
-        }
         s1 = L.side;
         // hop 1 of this call writes the staging buffer that hop 2 of the call before the previous one read
         if (L.hop2_used[par]) HIP_TRY(hipStreamWaitEvent(s1, L.hop2[par], 0));
@@ -721,8 +784,11 @@ int dfft_comm::sendrecv_list(int myrank, const dfft_xfer *sends, int ns, const d
             }
         static const char none = 0;
         counters.alltoallv++;
-        if (int r = alltoallv(myrank, smin ? smin : &none, sc.data(), sd.data(), rmin ? const_cast<char *>(rmin) : const_cast<char *>(&none), rc.data(),
-                              rd.data(), world.data(), n, myrank, stream, channel)) return r;
+        counters.layered++;
+        const int r = alltoallv(myrank, smin ? smin : &none, sc.data(), sd.data(), rmin ? const_cast<char *>(rmin) : const_cast<char *>(&none), rc.data(),
+                                rd.data(), world.data(), n, myrank, stream, channel);
+        counters.layered--;
+        if (r) return r;
     }
     return 0;
 }

@@ -60,7 +60,10 @@ struct dfft_comm {
     int test_channel = 0;      // the channel of the bare transport calls of the C ABI (dfft_comm_alltoallv, dfft_comm_sendrecv_list)
     // what went through the transport since the communicator was made (dfft_comm_get_counter): calls of alltoallv / sendrecv_list
     // made by plans and by the relay, and relayed exchanges
-    struct Counters { std::atomic<long> alltoallv{0}, list{0}, relayed{0}, relay_meta{0}; } counters;
+    struct Counters { std::atomic<long> alltoallv{0}, list{0}, relayed{0}, relay_meta{0}, relay_agree{0};
+                      // > 0 while sendrecv_list's default runs a schedule as all-to-all-v layers: the pieces of such a call lie in
+                      // unrelated allocations ("layered" tells a callback transport not to look for back-to-back blocks)
+                      std::atomic<long> layered{0}; } counters;
 };
 
 namespace dfft {

@@ -1572,7 +1572,9 @@ int dfft_comm_get_counter(const dfft_comm *comm, const char *name, long *value)
     else if (k == "list") *value = comm->counters.list;
     else if (k == "relayed") *value = comm->counters.relayed;
     else if (k == "relay_meta") *value = comm->counters.relay_meta;
-    else return fail(ERR_ARG, "unknown counter " + k + " (alltoallv, list, relayed, relay_meta)");
+    else if (k == "layered") *value = comm->counters.layered;
+    else if (k == "relay_agree") *value = comm->counters.relay_agree;
+    else return fail(ERR_ARG, "unknown counter " + k + " (alltoallv, list, relayed, relay_meta, relay_agree, layered)");
     return 0;
 }
 int dfft_comm_set_option(dfft_comm *comm, const char *key, long value)

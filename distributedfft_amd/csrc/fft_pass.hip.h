@@ -1226,6 +1226,9 @@ __global__ __launch_bounds__(Cfg::THREADS, ONEPLANE == 2 && is_pow2(Cfg::kN) ? 4
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     R *lds = reinterpret_cast<R *>(smem);
     const int tid = threadIdx.x;
+    // (MAP == 3 -- point fastest after the first pass only on the store side, PassCfg::PF_FIRST / PF_REST -- is a form of
+    // fft_pass_kernel; the spans and uniform-table paths of the real kernels assume the mappings below)
+    static_assert(Cfg::kMAP != 3, "the real z passes support the thread mappings 0, 1 and 2");
     constexpr bool PF_FIRST = Cfg::kMAP == 1, PF_REST = Cfg::kMAP != 0;
     int lw, t, lw2, t2;
     thread_map<Cfg, PF_FIRST>(tid, lw, t);      // coordinates of the load and the first pass
@@ -1396,6 +1399,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     R *lds = reinterpret_cast<R *>(smem);
     const int tid = threadIdx.x;
+    static_assert(Cfg::kMAP != 3, "the real z passes support the thread mappings 0, 1 and 2");
     constexpr bool PF_FIRST = Cfg::kMAP == 1, PF_REST = Cfg::kMAP != 0 && Cfg::NPASS > 1 ? true : Cfg::kMAP == 1;
     int lw, t, lw2, t2;
     thread_map<Cfg, PF_FIRST>(tid, lw, t);
@@ -1435,7 +1439,9 @@ __global__ __launch_bounds__(Cfg::THREADS) void fft_c2r_kernel(const PassArgs A)
                 constexpr int c = decltype(cc)::value;
                 constexpr int i = c % S1, m = c / S1;
                 const int k = pair_j<Cfg, R1, i>(t) + m * LEG;
-                const int kf = pair_j<Cfg, R1, i>(t0) + m * LEG, kl = pair_j<Cfg, R1, i>(t0 + SPAN - 1) + m * LEG;
+                // (the wave's last t: clamped to the line's last thread -- a workgroup smaller than a wave, round-5 advice)
+                const int tl = t0 + SPAN - 1 < NT ? t0 + SPAN - 1 : NT - 1;
+                const int kf = pair_j<Cfg, R1, i>(t0) + m * LEG, kl = pair_j<Cfg, R1, i>(tl) + m * LEG;
                 const bool linear = i < H || t0 != 0;
                 x[c] = stream_load<Cfg>(in + tiled_load_offset_wave<TL>(A, tc, (uint32_t)k, (uint32_t)kf, (uint32_t)kl, linear));
             });

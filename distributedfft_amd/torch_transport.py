@@ -52,6 +52,9 @@ class TorchComm:
         self.p2p_calls = 0
         self.list_calls = 0
 
+    def _device(self):
+        return self.buffers[0].device if self.buffers else torch.device("cpu")
+
     def register(self, tensor):
         """make a tensor's storage known to the pointer -> tensor lookup"""
         self.buffers.append(tensor.reshape(-1).view(torch.uint8))
@@ -129,15 +132,22 @@ class TorchComm:
         self.list_calls += 1
 
     def _alltoallv(self, send, sc, sd, recv, rc, rd, group, me, stream):
-        # one all_to_all_single when the peer blocks lie back to back in rank order (every exchange table of a plan: on every rank, so
-        # that all members take the same path -- an empty block is back to back with anything; zero splits are fine)
-        nzs, nzr = [q for q in range(len(group)) if sc[q]], [q for q in range(len(group)) if rc[q]]
-        packed = all(sd[b] == sd[a] + sc[a] for a, b in zip(nzs, nzs[1:])) and all(rd[b] == rd[a] + rc[a] for a, b in zip(nzr, nzr[1:]))
-        packed = packed and all(c % 8 == 0 for c in sc + rc)
-        if packed:      # peer blocks back to back in rank order: one all_to_all_single
+        # Which collective: decided by WHAT the library is doing, which is the same on every rank of the group -- never by this
+        # rank's tables alone (round-5 advice: ranks that choose differently hang).  A plan's exchange has its peer blocks back to
+        # back in rank order on every rank by construction: one all_to_all_single.  The layers of a relay schedule run through the
+        # default sendrecv_list (counter "layered" > 0 while it does) are pieces in unrelated allocations: one send / receive per peer.
+        layered = self.comm.getCounter("layered") > 0
+        packed = not layered
+        if packed:
+            nzs, nzr = [q for q in range(len(group)) if sc[q]], [q for q in range(len(group)) if rc[q]]
+            ok = all(sd[b] == sd[a] + sc[a] for a, b in zip(nzs, nzs[1:])) and all(rd[b] == rd[a] + rc[a] for a, b in zip(nzr, nzr[1:]))
+            if not (ok and all(c % 8 == 0 for c in sc + rc)):
+                raise RuntimeError("exchange table with peer blocks that are not back to back in rank order (or not multiples of 8 bytes): "
+                                   f"counts {sc} / {rc}, displacements {sd} / {rd}")
             first_s, first_r = (nzs or [0])[0], (nzr or [0])[0]
-            s = self._slice(send + sd[first_s], sum(sc)).view(torch.int64)
-            r = self._slice(recv + rd[first_r], sum(rc)).view(torch.int64)
+            # (a rank with nothing to send or receive still takes part, with an empty tensor)
+            s = self._slice(send + sd[first_s], sum(sc)).view(torch.int64) if sum(sc) else torch.empty(0, dtype=torch.int64, device=self._device())
+            r = self._slice(recv + rd[first_r], sum(rc)).view(torch.int64) if sum(rc) else torch.empty(0, dtype=torch.int64, device=self._device())
         on_device = bool(self.buffers and self.buffers[0].is_cuda)
 
         def run():

@@ -165,13 +165,16 @@ def main():
     cnt = tc.comm.counters()
     nrel = (1 if l2 else 0) + (2 if l1 else 0)
     assert cnt["relayed"] == nrel and cnt["relay_meta"] == nrel, cnt
+    # ... and one one-word agreement per relayed table at its first use (every rank could set up its staging: comm.hip relay_agree)
+    agree = cnt["relay_agree"]
+    assert agree == nrel, cnt
     if not layered:
-        assert tc.calls == c2 + 2 * c1 and tc.p2p_calls == 0 and tc.list_calls == l2 + 2 * l1, (tc.calls, tc.p2p_calls, tc.list_calls, c2, c1, l2, l1)
+        assert tc.calls == c2 + 2 * c1 + agree and tc.p2p_calls == 0 and tc.list_calls == l2 + 2 * l1, (tc.calls, tc.p2p_calls, tc.list_calls, c2, c1, l2, l1)
         assert cnt["list"] == 2 * nrel and cnt["alltoallv"] == tc.calls, (cnt, tc.calls)
     else:
         # every hop of a relayed exchange is group - 1 all-to-all-v layers whose pieces are not back to back (the transport's per-peer path)
         layers = (2 * (P1 - 1) if l2 else 0) + (2 * 2 * (P2 - 1) if l1 else 0)
-        assert cnt["list"] == 0 and tc.list_calls == 0 and cnt["alltoallv"] == tc.calls == c2 + 2 * c1 + layers, (cnt, tc.calls, layers)
+        assert cnt["list"] == 0 and tc.list_calls == 0 and cnt["alltoallv"] == tc.calls == c2 + 2 * c1 + agree + layers, (cnt, tc.calls, layers)
         assert tc.p2p_calls == layers, (tc.p2p_calls, layers)
     dist.barrier()
     dist.destroy_process_group()

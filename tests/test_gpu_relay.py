@@ -79,8 +79,9 @@ def test_relay_is_two_grouped_operations_per_exchange_and_chunk(overlap):
     cnt = plans_r[0].comm.counters()      # one communicator, shared by the 8 virtual ranks
     per_rank = 2 * 2 * chunks             # (exchange 1 + exchange 2) x (forward + inverse) x chunks
     assert cnt["relayed"] == 8 * per_rank and cnt["list"] == 2 * cnt["relayed"], cnt
-    assert cnt["relay_meta"] == 8 * per_rank and cnt["alltoallv"] == cnt["relay_meta"], cnt
-    assert plans[0].comm.counters() == {"alltoallv": 8 * per_rank, "list": 0, "relayed": 0, "relay_meta": 0}
+    # per table at its first use: one gather and one one-word agreement (every rank could set up its staging), both all-to-all-v
+    assert cnt["relay_meta"] == 8 * per_rank and cnt["relay_agree"] == cnt["relay_meta"] and cnt["alltoallv"] == 2 * cnt["relay_meta"], cnt
+    assert plans[0].comm.counters() == {"alltoallv": 8 * per_rank, "list": 0, "relayed": 0, "relay_meta": 0, "relay_agree": 0}
     # a second transform gathers nothing again
     from concurrent.futures import ThreadPoolExecutor
     outs = [torch.zeros(pl.getDomainSize() // 16, dtype=torch.complex128, device="cuda") for pl in plans_r]
@@ -89,7 +90,7 @@ def test_relay_is_two_grouped_operations_per_exchange_and_chunk(overlap):
         list(ex.map(lambda r: plans_r[r].execC2C(outs[r], tin[r], dfft.FORWARD), range(8)))
     torch.cuda.synchronize()
     cnt2 = plans_r[0].comm.counters()
-    assert cnt2["relay_meta"] == cnt["relay_meta"] and cnt2["list"] == cnt["list"] + 8 * 2 * 2 * chunks, (cnt, cnt2)
+    assert cnt2["relay_meta"] == cnt["relay_meta"] and cnt2["relay_agree"] == cnt["relay_agree"] and cnt2["list"] == cnt["list"] + 8 * 2 * 2 * chunks, (cnt, cnt2)
     for r, pl in enumerate(plans_r):
         s = pl.getOutSize()
         assert np.array_equal(outs[r][:s[0] * s[1] * s[2]].cpu().numpy().reshape(s), spec_d[r])
@@ -119,3 +120,18 @@ def test_relay_repeated_runs_stay_bit_identical():
         for r in range(P1 * P2):
             assert np.array_equal(spec_d[r], spec_r[r]), (rep, r)
             assert np.array_equal(backs_d[r], backs_r[r]), (rep, r)
+
+
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_a_rank_that_cannot_set_up_its_staging_makes_every_rank_send_directly(monkeypatch, overlap):
+    """everything that can fail locally in a relayed exchange (staging, side stream, events) happens at the first use of an exchange
+    table, followed by one word of agreement; a failure on ONE rank (injected) turns the table into a direct exchange on EVERY rank
+    instead of leaving the others inside a collective (round-5 advice).  Same bytes, no relayed exchange counted."""
+    shape, P1, P2, chunks = (66, 50, 38), 2, 4, 3
+    _, _, spec_d, backs_d = run_distributed(shape, P1, P2, "double", chunks=chunks)
+    monkeypatch.setenv("DFFT_RELAY_TEST_FAIL_RANK", "5")
+    plans_r, _, spec_r, backs_r = run_distributed(shape, P1, P2, "double", chunks=chunks, comm_options={"relay": 3, "relay_overlap": overlap})
+    for r in range(P1 * P2):
+        assert np.array_equal(spec_d[r], spec_r[r]) and np.array_equal(backs_d[r], backs_r[r])
+    cnt = plans_r[0].comm.counters()
+    assert cnt["relayed"] == 0 and cnt["list"] == 0 and cnt["relay_agree"] == cnt["relay_meta"] > 0, cnt

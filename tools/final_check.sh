@@ -3,14 +3,14 @@
 #   gpurun --timeout 2400 -- 'bash tools/final_check.sh r4'
 # full GPU parity suite, the default bench line, the same line under rocprofv3 --kernel-trace --stats, and the PMC traffic of the
 # library as it is (FETCH_SIZE / WRITE_SIZE in separate passes; the json records the library's sha256, bench.py refuses another's).
-TAG=${1:-r5}
+TAG=${1:-r6}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/final_check
 mkdir -p $OUT
 cd $R
 export TMPDIR=/tmp
 K=$R/tools/kbench
-sha256sum distributedfft_amd/libdfft_amd.so > $OUT/${TAG}_library_sha256.txt
+sha256sum distributedfft_amd/libdfft_amd.so distributedfft_amd/libdfft_amd_any.so > $OUT/${TAG}_library_sha256.txt
 # PMC first: bench.py then finds a profile of THIS library (profiles/ is where it looks: the files are copied there by hand afterwards;
 # for this call they are also put where bench.py reads them)
 bash tools/pmc_traffic.sh ${TAG}_f64_1024 -- $K --size 1024 --prec f64 --iters 2 > /dev/null 2>&1
@@ -32,7 +32,10 @@ for f in ("${TAG}_pmc_traffic.json", "${TAG}_pmc_traffic_f32_2048.json", "${TAG}
 PY
 # SUITE=full (default): the whole GPU suite; SUITE=<pytest -k expression>: only the tests that expression selects (a late change of one subsystem)
 if [ "${SUITE:-full}" = "full" ]; then
-  timeout 1500 python -m pytest tests -x -q -m gpu --durations=40 > $OUT/${TAG}_pytest_gpu.txt 2>&1; tail -22 $OUT/${TAG}_pytest_gpu.txt
+  rm -f $OUT/${TAG}_parity_table.txt
+  ( export DFFT_PARITY_TABLE=$OUT/${TAG}_parity_table.txt; timeout 1500 python -m pytest tests -x -q -m gpu --durations=40 ) > $OUT/${TAG}_pytest_gpu.txt 2>&1; tail -22 $OUT/${TAG}_pytest_gpu.txt
+  # the part of the thinned parametrisation that the default run leaves out (tests/conftest.py)
+  timeout 600 python -m pytest tests -q -m "gpu and slow" --durations=5 > $OUT/${TAG}_pytest_gpu_slow.txt 2>&1; tail -4 $OUT/${TAG}_pytest_gpu_slow.txt
 else
   timeout 900 python -m pytest tests -x -q -m gpu -k "$SUITE" --durations=10 > $OUT/${TAG}_pytest_gpu_subset.txt 2>&1; tail -14 $OUT/${TAG}_pytest_gpu_subset.txt
 fi
