@@ -425,6 +425,11 @@ def main():
                         print(f"[bench] dup_channel unavailable: {e}", file=sys.stderr, flush=True)
         kind = dfft.MPIcuFFT_Slab_Opt1 if P2 == 1 and ngpus > 1 else dfft.MPIcuFFT_Pencil_Opt1
         plan = kind(dfft.Configurations(), comm, precision=prec, rank=rank)
+        # The chunks of a pass on ONE compute stream: the timed region prices the axis-pass kernel by its own launches (roofline:
+        # algorithmic bytes / average launch duration, from events around each launch), which only means something for launches that
+        # own the device; the library's default from three chunks on is two streams (chunk c + 1 ramps under the drain of chunk c:
+        # 2-3 % of the per-GPU kernel time, config.per_gpu_kernels_8gpu reports it as step_ms against step_ms_one_stream).
+        plan.setOption("compute_streams", 1)
         for k, v in (options or {}).items():
             plan.setOption(k, v)
         plan.initFFT(dfft.GlobalSize(N, N, N), dfft.Partition(P1, P2), allocate=False, c2c=True)

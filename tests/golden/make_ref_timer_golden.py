@@ -1,4 +1,4 @@
-"""Generates tests/golden/ref_timer_*.csv: the CSV bytes written by the REFERENCE's own Timer (src/timer.cpp, built unmodified
+"""Generates tests/golden/ref_timer_*.csv and tests/golden/ref_params_probe.txt: the CSV bytes written by the REFERENCE's own Timer (src/timer.cpp, built unmodified
 into oracle/_ref/ by `make -C oracle _ref`) for fixed durations (oracle/timer_probe.cpp).  Run in the build container, where
 /root/reference exists; the fixtures are data (the reference's OUTPUT), and tests/test_ref_timer.py compares
 include/timer_amd.hpp with them wherever oracle/_ref did not travel."""
@@ -37,3 +37,7 @@ if __name__ == "__main__":
             name = os.path.join(ROOT, "tests", "golden", "ref_timer_%d_%d_%d_%d.csv" % case)
             open(name, "wb").write(data)
             print(name, len(data), "bytes")
+        # the parameter structs: what a program compiled against the reference's include/params.hpp prints (oracle/params_probe.cpp)
+        out = subprocess.check_output([os.path.join(ROOT, "oracle", "_ref", "params_probe_ref")])
+        open(os.path.join(ROOT, "tests", "golden", "ref_params_probe.txt"), "wb").write(out)
+        print("ref_params_probe.txt", len(out), "bytes")
