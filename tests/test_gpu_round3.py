@@ -235,16 +235,18 @@ def test_c5_2048_fp32_separable_input_every_point_single_gpu():
 
 
 @pytest.mark.baseline_config
-def test_c5_2048_fp32_pencil_2x4_rank0_at_real_size_every_point():
-    """BASELINE C5 itself -- 2048^3 fp32 complex on the 2 x 4 pencil grid -- at its REAL size, as far as one GPU goes (round-5
-    verdict, item 8): eight virtual ranks of 40 GiB each do not fit 288 GB at once, so the ranks run ONE AFTER THE OTHER on one
-    shared set of buffers (in 8 + out 8 + work area 24 GiB) behind a callback transport that keeps what a rank sends to the rank
-    under test and feeds it back when that rank's exchange asks for it:
-        ranks 5, 6, 7 (z pass)  -> their exchange-1 messages to rank 4          ranks 1, 2, 3 (z pass) -> theirs to rank 0
-        rank 4 (z, exchange 1 fed, y) -> its exchange-2 message to rank 0      rank 0: both exchanges fed, all three passes
-    Every message is produced by the sending rank's own plan at its real size (per pipeline chunk, with the plan's own counts
-    and displacements, which are asserted to agree at both ends); rank 0's spectrum block [2048][1024][512] is compared at EVERY
-    point with the outer product of three oracle transforms (the separable input of the single-GPU test above)."""
+def test_c5_2048_fp32_pencil_2x4_every_rank_at_real_size_every_point():
+    """BASELINE C5 itself -- 2048^3 fp32 complex on the 2 x 4 pencil grid -- at its REAL size on one GPU (round-5 verdict, item 8):
+    eight virtual ranks of 40 GiB each do not fit 288 GB at once, so the ranks run ONE AFTER THE OTHER on one shared set of buffers
+    (in 8 + out 8 + work area 24 GiB) behind a callback transport that keeps what a rank sends to the rank under test and feeds it
+    back when that rank's exchange asks for it.  For the rank under test T = (i, j) and its column partner P = (1 - i, j):
+        P's row peers (z pass) -> their exchange-1 messages to P          T's row peers (z pass) -> theirs to T
+        P (z, exchange 1 fed, y) -> its exchange-2 message to T           T: both exchanges fed, all three passes
+    i.e. all eight ranks run once per rank under test, and EVERY rank is the rank under test in turn.  Every message is produced by
+    the sending rank's own plan at its real size (per pipeline chunk, with the plan's own counts and displacements, which are asserted
+    to agree at both ends); each rank's spectrum block [2048][1024][512] is compared at EVERY point with the outer product of three
+    oracle transforms (the separable input of the single-GPU test above): all 2^33 entries of the C5 spectrum, from the plans that
+    an 8-GPU run would execute."""
     N, P1, P2 = 2048, 2, 4
     n = N ** 3
     if gpu_free_gib() < 70:
@@ -309,35 +311,44 @@ def test_c5_2048_fp32_pencil_2x4_rank0_at_real_size_every_point():
             pl.execC2C(d_out, d_in, dfft.FORWARD)
         torch.cuda.synchronize()
 
-    for r in (5, 6, 7):
-        run(r, 4)
-    for r in (1, 2, 3):
-        run(r, 0)
-    feeding.add((4, 1))        # (rank 4's exchange 2 receives from rank 0, which has not run: its x pass works on whatever is there)
-    run(4, 0)
-    assert not [k for k in held if k[1] == 4], "rank 4 did not consume every message it was sent"
-    feeding.update({(0, 1), (0, 2)})
-    run(0, -1)
-    assert not held, f"messages left over: {sorted(held)[:4]}"
-    assert calls[(0, 1)] == calls[(0, 2)] == plans[0].getPipelineChunks() - 1
-    osz, ost = plans[0].getOutSize(), plans[0].getOutStart()
-    spec = d_out[:osz[0] * osz[1] * osz[2]].reshape(osz)
-    Gb, Hb = G[ost[1]:ost[1] + osz[1]], H[ost[2]:ost[2] + osz[2]]
-    worst = torch.zeros((), dtype=torch.float64, device="cuda")
-    worst_abs = torch.zeros((), dtype=torch.float64, device="cuda")
-    step = 64
-    for i in range(0, N, step):
-        want = (F[i:i + step, None, None] * Gb[None, :, None]) * Hb[None, None, :]
-        err = (spec[i:i + step].to(torch.complex128) - want).abs()
-        worst_abs = torch.maximum(worst_abs, err.max())
-        worst = torch.maximum(worst, (err / want.abs().clamp_(min=spec_rms)).max())
-        del want, err
     peak = float(np.prod([np.max(np.abs(v)) for v in spec1d]))
     bound = 3 * forward_bound("float", n)           # separable input: see the single-GPU test above
-    record("C5 2048^3 fp32 pencil 2x4, rank 0 at real size (peers' messages from their own plans), every point", "float", n,
-           float(worst), bound, float(worst_abs) / peak)
-    assert float(worst_abs) / peak < 1e-4
-    assert float(worst) <= bound, float(worst)
+    chunks = plans[0].getPipelineChunks()
+    for target in range(P1 * P2):
+        # the rank under test, its column partner (the source of its exchange-2 message) and the row peers of both
+        ti, tj = target // P2, target % P2
+        partner = (1 - ti) * P2 + tj
+        held.clear(); calls.clear(); feeding.clear()
+        for r in range(P1 * P2):
+            if r // P2 == partner // P2 and r != partner:
+                run(r, partner)                       # z pass -> exchange-1 message to the partner
+        for r in range(P1 * P2):
+            if r // P2 == ti and r != target:
+                run(r, target)                        # z pass -> exchange-1 message to the rank under test
+        feeding.add((partner, 1))     # (the partner's exchange 2 receives from the rank under test, which has not run: its x pass works on whatever is there)
+        run(partner, target)                          # z, exchange 1 fed, y -> exchange-2 message to the rank under test
+        assert not [k for k in held if k[1] == partner], f"rank {partner} did not consume every message it was sent"
+        feeding.update({(target, 1), (target, 2)})
+        run(target, -1)
+        assert not held, f"messages left over: {sorted(held)[:4]}"
+        assert calls[(target, 1)] == calls[(target, 2)] == chunks - 1
+        osz, ost = plans[target].getOutSize(), plans[target].getOutStart()
+        assert osz == (2048, 1024, 512) and ost == (0, 1024 * ti, 512 * tj)
+        spec = d_out[:osz[0] * osz[1] * osz[2]].reshape(osz)
+        Gb, Hb = G[ost[1]:ost[1] + osz[1]], H[ost[2]:ost[2] + osz[2]]
+        worst = torch.zeros((), dtype=torch.float64, device="cuda")
+        worst_abs = torch.zeros((), dtype=torch.float64, device="cuda")
+        step = 64
+        for i in range(0, N, step):
+            want = (F[i:i + step, None, None] * Gb[None, :, None]) * Hb[None, None, :]
+            err = (spec[i:i + step].to(torch.complex128) - want).abs()
+            worst_abs = torch.maximum(worst_abs, err.max())
+            worst = torch.maximum(worst, (err / want.abs().clamp_(min=spec_rms)).max())
+            del want, err
+        record(f"C5 2048^3 fp32 pencil 2x4, rank {target} at real size (peers' messages from their own plans), every point", "float", n,
+               float(worst), bound, float(worst_abs) / peak)
+        assert float(worst_abs) / peak < 1e-4, (target, float(worst_abs) / peak)
+        assert float(worst) <= bound, (target, float(worst))
     for r in plans:
         plans[r] = None
     for c in comms.values():
