@@ -71,8 +71,14 @@ int main(int argc, char *argv[])
         p.comm_method2 = comm_method_named(arg_value(argc, argv, "--comm-method2", "-comm2"));
         p.send_method1 = send_method_named(arg_value(argc, argv, "--send-method1", "-snd1"));
         p.send_method2 = send_method_named(arg_value(argc, argv, "--send-method2", "-snd2"));
-        World w(p.cuda_aware);
         const int need = (int)(p.P1 * p.P2) + (p.testcase == 1 ? 1 : 0);
+        if (getenv("DFFT_DRIVER_PARSE_ONLY")) {      // what the command line means, before MPI or the GPU are touched (tests/test_launch_commands.py)
+            printf("PARSED pencil nx=%zu ny=%zu nz=%zu p1=%zu p2=%zu t=%d o=%d runs=%d w=%d c=%d d=%d f=%d comm1=%d snd1=%d comm2=%d snd2=%d b=%s ranks=%d\n",
+                   p.Nx, p.Ny, p.Nz, p.P1, p.P2, p.testcase, p.opt, p.iterations, p.warmup_rounds, (int)p.cuda_aware, (int)p.double_prec, p.fft_dim,
+                   (int)p.comm_method1, (int)p.send_method1, (int)p.comm_method2, (int)p.send_method2, p.benchmark_dir.c_str(), need);
+            return 0;
+        }
+        World w(p.cuda_aware);
         if (w.size != need) throw std::runtime_error("P1*P2 (+1 for testcase 1) must equal the number of MPI ranks.");
         return p.double_prec ? run<double>(p, w) : run<float>(p, w);
     } catch (std::runtime_error &e) {

@@ -70,6 +70,12 @@ int main(int argc, char *argv[])
         if (!p.sequence.empty() && p.sequence != "ZY_Then_X" && p.sequence != "Z_Then_YX" && p.sequence != "Y_Then_ZX") throw std::runtime_error("Invalid sequence.");
         p.comm_method = comm_method_named(arg_value(argc, argv, "--comm-method", "-comm"));
         p.send_method = send_method_named(arg_value(argc, argv, "--send-method", "-snd"));
+        if (getenv("DFFT_DRIVER_PARSE_ONLY")) {      // what the command line means, before MPI or the GPU are touched (tests/test_launch_commands.py)
+            printf("PARSED slab nx=%zu ny=%zu nz=%zu s=%s t=%d o=%d runs=%d w=%d c=%d d=%d comm=%d snd=%d b=%s\n", p.Nx, p.Ny, p.Nz,
+                   p.sequence.empty() ? "ZY_Then_X" : p.sequence.c_str(), p.testcase, p.opt, p.iterations, p.warmup_rounds, (int)p.cuda_aware,
+                   (int)p.double_prec, (int)p.comm_method, (int)p.send_method, p.benchmark_dir.c_str());
+            return 0;
+        }
         World w(p.cuda_aware);
         return p.double_prec ? run<double>(p, w) : run<float>(p, w);
     } catch (std::runtime_error &e) {
