@@ -14,6 +14,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MPIEXEC = "/opt/conda/bin/mpiexec"
 MPI_LIB = "/opt/conda/lib/libmpi.so.12"
 
+# section labels and file-name shapes of the 25 000 timer CSV files the reference ships under benchmarks/ (written by its own Timer and
+# classes; extracted by tests/golden/make_ref_csv_shapes.py): one ordered label list per directory kind
+import json  # noqa: E402
+REF_SHAPES = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_benchmark_csv_shapes.json")))
+
+
+def assert_reference_shape(kind, path, blocks):
+    ref = REF_SHAPES[kind]
+    assert len(ref["label_lists"]) == 1 and ref["files_with_the_rank_header_row"] == ref["files"]
+    for b in blocks:
+        assert list(b) == ref["label_lists"][0]["labels"], (kind, list(b))
+    assert str(len(os.path.basename(str(path))[:-4].split("_"))) in ref["fields_in_the_file_name"], path
+
+
 needs_mpich = pytest.mark.skipif(not (os.path.exists(MPI_LIB) and os.path.exists(MPIEXEC)), reason="MPICH from the image is not present")
 
 
@@ -82,6 +96,7 @@ def test_pencil_round_trip_and_timer_csv(drivers, tmp_path, opt, P1, P2, prec):
     assert max(mx) < tol and max(avg) < tol
     name = f"test_{opt}_0_0_0_0_{n}_{n}_{n}_0_{P1}_{P2}.csv"      # Peer2Peer = 0, Sync = 0, cuda_aware = 0
     blocks = read_csv(tmp_path / "pencil" / name, P1 * P2)
+    assert_reference_shape("pencil", name, blocks)
     # one block per exec* once the warm-up counter is used up.  The reference's classes count execR2C and execC2R on ONE counter
     # (src/pencil/mpicufft_pencil_opt1.cpp:1515-1518, 1596-1599): -w 1 skips the first execR2C only
     assert len(blocks) == 2 * (iters + warm) - warm
@@ -136,6 +151,8 @@ def test_slab_sequences(drivers, tmp_path, seq, opt, tc, sub):
         assert len(sums) == 2 and all(s < 1e-9 * 255 * n ** 6 / 2 for s in sums)
     path = tmp_path / sub / f"test_{opt}_0_0_{n}_{n}_{n}_0_{P}.csv"
     blocks = read_csv(path, P)
+    if sub in REF_SHAPES:      # (the reference ships no slab_y_then_zx files)
+        assert_reference_shape(sub, path, blocks)
     assert len(blocks) == (4 if tc in (3, 4) else 2)
     last = {"slab_default": "1D FFT X-Direction", "slab_z_then_yx": "2D FFT Y-X-Direction", "slab_y_then_zx": "2D FFT Z-X-Direction"}[sub]
     assert all(v > 0 for v in blocks[0][last]) and all(v > 0 for v in blocks[0]["Run complete"])
