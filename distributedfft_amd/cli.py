@@ -182,8 +182,12 @@ class Rank:
         k1 = wrapped(t.arange(Nx, device="cuda"), Nx).reshape(-1, 1, 1)
         k2 = wrapped(t.arange(self.ost[1], self.ost[1] + self.osz[1], device="cuda"), Ny).reshape(1, -1, 1)
         k3 = wrapped(t.arange(self.ost[2], self.ost[2] + self.osz[2], device="cuda"), Nz, half=not self.args.complex).reshape(1, 1, -1)
-        scale = -(k1 ** 2 + k2 ** 2 + k3 ** 2) / math.sqrt(float(Nx) * Ny * Nz)
-        blk.mul_(scale.to(blk.real.dtype))
+        # the reference's arithmetic: x * scale / sqrtf(Nx*Ny*Nz) -- a SINGLE-precision root of the int product (:117-118); it is why
+        # its own runs print 1.91723e-05 at 128^3 (tests/golden/ref_testcase4_results.json)
+        root = float(t.sqrt(t.tensor(float(Nx * Ny * Nz), dtype=t.float32)))
+        scale = -(k1 ** 2 + k2 ** 2 + k3 ** 2)
+        rd = blk.real.dtype
+        t.view_as_real(blk).copy_((t.view_as_real(blk).to(t.float64) * scale.unsqueeze(-1) / root).to(rd))
 
 
 class _Timings:      # what write_csv needs of a rank (the rank objects themselves, or what other processes sent to rank 0)

@@ -11,13 +11,24 @@
  * *published contract* instead: unnormalised DFT, forward kernel exp(-2*pi*i*j*k/N), inverse
  * exp(+...), R2C keeps k = 0..N/2 of the last axis (include/params.hpp:30).
  *
- * PARITY PINNING STATUS.  The reference ships no golden vectors and seeds its inputs with
- * clock() (tests/src/pencil/base.cu:49), so bit patterns against cuFFT are UNPINNED.  The
- * oracle is pinned instead by (a) a long-double O(N^2) DFT for every 1-D length used in
- * tests, (b) numpy.fft (pocketfft, independent implementation) on 3-D grids, and (c) the
- * three properties the reference's own tests check at this boundary: testcase 3 round trip
- * (tests/src/pencil/random_dist_3D.cu:641-666), testcase 4 analytic Laplacian (:73-121,
- * :748-793) and testcase 1 distributed == single device (:386-403).  See tests/test_oracle.py.
+ * PARITY PINNING STATUS.  PINNED against outputs of the reference itself, as far as the reference holds any (round 6):
+ *   (1) KNOWN ANSWERS THE REFERENCE PRODUCED: testcase 4 has a deterministic input (u = sin sin sin,
+ *       tests/src/pencil/random_dist_3D.cu:748-762), and the reference ships the logs of its own runs (benchmarks/argon and
+ *       benchmarks/pcsgs: `Result (avg)` / `Result (max)` per grid, decomposition and option, double precision, 4 ranks, cuFFT +
+ *       its kernels).  tests/golden/ref_testcase4_results.json holds them; this file's decomposed R2C -> derivativeCoefficients
+ *       (the reference's arithmetic to the letter, single-precision root included) -> decomposed C2R prints the same average in
+ *       all six digits (1.91723e-05 at 128^3) and a maximum inside the logs' own scatter
+ *       (tests/test_oracle.py::test_testcase4_reproduces_the_references_own_shipped_results); the HIP path and the C++ drivers are
+ *       held to the same numbers at 128^3 and 512^3 (tests/test_gpu_parity.py, tests/test_gpu_cpp_drivers.py);
+ *   (2) the reference's own code where it builds here without stand-ins: src/timer.cpp (oracle/_ref: the timer CSV byte for byte)
+ *       and include/params.hpp (struct layout of the boundary); its launcher launch.py (the command lines the drivers must accept)
+ *       and the 25 000 timer CSV files it ships (section labels, file names);
+ *   (3) for inputs the reference holds nothing for -- it seeds its random inputs with clock() (tests/src/pencil/base.cu:49), owns no
+ *       arithmetic (closed cuFFT) and cannot be built here (CUDA, cuFFT, OpenMPI's mpi-ext.h; stand-ins are not allowed) --
+ *       bit patterns against cuFFT stay UNPINNED, and the oracle is pinned by (a) a long-double O(N^2) DFT for every 1-D length
+ *       used in tests, (b) numpy.fft (pocketfft, independent implementation) on 3-D grids, and (c) the properties the reference's
+ *       own tests check at this boundary: testcase 3 round trip (:641-666) and testcase 1 distributed == single device (:386-403).
+ *   See tests/test_oracle.py, tests/test_ref_timer.py, tests/test_launch_commands.py, tests/test_ref_csv_shapes.py.
  *
  * Citations are paths relative to /root/reference.
  */
@@ -566,15 +577,21 @@ void orc_fill_block(double *dst, size_t Ny, size_t Nz, size_t x0, size_t y0, siz
 void orc_derivative_coefficients(cplx *out, size_t Nx, size_t Ny, size_t Nz, size_t Nz_offset,
                                  size_t Ny_offset, size_t N1, size_t N2, int half)
 {
-    double norm = sqrt((double)Nx * (double)Ny * (double)Nz);
+    /* the reference's arithmetic to the letter (tests/src/pencil/random_dist_3D.cu:98-121, the double overload): the divisor is
+     * sqrtf -- SINGLE precision -- of the int product Nx*Ny*Nz, the numerator -powf(k1,2)-powf(k2,2)-powf(k3,2) (exact in float
+     * for these sizes), and each component is x * scale / root in double.  The float root is why the reference's own runs of
+     * testcase 4 print 1.91723e-05 / 7.43e-05 at 128^3 and 1.53465e-04 at 512^3 (3 |N^3/sqrtf(N^3) - sqrt(N^3)| times mean / max |u|;
+     * the logs it ships under benchmarks/argon and benchmarks/pcsgs, tests/golden/ref_testcase4_results.json) and ~1e-8 where N^3 is a power of 4 */
+    const double root = (double)sqrtf((float)(int)(Nx * Ny * Nz));
     for (size_t x = 0; x < Nx; x++) for (size_t y = 0; y < N2; y++) for (size_t z = 0; z < N1; z++) {
         double k1 = 0, k2 = 0, k3 = 0;
         size_t gy = y + Ny_offset, gz = z + Nz_offset;
         if (x < Nx / 2) k1 = (double)x; else if (x > Nx / 2) k1 = (double)(Nx - x);
         if (gy < Ny / 2) k2 = (double)gy; else if (gy > Ny / 2) k2 = (double)(Ny - gy);
         if (gz < Nz / 2) k3 = (double)gz; else if (!half && gz > Nz / 2) k3 = (double)(Nz - gz);
-        double scale = -(k1 * k1) - (k2 * k2) - (k3 * k3);
-        out[(x * N2 + y) * N1 + z] *= scale / norm;
+        const double scale = (double)(-(float)(k1 * k1) - (float)(k2 * k2) - (float)(k3 * k3));
+        cplx *v = &out[(x * N2 + y) * N1 + z];
+        *v = (creal(*v) * scale / root) + I * (cimag(*v) * scale / root);
     }
 }
 

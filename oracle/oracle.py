@@ -149,6 +149,29 @@ def derivative_coefficients(block, Nglobal, Nz_offset, Ny_offset, half):
     return block
 
 
+def testcase4_root(shape):
+    """the divisor of the reference's derivativeCoefficients: sqrtf (single precision) of the int product Nx*Ny*Nz
+    (tests/src/pencil/random_dist_3D.cu:117-118)"""
+    return float(np.sqrt(np.float32(int(shape[0]) * int(shape[1]) * int(shape[2]))))
+
+
+def testcase4_expected(shape, u):
+    """what forward -> derivativeCoefficients -> unnormalised inverse yields for u = sin sin sin in the reference's arithmetic:
+    -3 N^3 / sqrtf(N^3) u (the test compares it with -3 sqrt(N^3) u, random_dist_3D.cu:758-762)"""
+    n3 = float(shape[0]) * shape[1] * shape[2]
+    return -3.0 * n3 / testcase4_root(shape) * u
+
+
+def testcase4_printed(shape):
+    """(avg, max) the reference's testcase 4 prints, up to the rounding of the transforms: 3 |N^3/sqrtf(N^3) - sqrt(N^3)| times the
+    mean / max of |sin sin sin| over the grid"""
+    Nx, Ny, Nz = shape
+    n3 = float(Nx) * Ny * Nz
+    dev = 3.0 * abs(n3 / testcase4_root(shape) - np.sqrt(n3))
+    sx, sy, sz = (np.abs(np.sin(2 * np.pi * np.arange(n) / n)) for n in shape)
+    return dev * sx.mean() * sy.mean() * sz.mean(), dev * sx.max() * sy.max() * sz.max()
+
+
 class PencilPlan:
     """Virtual-rank restatement of MPIcuFFT_Pencil_Opt1 (slab == P2 = 1)."""
 
