@@ -28,21 +28,12 @@
 
 #include "alloc.hpp"
 #include "host_common.hpp"
+#include "plan.hpp"
 
 namespace dfft {
 
 static thread_local std::string g_error;
 void set_error(const std::string &msg) { g_error = msg; }
-
-// remainder to the lowest ranks (mpicufft_pencil_opt1.cpp:71-73)
-static void split(size_t n, int p, std::vector<size_t> &size, std::vector<size_t> &start)
-{
-    size.assign(p, n / p);
-    start.assign(p, 0);
-    for (size_t i = 0; i < n % p; i++) size[i]++;
-    size_t off = 0;
-    for (int i = 0; i < p; i++) { start[i] = off; off += size[i]; }
-}
 
 static int launch_pass(int prec, int N, int variant, const PassArgs &A, hipStream_t s)
 {
@@ -88,27 +79,6 @@ static int make_twiddles(int prec, size_t N, void **dev)
 }
 
 
-static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
-static size_t next_pow2(size_t n) { size_t m = 1; while (m < n) m <<= 1; return m; }
-
-// One axis of the 3-D transform: native Stockham chain, Bluestein on top of it, or two levels of either (N = N1*N2)
-struct Axis {
-    size_t N = 0;          // line length
-    bool bluestein = false;    // the generic kernel (fft_bluestein_kernel) runs the pass: Bluestein, or the levels of a two-level line
-    size_t M = 0;          // inner power-of-two length (== N when native)
-    void *tw = nullptr;    // exp(-2 pi i j / M), M entries
-    void *chirp = nullptr; // Bluestein: exp(-i pi n^2 / N), N entries
-    void *bhat = nullptr;  // Bluestein: FFT_M(conj chirp, wrapped) / M
-    // two-level line (fft_pass.hip.h, "Two-level lines"): lv[0] transforms N1 = lv[0].N points, lv[1] N2 = lv[1].N; a level is
-    // the plain power-of-two chain (bluestein == false, M == N) or Bluestein on an arbitrary factor
-    bool two = false;
-    // long Bluestein line (a length that neither fits one launch nor splits into two such factors: a prime above 4096, twice such a
-    // prime ...): Bluestein's algorithm whose M-point transforms are two-level lines; lv[0] is that two-level plan of M, chirp / bhat as
-    // for the one-launch form.  Four launches of the generic kernel (launch_long_bluestein).
-    bool longb = false;
-    std::vector<Axis> lv;
-    void *twN = nullptr;   // exp(-2 pi i j / N), N entries: twiddles between the levels
-};
 
 static void host_fft_pow2(std::vector<std::complex<long double>> &a)
 {
@@ -271,577 +241,6 @@ static int axis_upload(int prec, Axis &a)
 }  // namespace dfft
 
 using namespace dfft;
-
-struct Launch {
-    PassArgs args{};          // in/out/tw and the device table pointers are filled at enqueue time (zeroed: a plan builds only the launches of its kind)
-    SegTable lseg{}, sseg{};  // host copies of the segment tables (uploaded by upload_tables)
-    size_t ltab = 0, stab = 0;   // byte offsets of the tables in the plan's device table buffer
-    size_t lent = SIZE_MAX, sent = SIZE_MAX;   // byte offsets of the per-point address tables (SIZE_MAX: none)
-    size_t in_off = 0;        // byte offset added to the stage's input buffer
-    size_t out_off = 0;       // byte offset added to the stage's output buffer
-};
-struct A2A {
-    std::vector<size_t> sc, sd, rc, rd;   // bytes, absolute displacements in the stage buffers
-};
-
-struct Pipeline {
-    int C = 1;
-    std::vector<Launch> fz, fy, ix, iy, iz;   // per chunk
-    Launch fx;                                 // forward x pass (needs complete lines)
-    // partial transforms (reference: execR2C/C2R(out, in, d), src/pencil/mpicufft_pencil.cpp:1644-1839)
-    Launch pz1, qz1;                           // d = 1: z pass natural -> natural [xs][ys][Nzc] and back
-    std::vector<Launch> py2, qy2;              // d = 2: y pass chunk -> [xs][Ny][zs] and back
-    // slab sequence Z_Then_YX (src/slab/z_then_yx/): y passes per (chunk, source peer) block and one
-    // unchunked inverse x pass; the exchange tables live in f2 / i2
-    std::vector<Launch> zy, ziy;
-    Launch zix;
-    Launch yz;                                 // Y_Then_ZX: final z pass (x pass = fx, y chunks = fy)
-    // single-rank complex plans, pass order z, x, y (build_pipeline_single): natural lines -> L1 -> L2 -> natural
-    Launch sz, sx, sy;
-    bool single = false;
-    size_t single_work_elems = 0;              // size of the padded L2 buffer
-    std::vector<A2A> f1, f2, i2, i1;          // per chunk exchange tables
-    std::vector<hipEvent_t> ev;               // reusable events
-    hipStream_t comm_stream = nullptr;
-    hipStream_t comm_stream2 = nullptr;       // second exchange of a pencil plan (disjoint links: may overlap the first)
-    hipStream_t compute_stream2 = nullptr;    // option compute_streams = 2: the odd pipeline chunks of a pass run here (enqueue_forward)
-};
-
-struct TimedSpan { hipEvent_t a = nullptr, b = nullptr; int phase = 0; bool used = false; };
-
-// Tuning knobs of a plan (dfft_set_option; a few have environment defaults read once at plan creation).
-// Nothing here is read on the execution path.
-struct Options {
-    int chunks = 0;          // requested pipeline depth (0 = default)
-    int mirror = 0;          // single-rank complex inverse in the mirrored (multi-rank) pass order x, y, z
-    int tables = 1;          // per-point address tables: 0 never, 1 sides with more than one segment, 2 always
-    int uniform_tables = 1;  // sides whose segments all start at multiples of 16 points: table entries through wave-uniform
-                             // (scalar) loads, PassArgs::luni / suni (0: per-lane vector loads, for A/B runs)
-    int shift = -1;          // row-aligned tile windows of odd-pitch point-major stores: -1 auto (fp64), 0 off, 2 always
-    int debug = 0;           // PassArgs::debug of every launch (measurement only; results are wrong when set)
-    int real_variant = 0;    // A/B configurations of the real z passes (DFFT_EXPERIMENTS builds)
-    int single_order = -1;   // single-rank complex plans: 1 = pass order z, x, y with padded private layouts, 0 = z, y, x,
-                             // -1 = by measurement: z, x, y where it won (fp32 with x and y lines of 2048 points or more)
-    int single_layout = 1;   // L2 of the z, x, y order: 0 = [kx][kz/TL][y][l], 1 = tile-outer [kz/TL][kx][y][l]
-    int single_pad = 128;    // bytes added to every L2 row (a row stride that is an odd multiple of 128 B; 0 = packed)
-    int graph = 0;           // 1: single-rank plans replay the launches of an exec as one hipGraph from the second call with the same
-                             // buffers on.  Off by default -- measured (profiles/r2_graph_latency.txt): a blocking 64^3 R2C takes 28 us
-                             // with three plain launches and 34 us as a graph, 128^3 54 vs 60 us; the launches are already hidden
-                             // behind the first kernel (128^3: 50 us of kernels in a 54 us call)
-    int native_mixed = 1;    // lengths 2^a 3^b 5^c 7^d with a configuration run the native chain (0: Bluestein, for A/B runs and tests)
-    int two_level = 0;       // 1: every axis whose length splits as N1*N2 runs as a two-level line (tests, A/B runs; 0: only lengths
-                             // that have no other plan)
-    int spectral = 0;        // 1: the spectrum is kept x-contiguous, [yo][zs][Nx] (lines along kx natural), instead of the reference's
-                             // [Nx][yo][zs]: the forward x pass stores natural lines and the inverse x pass loads them -- neither
-                             // touches the point-major layout whose strided read is the slowest pass of every multi-rank plan
-    int compute_streams = -1; // 2: the pipeline chunks of a pass alternate over two compute streams, so that the drain of chunk c
-                             // overlaps the ramp of chunk c + 1 (a chunk launch of 0.1-0.2 ms pays ~20 us of launch / drain / ramp when
-                             // the chunks queue up behind each other on one stream).  -1 = by measurement
-                             // (profiles/r6_compute_streams.txt): two streams from three chunks per pass on (rank 0 of 2x4, 1024^3
-                             // fp64: 4 chunks 4.89 -> 4.78 ms, 8 chunks 5.31 -> 4.90; at two chunks there is nothing to gain), 1 = one
-    int order[6] = {-1, -1, -1, -1, -1, -1};     // workgroup->tile order per pass: fz fy fx ix iy iz; a_fastest + 2*xcd_swizzle
-    int variant[6] = {-1, -1, -1, -1, -1, -1};   // kernel configuration per pass, same order (-1 = the plan's choice)
-};
-
-struct dfft_plan {
-    int kind = DFFT_PENCIL_OPT1, prec = DFFT_F64;
-    dfft_config cfg{};
-    dfft_comm *comm = nullptr;
-    int rank = 0, nranks = 1;
-    bool initialized = false, c2c = false;
-    bool spectral_mirror = false;   // one rank with an x-contiguous spectrum (option spectral_layout): the inverse runs the mirrored pass order
-    bool zyx = false;            // slab sequence Z_Then_YX: input split along x, output split along z
-    bool yzx = false;            // slab sequence Y_Then_ZX: R2C along y, output [Nx][(Ny/2+1)/P][Nz], forward only
-    size_t Nyc = 0;              // y extent of the spectrum (Ny/2+1 for a Y_Then_ZX R2C plan, else Ny)
-    size_t Nx = 0, Ny = 0, Nz = 0, Nzc = 0;
-    int P1 = 1, P2 = 1, pi = 0, pj = 0;
-    int TL = 8;
-    std::vector<size_t> xs, xstart, ys, ystart, zs, zstart, yo, yostart;
-    size_t esz = 16, domain_elems = 0, domainsize = 0, worksize_d = 0;
-    void *work_d = nullptr;
-    bool work_owned = false;
-    Axis ax[3];                  // [0] = z, [1] = y, [2] = x
-    bool zreal_native = false;   // R2C plan whose z axis uses the packed Nz/2-point kernels
-    bool yreal_native = false;   // Y_Then_ZX R2C plan whose y axis uses the packed Ny/2-point kernel (strided real lines)
-    size_t lv_off = 0, lv_bytes = 0;   // two-level axes: scratch between the levels, a region of the work area (behind the exchange slices)
-    void *tw_zr = nullptr;       // split/merge table exp(-2 pi i k / Nz) (or / Ny) of the packed real kernels
-    void *tables_d = nullptr;    // segment tables of every launch, device copy
-    hipStream_t stream = nullptr;
-    bool stream_owned = false;
-    bool stream_user = false;    // caller chose the stream (the null stream is a valid choice)
-    // exchange tables in bytes (row comm = 1, column comm = 2) and member lists
-    std::vector<size_t> sc1, sd1, rc1, rd1, sc2, sd2, rc2, rd2;
-    std::vector<int> group1, group2;
-    dfft::RelayCache *relay = nullptr;      // two-hop relay of the group exchanges (dfft_comm_set_option "relay"): gathered world tables, staging
-    int vfwd[3] = {0, 0, 0}, vinv[3] = {0, 0, 0};   // kernel variant per pass: [0]=z [1]=y [2]=x
-    Options opt;
-    Pipeline pl;
-    // phase timing: (start, stop) event pairs, phases 0..4 = z, exchange 1, y, exchange 2, x
-    bool timing = false;
-    std::vector<TimedSpan> spans;
-    size_t nspans = 0;
-    int last_dir = -1;
-    // hipGraph replay of single-rank execs (launch-bound small grids): one instantiated graph per (operation, in, out)
-    struct GraphEntry { int kind; const void *in; void *out; int uses; hipGraphExec_t exec; };
-    std::vector<GraphEntry> graphs;
-};
-
-// ------------------------------------------------------------------------------------------
-// Pipelined execution plan.
-//
-// Every axis pass that feeds an exchange is cut into C chunks along its outer line-set axis
-// (x for the forward z/y passes and the inverse y/z passes, ky for the inverse x pass).  Send
-// and receive buffers are laid out chunk-outermost, [chunk][peer block], so one (chunk, peer)
-// message is contiguous: chunk c is exchanged on the communication stream while chunk c+1 is
-// still being transformed on the compute stream.  This replaces the reference's only overlap
-// mechanism, the Peer2Peer modes with MPI_Waitany / the sender thread
-// (src/pencil/mpicufft_pencil_opt1.cpp:601-754, src/pencil/mpicufft_pencil.cpp:513-585), at
-// chunk instead of whole-peer granularity.  C = 1 reproduces the reference's message sizes and
-// displacements exactly (mpicufft_pencil_opt1.cpp:269-273, 315-319).
-// ------------------------------------------------------------------------------------------
-// descriptor of one axis pass over `na` outer slices of `LB` lines each (tiles of TL lines)
-static PassArgs pass_args(int TL, size_t na, size_t LB, int load_kind, int store_kind, int swap)
-{
-    PassArgs A;
-    memset(&A, 0, sizeof(A));
-    A.na = (uint32_t)na; A.LB = (uint32_t)LB; A.nb = (uint32_t)((LB + TL - 1) / TL); A.ntiles = A.na * A.nb;
-    A.load_kind = load_kind; A.store_kind = store_kind; A.swap = swap; A.T2shift = ilog2(TL);
-    return A;
-}
-
-// Point-major store whose row pitch (AS_out) is not a multiple of the tile, e.g. the 513-wide rows
-// of an R2C spectrum: let every workgroup's window start at a cache-line boundary of its output row.
-// Needs every row start to differ from an aligned address by (a*AS_out) mod TL only, i.e. KS_out a
-// multiple of TL (the caller's buffer is assumed 128-byte aligned, like every hipMalloc result).
-static void set_shift(const dfft_plan *p, PassArgs &X)
-{
-    const uint32_t TL = (uint32_t)p->TL;
-    if (p->opt.shift == 0) return;
-    if (p->ax[2].bluestein) return;               // the Bluestein kernel has no shifted windows
-    // fp32 (16-line tiles of 8-byte points) measured 10 % slower with shifted windows, fp64 24 % faster
-    if (p->prec != DFFT_F64 && p->opt.shift != 2) return;
-    if (X.AS_out % TL == 0 || X.KS_out % TL != 0 || X.LB < TL) return;
-    X.shift = 1;
-    X.nb += 1;
-    X.ntiles = X.na * X.nb;
-}
-
-static void seg_push(SegTable &t, size_t start, size_t len, size_t base_elems)
-{
-    int s = t.nseg++;
-    t.start[s] = (uint32_t)start;
-    t.len[s] = (uint32_t)len;
-    t.base[s] = base_elems;
-}
-
-static int build_pipeline(dfft_plan *p, Pipeline &pl)
-{
-    const int TL = p->TL, P1 = p->P1, P2 = p->P2, C = pl.C;
-    const size_t xs = p->xs[p->pi], ys = p->ys[p->pj], zs = p->zs[p->pj], yo = p->yo[p->pi];
-    const size_t Nx = p->Nx, Ny = p->Ny, Nzc = p->Nzc, e = p->esz;
-    // bytes per input/output LINE of the z pass as the caller sees it (real lines in R2C mode)
-    const size_t zline_bytes = p->c2c ? p->Nz * e : p->Nz * (e / 2);
-    auto base = [&](size_t na, size_t LB, int lk, int sk, int swap) { return pass_args(TL, na, LB, lk, sk, swap); };
-    std::vector<size_t> xl, x0, kl, k0;
-    split(xs, C, xl, x0);       // my x range in chunks (forward z/y, inverse y/z passes)
-    split(yo, C, kl, k0);       // my ky range in chunks (inverse x pass)
-    // chunk c of every column peer's x / ky range (they split with the same rule)
-    std::vector<std::vector<size_t>> xlq(P1), x0q(P1), klq(P1), k0q(P1);
-    for (int q = 0; q < P1; q++) { split(p->xs[q], C, xlq[q], x0q[q]); split(p->yo[q], C, klq[q], k0q[q]); }
-
-    pl.fx = Launch();           // (initFFT may be called again on the same plan)
-    pl.fz.assign(C, Launch()); pl.fy.assign(C, Launch()); pl.ix.assign(C, Launch());
-    pl.iy.assign(C, Launch()); pl.iz.assign(C, Launch());
-    pl.f1.assign(C, A2A()); pl.f2.assign(C, A2A()); pl.i2.assign(C, A2A()); pl.i1.assign(C, A2A());
-
-    // ---------------- forward (mpicufft_pencil_opt1.cpp:1422-1519) ----------------
-    size_t R2c = 0;   // running element offset of chunk c in the exchange-2 receive buffer
-    {
-        PassArgs X = base(yo, zs, LOAD_TILED, STORE_KMAJOR, 0);
-        X.KS_out = (uint64_t)yo * zs;
-        X.AS_out = zs;
-        // neighbouring tiles along z' share cache lines whenever the pitch zs is not a multiple of the
-        // tile; keeping consecutive tiles on one XCD lets its L2 merge them (R2C, 513-wide: 6.3 -> 4.5 ms)
-        X.a_fastest = 0; X.xcd_swizzle = 1;
-        if (p->opt.spectral) {
-            // x-contiguous spectrum [ky][kz'][kx]: natural lines out (a = ky, lines of a slice = kz'), no point-major store
-            X.store_kind = STORE_LINES;
-            X.KS_out = 0; X.AS_out = 0;
-        } else
-        set_shift(p, X);
-        // segments of the x axis, ascending: peer q major, chunk c minor
-        std::vector<size_t> r2c_of(C, 0);
-        { size_t acc = 0; for (int c = 0; c < C; c++) { r2c_of[c] = acc; for (int q = 0; q < P1; q++) acc += xlq[q][c] * yo * zs; } }
-        for (int q = 0; q < P1; q++)
-            for (int c = 0; c < C; c++) {
-                size_t off = r2c_of[c];
-                for (int q2 = 0; q2 < q; q2++) off += xlq[q2][c] * yo * zs;
-                if (xlq[q][c]) seg_push(pl.fx.lseg, p->xstart[q] + x0q[q][c], xlq[q][c], off);
-            }
-        pl.fx.args = X;
-    }
-    for (int c = 0; c < C; c++) {
-        const size_t S1c = x0[c] * Nzc * ys, R1c = x0[c] * zs * Ny, S2c = x0[c] * zs * Ny;
-        {   // z pass chunk: natural lines -> send1 block (c,p) = [x][kz/TL][y][kz%TL], kz in zs[p]
-            Launch &L = pl.fz[c];
-            L.args = base(xl[c], ys, LOAD_LINES, STORE_TILED_TRANSPOSE, 0);
-            L.in_off = x0[c] * ys * zline_bytes;
-            for (int q = 0; q < P2; q++) seg_push(L.sseg, p->zstart[q], p->zs[q], S1c + xl[c] * p->zstart[q] * ys);
-        }
-        {   // exchange 1, row group (:269-273 restricted to the chunk)
-            A2A &T = pl.f1[c];
-            for (int q = 0; q < P2; q++) {
-                T.sc.push_back(e * xl[c] * p->zs[q] * ys);
-                T.sd.push_back(e * (S1c + xl[c] * p->zstart[q] * ys));
-                T.rc.push_back(e * xl[c] * p->ys[q] * zs);
-                T.rd.push_back(e * (R1c + xl[c] * p->ystart[q] * zs));
-            }
-        }
-        {   // y pass chunk: lines along y from the P2 blocks -> send2 block (c,p) = [ky][kz/TL][x][kz%TL]
-            Launch &L = pl.fy[c];
-            L.args = base(xl[c], zs, LOAD_TILED, STORE_TILED_SAME, 0);
-            for (int q = 0; q < P2; q++) seg_push(L.lseg, p->ystart[q], p->ys[q], R1c + xl[c] * p->ystart[q] * zs);
-            for (int q = 0; q < P1; q++) seg_push(L.sseg, p->yostart[q], p->yo[q], S2c + xl[c] * zs * p->yostart[q]);
-            L.args.LA = (uint32_t)xl[c];
-        }
-        {   // exchange 2, column group (:315-319 restricted to the chunk)
-            A2A &T = pl.f2[c];
-            size_t roff = R2c;
-            for (int q = 0; q < P1; q++) {
-                T.sc.push_back(e * xl[c] * zs * p->yo[q]);
-                T.sd.push_back(e * (S2c + xl[c] * zs * p->yostart[q]));
-                T.rc.push_back(e * xlq[q][c] * yo * zs);
-                T.rd.push_back(e * roff);
-                roff += xlq[q][c] * yo * zs;
-            }
-            R2c = roff;
-        }
-    }
-    // ---------------- inverse (mpicufft_pencil_opt1.cpp:1522-1600) ----------------
-    std::vector<size_t> r2i_of(C, 0);
-    { size_t acc = 0; for (int c = 0; c < C; c++) { r2i_of[c] = acc; for (int q = 0; q < P1; q++) acc += xs * zs * klq[q][c]; } }
-    for (int c = 0; c < C; c++) {
-        const size_t S2i = k0[c] * zs * Nx;
-        {   // x^-1 chunk (ky range): API layout point-major -> block (c,p) = [x][kz/TL][ky][kz%TL], x in xs[p]
-            Launch &L = pl.ix[c];
-            L.args = base(kl[c], zs, LOAD_KMAJOR, STORE_TILED_SAME, 1);
-            L.args.KS_in = (uint64_t)yo * zs;
-            L.args.AS_in = zs;
-            // aligned pitch: step along ky between neighbouring workgroups (DRAM/TLB spread);
-            // odd pitch (R2C): neighbouring z' tiles on one XCD so the shared lines are read once.
-            // (Row-aligned LOAD windows -- the mirror image of set_shift -- were measured in round 4 and rejected: the loads become
-            // whole cache lines, but every 128-byte run of the private layout is then written in two pieces by two workgroups:
-            // 3.63 -> 5.88 ms at 1024^3 on 513-wide rows, 0.80 -> 1.03 ms on rank 0 of 2 x 4, profiles/r4_shift_load_rejected.txt)
-            L.args.xcd_swizzle = 1;
-            L.args.a_fastest = zs % TL == 0 ? 1 : 0;
-            L.in_off = e * k0[c] * zs;
-            if (p->opt.spectral) {
-                // x-contiguous spectrum: natural lines in, [ky][kz'][kx], this chunk's ky rows first
-                L.args.load_kind = LOAD_LINES;
-                L.args.KS_in = 0; L.args.AS_in = 0;
-                L.args.a_fastest = 0;
-                L.in_off = e * k0[c] * zs * Nx;
-            }
-            for (int q = 0; q < P1; q++) seg_push(L.sseg, p->xstart[q], p->xs[q], S2i + p->xstart[q] * zs * kl[c]);
-            L.args.LA = (uint32_t)kl[c];
-        }
-        {   // exchange 2 backwards
-            A2A &T = pl.i2[c];
-            size_t roff = r2i_of[c];
-            for (int q = 0; q < P1; q++) {
-                T.sc.push_back(e * p->xs[q] * zs * kl[c]);
-                T.sd.push_back(e * (S2i + p->xstart[q] * zs * kl[c]));
-                T.rc.push_back(e * xs * zs * klq[q][c]);
-                T.rd.push_back(e * roff);
-                roff += xs * zs * klq[q][c];
-            }
-        }
-    }
-    for (int c = 0; c < C; c++) {
-        const size_t S1i = x0[c] * Ny * zs, R1i = x0[c] * ys * Nzc;
-        {   // y^-1 chunk (x range): lines along ky from the (peer, ky-chunk) blocks ->
-            // block (c,p) = [x][y/TL][kz][y%TL], y in ys[p]
-            Launch &L = pl.iy[c];
-            L.args = base(xl[c], zs, LOAD_TILED, STORE_TILED_TRANSPOSE, 1);
-            for (int q = 0; q < P1; q++)
-                for (int c2 = 0; c2 < C; c2++) {
-                    size_t off = r2i_of[c2];
-                    for (int q2 = 0; q2 < q; q2++) off += xs * zs * klq[q2][c2];
-                    // the block is [x in xs][kz/TL][ky][kz%TL]: skip the x rows before this chunk
-                    if (klq[q][c2]) seg_push(L.lseg, p->yostart[q] + k0q[q][c2], klq[q][c2], off + x0[c] * klq[q][c2] * zs);
-                }
-            for (int q = 0; q < P2; q++) seg_push(L.sseg, p->ystart[q], p->ys[q], S1i + xl[c] * p->ystart[q] * zs);
-        }
-        {   // exchange 1 backwards
-            A2A &T = pl.i1[c];
-            for (int q = 0; q < P2; q++) {
-                T.sc.push_back(e * xl[c] * p->ys[q] * zs);
-                T.sd.push_back(e * (S1i + xl[c] * p->ystart[q] * zs));
-                T.rc.push_back(e * xl[c] * ys * p->zs[q]);
-                T.rd.push_back(e * (R1i + xl[c] * ys * p->zstart[q]));
-            }
-        }
-        {   // z^-1 chunk: lines along kz from the P2 blocks -> natural [x][y][z]
-            Launch &L = pl.iz[c];
-            L.args = base(xl[c], ys, LOAD_TILED, STORE_LINES, 1);
-            L.args.xcd_swizzle = 1;       // measured +3 % on the natural-line stores
-            for (int q = 0; q < P2; q++) seg_push(L.lseg, p->zstart[q], p->zs[q], R1i + xl[c] * ys * p->zstart[q]);
-            L.out_off = x0[c] * ys * zline_bytes;
-        }
-    }
-    // ---------------- partial transforms (d = 1, 2) ----------------
-    pl.pz1 = Launch(); pl.qz1 = Launch();
-    pl.pz1.args = base(xs, ys, LOAD_LINES, STORE_LINES, 0);
-    pl.qz1.args = base(xs, ys, LOAD_LINES, STORE_LINES, 1);
-    pl.py2.assign(C, Launch()); pl.qy2.assign(C, Launch());
-    for (int c = 0; c < C; c++) {
-        const size_t R1c = x0[c] * zs * Ny, S1i = x0[c] * Ny * zs;
-        {   // forward y pass chunk writing the reference's opt0 stage layout [xs][Ny][zs]
-            Launch &L = pl.py2[c];
-            L.args = base(xl[c], zs, LOAD_TILED, STORE_KMAJOR, 0);
-            for (int q = 0; q < P2; q++) seg_push(L.lseg, p->ystart[q], p->ys[q], R1c + xl[c] * p->ystart[q] * zs);
-            L.args.KS_out = zs; L.args.AS_out = Ny * zs; L.args.xcd_swizzle = 1;
-            L.out_off = e * x0[c] * Ny * zs;
-        }
-        {   // inverse y pass chunk reading [xs][Ny][zs]
-            Launch &L = pl.qy2[c];
-            L.args = base(xl[c], zs, LOAD_KMAJOR, STORE_TILED_TRANSPOSE, 1);
-            L.args.KS_in = zs; L.args.AS_in = Ny * zs;
-            L.in_off = e * x0[c] * Ny * zs;
-            for (int q = 0; q < P2; q++) seg_push(L.sseg, p->ystart[q], p->ys[q], S1i + xl[c] * p->ystart[q] * zs);
-        }
-    }
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------
-// Slab sequence Z_Then_YX (src/slab/z_then_yx/mpicufft_slab_z_then_yx.cpp:74-200): the input is
-// split along x, [xs][Ny][Nz]; after the z pass ONE all-to-all over all P ranks sends the slice
-// kz in zs[p] to rank p (counts :190-196), and the (y, x) transform runs on [Nx][Ny][zs].  Here:
-//   z pass chunk c      natural lines -> block (c,p) = [x][kz/TL][y][kz%TL]           (send)
-//   exchange chunk c    receive block (c,q) = [x in chunk c of xs[q]][kz/TL][y][kz%TL]
-//   y pass per (c,q)    -> block (c,q) = [ky][kz/TL][x][kz%TL]        (same offsets, other buffer)
-//   x pass              lines along x gathered from the P*C blocks -> API layout [kx][ky][kz']
-// and the mirror image for the inverse.  Uses p->xs (x split), p->zs (z split over P1 = P ranks).
-// ------------------------------------------------------------------------------------------
-static int build_pipeline_zyx(dfft_plan *p, Pipeline &pl)
-{
-    const int TL = p->TL, P = p->P1, C = pl.C, r = p->pi;
-    const size_t xs = p->xs[r], zs = p->zs[r];
-    const size_t Ny = p->Ny, Nzc = p->Nzc, e = p->esz;
-    const size_t zline_bytes = p->c2c ? p->Nz * e : p->Nz * (e / 2);
-    auto base = [&](size_t na, size_t LB, int lk, int sk, int swap) { return pass_args(TL, na, LB, lk, sk, swap); };
-    std::vector<size_t> xl, x0;
-    split(xs, C, xl, x0);
-    std::vector<std::vector<size_t>> xlq(P), x0q(P);
-    for (int q = 0; q < P; q++) split(p->xs[q], C, xlq[q], x0q[q]);
-    // element offset of block (c,q) on the z-split side, chunk outermost
-    std::vector<std::vector<size_t>> blk(C, std::vector<size_t>(P, 0));
-    { size_t acc = 0; for (int c = 0; c < C; c++) for (int q = 0; q < P; q++) { blk[c][q] = acc; acc += xlq[q][c] * Ny * zs; } }
-
-    pl.fx = Launch(); pl.zix = Launch();
-    pl.fz.assign(C, Launch()); pl.iz.assign(C, Launch());
-    pl.zy.assign((size_t)C * P, Launch()); pl.ziy.assign((size_t)C * P, Launch());
-    pl.f2.assign(C, A2A()); pl.i2.assign(C, A2A());
-    pl.fy.clear(); pl.ix.clear(); pl.iy.clear(); pl.f1.clear(); pl.i1.clear(); pl.py2.clear(); pl.qy2.clear();
-    pl.pz1 = Launch(); pl.qz1 = Launch();
-
-    for (int c = 0; c < C; c++) {
-        const size_t S1c = x0[c] * Nzc * Ny;     // send side: my x chunk, every kz
-        {   // z pass chunk
-            Launch &L = pl.fz[c];
-            L.args = base(xl[c], Ny, LOAD_LINES, STORE_TILED_TRANSPOSE, 0);
-            L.in_off = x0[c] * Ny * zline_bytes;
-            for (int q = 0; q < P; q++) seg_push(L.sseg, p->zstart[q], p->zs[q], S1c + xl[c] * p->zstart[q] * Ny);
-        }
-        {   // forward exchange (:190-196 restricted to the chunk)
-            A2A &T = pl.f2[c];
-            for (int q = 0; q < P; q++) {
-                T.sc.push_back(e * xl[c] * p->zs[q] * Ny);
-                T.sd.push_back(e * (S1c + xl[c] * p->zstart[q] * Ny));
-                T.rc.push_back(e * xlq[q][c] * Ny * zs);
-                T.rd.push_back(e * blk[c][q]);
-            }
-        }
-        for (int q = 0; q < P; q++) {   // y pass on the block received from q
-            Launch &L = pl.zy[(size_t)c * P + q];
-            L.args = base(xlq[q][c], zs, LOAD_TILED, STORE_TILED_SAME, 0);
-            seg_push(L.lseg, 0, Ny, blk[c][q]);
-            seg_push(L.sseg, 0, Ny, blk[c][q]);
-            L.args.LA = (uint32_t)xlq[q][c];
-        }
-    }
-    {   // x pass: lines along x from the P*C blocks -> [kx][ky][kz']
-        PassArgs X = base(Ny, zs, LOAD_TILED, STORE_KMAJOR, 0);
-        X.KS_out = (uint64_t)Ny * zs; X.AS_out = zs; X.xcd_swizzle = 1;
-        set_shift(p, X);
-        pl.fx.args = X;
-        for (int q = 0; q < P; q++)
-            for (int c = 0; c < C; c++)
-                if (xlq[q][c]) seg_push(pl.fx.lseg, p->xstart[q] + x0q[q][c], xlq[q][c], blk[c][q]);
-    }
-    // ---------------- inverse ----------------
-    {   // x^-1: API layout -> blocks (c,q) = [x][kz/TL][ky][kz%TL]
-        Launch &L = pl.zix;
-        L.args = base(Ny, zs, LOAD_KMAJOR, STORE_TILED_SAME, 1);
-        L.args.KS_in = (uint64_t)Ny * zs; L.args.AS_in = zs;
-        L.args.xcd_swizzle = 1; L.args.a_fastest = zs % TL == 0 ? 1 : 0;
-        L.args.LA = (uint32_t)Ny;
-        for (int q = 0; q < P; q++)
-            for (int c = 0; c < C; c++)
-                if (xlq[q][c]) seg_push(L.sseg, p->xstart[q] + x0q[q][c], xlq[q][c], blk[c][q]);
-    }
-    for (int c = 0; c < C; c++) {
-        const size_t R1i = x0[c] * Ny * Nzc;
-        for (int q = 0; q < P; q++) {   // y^-1 on block (c,q) -> send block [x][y/TL][kz'][y%TL]
-            Launch &L = pl.ziy[(size_t)c * P + q];
-            L.args = base(xlq[q][c], zs, LOAD_TILED, STORE_TILED_TRANSPOSE, 1);
-            seg_push(L.lseg, 0, Ny, blk[c][q]);
-            seg_push(L.sseg, 0, Ny, blk[c][q]);
-        }
-        {   // inverse exchange, already in send/receive order
-            A2A &T = pl.i2[c];
-            for (int q = 0; q < P; q++) {
-                T.sc.push_back(e * xlq[q][c] * Ny * zs);
-                T.sd.push_back(e * blk[c][q]);
-                T.rc.push_back(e * xl[c] * Ny * p->zs[q]);
-                T.rd.push_back(e * (R1i + xl[c] * Ny * p->zstart[q]));
-            }
-        }
-        {   // z^-1 chunk: lines along kz from the P blocks -> natural [x][y][z]
-            Launch &L = pl.iz[c];
-            L.args = base(xl[c], Ny, LOAD_TILED, STORE_LINES, 1);
-            L.args.xcd_swizzle = 1;
-            for (int q = 0; q < P; q++) seg_push(L.lseg, p->zstart[q], p->zs[q], R1i + xl[c] * Ny * p->zstart[q]);
-            L.out_off = x0[c] * Ny * zline_bytes;
-        }
-    }
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------
-// Slab sequence Y_Then_ZX (src/slab/y_then_zx/mpicufft_slab_y_then_zx.cpp:71-175, 268-378; the
-// reference provides the forward direction only).  The real-to-complex transform runs along y, the
-// output [Nx][(Ny/2+1)/P][Nz] keeps z contiguous:
-//   y pass chunk c   real lines along y read in place (lanes along z) -> send block (c,p) =
-//                    [ky in yo[p]][z/TL][x][z%TL]
-//   exchange chunk c (counts :309-319)  -> recv block (c,q), x in chunk c of xs[q]
-//   x pass           lines along x gathered from the P*C blocks -> [ky][kx/TL][z][kx%TL]
-//   z pass           -> rows (kx*yo + ky)*Nz of the API layout (strided-lines store)
-// ------------------------------------------------------------------------------------------
-static int build_pipeline_yzx(dfft_plan *p, Pipeline &pl)
-{
-    const int TL = p->TL, P = p->P1, C = pl.C, r = p->pi;
-    const size_t xs = p->xs[r], yo = p->yo[r];
-    const size_t Nx = p->Nx, Ny = p->Ny, Nz = p->Nz, e = p->esz;
-    auto base = [&](size_t na, size_t LB, int lk, int sk) { return pass_args(TL, na, LB, lk, sk, 0); };
-    std::vector<size_t> xl, x0;
-    split(xs, C, xl, x0);
-    std::vector<std::vector<size_t>> xlq(P), x0q(P);
-    for (int q = 0; q < P; q++) split(p->xs[q], C, xlq[q], x0q[q]);
-    std::vector<std::vector<size_t>> blk(C, std::vector<size_t>(P, 0));
-    { size_t acc = 0; for (int c = 0; c < C; c++) for (int q = 0; q < P; q++) { blk[c][q] = acc; acc += xlq[q][c] * yo * Nz; } }
-
-    pl.fx = Launch(); pl.yz = Launch(); pl.zix = Launch(); pl.pz1 = Launch(); pl.qz1 = Launch();
-    pl.fy.assign(C, Launch()); pl.f2.assign(C, A2A());
-    pl.fz.clear(); pl.iz.clear(); pl.ix.clear(); pl.iy.clear(); pl.zy.clear(); pl.ziy.clear();
-    pl.f1.clear(); pl.i1.clear(); pl.i2.clear(); pl.py2.clear(); pl.qy2.clear();
-    // in-place input lines: element (x, y, z) at (x*Ny + y)*Nz + z, in reals (R2C) or complex (C2C)
-    const size_t in_elem = p->c2c ? e : e / 2;
-    for (int c = 0; c < C; c++) {
-        const size_t S1c = x0[c] * p->Nyc * Nz;
-        {
-            Launch &L = pl.fy[c];
-            L.args = base(xl[c], Nz, LOAD_KMAJOR, STORE_TILED_SAME);
-            L.args.KS_in = Nz; L.args.AS_in = (uint64_t)Ny * Nz;
-            L.args.LA = (uint32_t)xl[c];
-            L.in_off = x0[c] * Ny * Nz * in_elem;
-            for (int q = 0; q < P; q++) seg_push(L.sseg, p->yostart[q], p->yo[q], S1c + xl[c] * Nz * p->yostart[q]);
-        }
-        {
-            A2A &T = pl.f2[c];
-            for (int q = 0; q < P; q++) {
-                T.sc.push_back(e * xl[c] * Nz * p->yo[q]);
-                T.sd.push_back(e * (S1c + xl[c] * Nz * p->yostart[q]));
-                T.rc.push_back(e * xlq[q][c] * Nz * yo);
-                T.rd.push_back(e * blk[c][q]);
-            }
-        }
-    }
-    {   // x pass: [ky][z/TL][x][z%TL] blocks -> [ky][kx/TL][z][kx%TL]
-        PassArgs X = base(yo, Nz, LOAD_TILED, STORE_TILED_TRANSPOSE);
-        pl.fx.args = X;
-        for (int q = 0; q < P; q++)
-            for (int c = 0; c < C; c++)
-                if (xlq[q][c]) seg_push(pl.fx.lseg, p->xstart[q] + x0q[q][c], xlq[q][c], blk[c][q]);
-        seg_push(pl.fx.sseg, 0, Nx, 0);
-    }
-    {   // z pass: lines along z, lanes along kx -> out[(kx*yo + ky)*Nz + kz]
-        PassArgs Z = base(yo, Nx, LOAD_TILED, STORE_LINES);
-        Z.KS_out = (uint64_t)yo * Nz; Z.AS_out = Nz;
-        pl.yz.args = Z;
-        seg_push(pl.yz.lseg, 0, Nz, 0);
-    }
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------
-// One rank, complex plan: input and output are both the natural [x][y][z] array, so the pass order is free (the
-// reference's fft3d branch is one cuFFT plan, src/pencil/mpicufft_pencil_opt1.cpp:132-135).  Order z, x, y:
-//   z pass   lines along z, 8 lines adjacent in x (rows a*AS_in + line*KS_in)  -> L1 = [y][kz/TL][x][kz%TL]   1 KiB runs
-//   x pass   chunk (y, kz tile) of L1                                          -> L2 = rows of 128 B, PADDED
-//   y pass   chunk (kx, kz tile) of L2                                         -> natural [kx][ky][kz]: a workgroup's
-//            1024 rows of 128 B lie 16 KiB apart inside ONE 16 MiB plane (the x-last order puts them 16 MiB apart)
-// L2 is private, so its row stride is made an odd multiple of 128 B (profiles/r2_placement_probe.txt: strided 128-byte
-// rows whose stride is a multiple of 256 B lose 6 % as a scatter and 15 % as a gather on this part).
-// The inverse runs the same launches with conjugation.
-// ------------------------------------------------------------------------------------------
-static int build_pipeline_single(dfft_plan *p, Pipeline &pl)
-{
-    const int TL = p->TL;
-    const size_t Nx = p->Nx, Ny = p->Ny, Nz = p->Nzc;
-    pl.single = false;
-    // measured (profiles/r2_single_order.txt): the y-last pass gains (2048^3 fp32: 34.7 -> 25.1 ms) but the z pass loses
-    // its contiguous 128 KiB read (8 lines from 8 x planes instead): 1024^3 fp64 38.0-38.8 vs 37.5 ms per step, fp32 21.4
-    // vs 20.1, 2048^3 fp32 181 vs 192 ms
-    const int order = p->opt.single_order >= 0 ? p->opt.single_order : (p->prec == DFFT_F32 && Nx >= 2048 && Ny >= 2048 ? 1 : 0);
-    if (p->nranks != 1 || !p->c2c || p->zyx || p->yzx || !order || p->opt.spectral) return 0;
-    const size_t nb = (Nz + TL - 1) / TL;
-    const size_t pad = (size_t)std::max(0, p->opt.single_pad) / p->esz;      // elements
-    pl.sz = Launch(); pl.sx = Launch(); pl.sy = Launch();
-    {   // z pass
-        PassArgs Z = pass_args(TL, Ny, Nx, LOAD_LINES, STORE_TILED_TRANSPOSE, 0);
-        Z.KS_in = (uint64_t)Ny * Nz;      // line stride: the 8 lines of a tile are adjacent in x
-        Z.AS_in = Nz;                      // a = y
-        Z.a_fastest = 1;                   // neighbouring workgroups read neighbouring (contiguous) lines
-        pl.sz.args = Z;
-        seg_push(pl.sz.sseg, 0, Nz, 0);
-    }
-    uint64_t SK, SB;
-    if (p->opt.single_layout == 1) { SK = (uint64_t)TL * Ny + pad; SB = (uint64_t)Nx * SK + pad; pl.single_work_elems = nb * SB; }
-    else { SK = (uint64_t)Nz * Ny + pad; SB = (uint64_t)TL * Ny; pl.single_work_elems = Nx * SK; }
-    {   // x pass: L1 chunk (y, kz tile) -> L2
-        PassArgs X = pass_args(TL, Ny, Nz, LOAD_TILED, STORE_TILED_SAME, 0);
-        X.LA = (uint32_t)Ny; X.SK = SK; X.SB = SB;
-        X.a_fastest = 1; X.xcd_swizzle = 1;      // neighbouring workgroups (y, y+1) write neighbouring 128-byte columns
-        pl.sx.args = X;
-        seg_push(pl.sx.lseg, 0, Nx, 0);
-        seg_push(pl.sx.sseg, 0, Nx, 0);
-    }
-    {   // y pass: L2 chunk (kx, kz tile) -> natural output
-        PassArgs Y = pass_args(TL, Nx, Nz, LOAD_TILED, STORE_KMAJOR, 0);
-        Y.IA = SK; Y.IB = SB;
-        Y.KS_out = Nz; Y.AS_out = (uint64_t)Ny * Nz;
-        Y.a_fastest = 0; Y.xcd_swizzle = 1;      // neighbouring workgroups (kz tiles) write neighbouring 128-byte columns of a row
-        if (!p->ax[1].bluestein && p->prec == DFFT_F64 && p->opt.shift != 0 && Y.AS_out % TL != 0 && Y.KS_out % TL == 0 && Y.LB >= (uint32_t)TL) {
-            Y.shift = 1; Y.nb += 1; Y.ntiles = Y.na * Y.nb;      // odd row pitch: row-aligned tile windows (see set_shift)
-        }
-        pl.sy.args = Y;
-        seg_push(pl.sy.lseg, 0, Ny, 0);
-    }
-    pl.single = true;
-    return 0;
-}
 
 static void fill_tables(dfft_plan *p, const Launch &L, PassArgs &A)
 {
@@ -1468,7 +867,7 @@ static int enqueue_partial_inverse(dfft_plan *p, void *out, void *in, int d)
 // Measured on ROCm 7.2 / MI355X the replay is 6-8 us SLOWER per exec than the three plain launches it replaces
 // (profiles/r2_graph_latency.txt), so it is not the default; it stays for callers that submit from a congested host thread.
 // ------------------------------------------------------------------------------------------
-static void graphs_clear(dfft_plan *p)
+void graphs_clear(dfft_plan *p)
 {
     for (auto &g : p->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     p->graphs.clear();
@@ -1507,7 +906,7 @@ template <typename F> static int run_graphed(dfft_plan *p, int kind, const void 
     return enqueue();                      // nothing ran during the failed capture
 }
 
-static int check_ready(dfft_plan *p)
+int check_ready(dfft_plan *p)
 {
     if (!p) return fail(ERR_ARG, "null plan");
     if (!p->initialized) return fail(ERR_STATE, "plan not initialised (call dfft_init first)");
@@ -2443,271 +1842,6 @@ int dfft_last_placement_info(char *buf, size_t capacity)
 {
     if (!buf || !capacity) return fail(ERR_ARG, "null buffer");
     return placement_info_json(buf, capacity);
-}
-
-// device time of the FFT passes (exchanges excluded) of one forward (+ inverse, if back != nullptr) execution on the given
-// buffers, best of `reps` after one untimed execution
-static int placement_measure(dfft_plan *p, const void *in, void *out, void *back, int reps, float *ms)
-{
-    auto once = [&](float *sum) -> int {
-        float ph[5];
-        if (p->c2c) TRY(dfft_exec_c2c(p, out, const_cast<void *>(in), DFFT_FORWARD)); else TRY(dfft_exec_r2c(p, out, in));
-        int n = dfft_get_phase_times(p, ph, 5);
-        float acc = 0;
-        for (int i = 0; i < n; i += 2) acc += ph[i];
-        if (back) {
-            if (p->c2c) TRY(dfft_exec_c2c(p, back, out, DFFT_INVERSE)); else TRY(dfft_exec_c2r(p, back, out));
-            n = dfft_get_phase_times(p, ph, 5);
-            for (int i = 0; i < n; i += 2) acc += ph[i];
-        }
-        *sum = acc;
-        return 0;
-    };
-    float best = 1e30f, cur = 0;
-    TRY(once(&cur));
-    for (int r = 0; r < reps; r++) { TRY(once(&cur)); best = std::min(best, cur); }
-    *ms = best;
-    return 0;
-}
-
-// The y / x passes of a plan on given buffers: the streaming (nontemporal) sibling of their kernel configuration where one
-// exists and measures faster HERE.  Whether the hints pay depends on the pass, the layout and the physical backing of the
-// buffers: on plain hipMalloc buffers they gained nothing repeatable on the 128-byte-run stores of 1024^3 fp64 (round 2), on
-// tuned backings the x pass goes 5.66 -> 5.44 ms (profiles/r3_yx_variants_on_tuned_buffers.txt); at fp32 2048 points they take
-// a quarter off two passes of the 8-GPU plan and double another (profiles/r3_f32_2048_tiled_variants.txt).
-// One trial of the tuners below: the plan executes forward in -> o and, if b, inverse o -> b three times; t[0..5] receive the
-// smallest time of every pass (fz fy fx ix iy iz, from the phase timers), *total their smallest sum.
-static int tune_trial(dfft_plan *p, const void *in, void *o, void *b, float t[6], float *total)
-{
-    for (int k = 0; k < 6; k++) t[k] = 1e30f;
-    *total = 1e30f;
-    for (int rep = 0; rep < 3; rep++) {
-        float ph[5], sum = 0;
-        if (p->c2c) TRY(dfft_exec_c2c(p, o, const_cast<void *>(in), DFFT_FORWARD)); else TRY(dfft_exec_r2c(p, o, in));
-        int n = dfft_get_phase_times(p, ph, 5);
-        for (int i = 0; i < n && i < 5; i += 2) { t[i / 2] = std::min(t[i / 2], ph[i]); sum += ph[i]; }
-        if (b) {
-            if (p->c2c) TRY(dfft_exec_c2c(p, b, o, DFFT_INVERSE)); else TRY(dfft_exec_c2r(p, b, o));
-            n = dfft_get_phase_times(p, ph, 5);
-            for (int i = 0; i < n && i < 5; i += 2) { t[3 + i / 2] = std::min(t[3 + i / 2], ph[i]); sum += ph[i]; }
-        }
-        *total = std::min(*total, sum);
-    }
-    return 0;
-}
-
-// The workgroup -> tile order of every pass (PassArgs::a_fastest, xcd_swizzle: which tiles are in flight together, and on which
-// XCD's L2 neighbours meet) and its kernel configuration (the variants of its length: streaming siblings, other lane mappings,
-// other tile shapes), chosen by measurement on the buffers the plan will run on.  The rules of build_pipeline / dfft_init were
-// fitted on the single-GPU 1024^3 plans; on the per-GPU plans of the 8-GPU grids other choices win some passes (rank 0 of 2 x 4 at
-// 1024^3 fp64: y 1.02 -> 0.88 ms with a-fastest tiles; 2048^3 fp32: y 4.89 -> 3.86 ms with the streaming configuration, y^-1
-// 5.59 -> 4.73 with the point-fastest store mapping on half tiles; profiles/r3_pass_orders_8gpu_plans.txt,
-// r3_pass_variants_8gpu_plans.txt) -- and whether the nontemporal hints pay depends on the pass, the layout and the physical backing
-// (profiles/r3_yx_variants_on_tuned_buffers.txt, r3_f32_2048_tiled_variants.txt).
-// A trial sets EVERY pass to order d (to variant v) at once and reads the per-pass times from the phase timers, so each pass
-// picks for itself from the same few executions: 4 order settings, then one setting per variant number that any axis length of
-// the plan has.  Which trials run depends on the global grid only, never on the rank (every trial executes the plan, exchanges
-// included: collective safety); the choices are each rank's own.  Passes the caller pinned (order_* / variant_*) are left alone.
-static int tune_variants(dfft_plan *p, const void *in, void *o, void *b, float &best, const std::function<void(float)> &note)
-{
-    if (p->zyx || p->yzx) return 0;                 // the slab sequences keep their rules
-    Pipeline &pl = p->pl;
-    const bool shared = p->nranks == 1 && !p->opt.mirror && !p->spectral_mirror && p->c2c;      // a single rank's complex inverse runs the forward launches
-    const bool single = pl.single && shared;                            // ... in the z, x, y order (three launches)
-    std::vector<Launch> *vecs[6] = {&pl.fz, &pl.fy, nullptr, &pl.ix, &pl.iy, &pl.iz};
-    auto launches = [&](int k, const std::function<void(Launch &)> &f) {
-        if (single) { if (k < 3) f(k == 0 ? pl.sz : k == 1 ? pl.sy : pl.sx); return; }
-        if (k == 2) f(pl.fx); else for (auto &L : *vecs[k]) f(L);
-    };
-    auto axis_of = [](int k) { return k < 3 ? k : 5 - k; };
-    auto slot = [&](int k) -> int & { return k < 3 ? p->vfwd[k] : p->vinv[5 - k]; };
-    auto usable = [&](int k) { return !(k >= 3 && (!b || shared)); };
-    float t[6], total = 0;
-    // judge a pass by both directions where they share its launches
-    auto cost = [&](const float *tt, int k) { return shared && b ? tt[k] + tt[5 - k] : tt[k]; };
-
-    // ---- orders
-    {
-        int keep[6];
-        float tb[6] = {0, 0, 0, 0, 0, 0}, td[4][6];
-        for (int k = 0; k < 6; k++) {
-            keep[k] = -1;
-            launches(k, [&](Launch &L) { if (keep[k] < 0) keep[k] = (L.args.a_fastest ? 1 : 0) + (L.args.xcd_swizzle ? 2 : 0); });
-        }
-        auto apply = [&](int k, int d) { launches(k, [&](Launch &L) { L.args.a_fastest = d & 1; L.args.xcd_swizzle = (d >> 1) & 1; }); };
-        auto tunable = [&](int k) { return keep[k] >= 0 && p->opt.order[k] < 0 && usable(k); };
-        for (int d = 0; d < 4; d++) {
-            for (int k = 0; k < 6; k++) if (tunable(k)) apply(k, d);
-            TRY(tune_trial(p, in, o, b, td[d], &total));
-            note(total);
-        }
-        for (int k = 0; k < 6; k++) {
-            if (!tunable(k)) continue;
-            int pick = keep[k];
-            for (int d = 0; d < 4; d++)
-                if (cost(td[d], k) < 1e29f && cost(td[d], k) < 0.99f * cost(td[pick], k)) pick = d;
-            apply(k, pick);
-            tb[k] = td[pick][k];
-        }
-        (void)tb;
-    }
-    // ---- kernel configurations
-    TRY(tune_trial(p, in, o, b, t, &total));        // the chosen orders with the rule-based configurations: the reference of the trials
-    note(total);
-    float cur[6];
-    for (int k = 0; k < 6; k++) cur[k] = t[k];
-    auto exists = [&](int k, int v) {
-        PassInfo pi;
-        const Axis &a = p->ax[axis_of(k)];
-        return !a.bluestein && (p->prec == DFFT_F64 ? pass_info_f64((int)a.N, v, &pi) : pass_info_f32((int)a.N, v, &pi));
-    };
-    auto tunable = [&](int k) { return usable(k) && p->opt.variant[k] < 0 && !p->ax[axis_of(k)].bluestein && !(p->c2c == false && axis_of(k) == 0); };
-    // only the role variants that the parity suite runs on every pass and address form (tests/test_gpu_variants.py); an A/B build
-    // (-DDFFT_EXPERIMENTS) carries further configuration numbers that are measured by hand, never picked here
-    auto validated = [&](int v) {
-        if (p->prec == DFFT_F64) return (v >= 0 && v <= 3) || v == 7 || v == 8;
-        return v == 0 || v == 1 || (v >= 3 && v <= 7) || v == 9 || v == 14 || v == 15;
-    };
-    for (int v = 0; v < 16; v++) {
-        if (!validated(v)) continue;
-        // does any axis length of the plan have this variant?  (global lengths: the same answer on every rank)
-        bool any = false;
-        for (int k = 0; k < 3; k++) any = any || exists(k, v);
-        if (!any) continue;
-        int old[6];
-        bool tried[6];
-        for (int k = 0; k < 6; k++) {
-            old[k] = slot(k);
-            tried[k] = tunable(k) && exists(k, v) && old[k] != v;
-            if (tried[k]) slot(k) = v;
-        }
-        if (shared) for (int k = 0; k < 3; k++) if (tried[k]) tried[5 - k] = false;      // (vinv is not used; judged through cost())
-        float tv[6];
-        TRY(tune_trial(p, in, o, b, tv, &total));
-        note(total);
-        for (int k = 0; k < 6; k++) {
-            if (!tried[k]) continue;
-            float c0[6], c1[6];
-            for (int q = 0; q < 6; q++) { c0[q] = cur[q]; c1[q] = tv[q]; }
-            if (cost(c1, k) < 1e29f && cost(c1, k) < 0.99f * cost(c0, k)) { cur[k] = tv[k]; if (shared && b) cur[5 - k] = tv[5 - k]; }
-            else slot(k) = old[k];
-        }
-    }
-    // ---- address forms: scalar base + 32-bit lane offset (the default) against per-point 64-bit vector addresses.  The scalar
-    // form saves a 64-bit multiply-add and a register pair per point and wins wherever instruction issue matters (fp32 passes
-    // 4-9 %, the fp32 strided read 23 %, profiles/r3_scalar_base_addresses.txt); the y and z passes of 1024^3 fp64 on one rank
-    // run 1-1.5 % faster with the old form (their accesses leave in one burst after all addresses are known)
-    {
-        TRY(tune_trial(p, in, o, b, t, &total));
-        float tv[6];
-        for (int k = 0; k < 6; k++) if (usable(k)) launches(k, [&](Launch &L) { L.args.addr64 = 1; });
-        TRY(tune_trial(p, in, o, b, tv, &total));
-        note(total);
-        for (int k = 0; k < 6; k++) {
-            if (!usable(k)) continue;
-            const bool keep64 = cost(tv, k) < 1e29f && cost(tv, k) < 0.995f * cost(t, k);      // (the two forms differ by 0.5 - 1.5 % where the old one wins)
-            launches(k, [&](Launch &L) { L.args.addr64 = keep64 ? 1 : 0; });
-        }
-    }
-    TRY(placement_measure(p, in, o, b, 2, &best));
-    note(best);
-    return 0;
-}
-
-// physical chunk sizes (MiB) tried in turn; 0 = plain hipMalloc
-static const size_t kPlacementRecipes[] = {1024, 64, 2, 256, 0, 16, 512, 128};      // ([0] is never used: the first candidate is the default recipe)
-
-int dfft_tune_variants(dfft_plan *p, const void *in, void *out, void *back, float *report_ms, int max_report, int *n_report)
-{
-    TRY(check_ready(p));
-    if (!in || !out) return fail(ERR_ARG, "null buffer");
-    const bool was_timing = p->timing;
-    TRY(dfft_enable_phase_timing(p, 1));
-    int nrep = 0;
-    auto note = [&](float v) { if (report_ms && nrep < max_report) report_ms[nrep] = v; nrep++; };
-    float best = 0;
-    int rc = placement_measure(p, in, out, back, 2, &best);
-    note(best);
-    if (rc == 0) rc = tune_variants(p, in, out, back, best, note);
-    p->timing = was_timing;
-    graphs_clear(p);
-    if (n_report) *n_report = nrep < max_report ? nrep : max_report;
-    return rc;
-}
-
-int dfft_tune_placement(dfft_plan *p, const void *in, int tries, void **out, void **back, float *report_ms, int max_report, int *n_report)
-{
-    TRY(check_ready(p));
-    if (!in || !out) return fail(ERR_ARG, "null buffer");
-    if (tries < 1) tries = 1;
-    // COLLECTIVE on a multi-rank plan: every trial executes the plan, exchanges included.  How many candidates fit depends on the
-    // rank's own buffer sizes and free memory, so a search there could run a different number of trials on different ranks and
-    // strand the peers in an exchange.  Multi-rank plans therefore get NO candidate search: out / back come from the default
-    // recipe (like the work area) and only the variant trials run, whose count depends on the global grid alone.
-    if (p->nranks > 1) tries = 1;
-    size_t isz[3];
-    TRY(dfft_get_in_size(p, isz));
-    const size_t in_bytes = isz[0] * isz[1] * isz[2] * (p->c2c ? p->esz : p->esz / 2);
-    const size_t out_bytes = p->domainsize, work_bytes = p->worksize_d;
-    const bool own_work = p->work_owned;      // a caller-provided work area stays as it is
-    const bool was_timing = p->timing;
-    TRY(dfft_enable_phase_timing(p, 1));
-    int nrep = 0;
-    auto note = [&](float v) { if (report_ms && nrep < max_report) report_ms[nrep] = v; nrep++; };
-    auto room_for = [&](size_t bytes) {
-        size_t free_b = 0, total_b = 0;
-        return hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > bytes + ((size_t)1 << 30);
-    };
-    const size_t nrec = sizeof(kPlacementRecipes) / sizeof(kPlacementRecipes[0]);
-    void *o = nullptr, *b = nullptr;
-    // first candidate of every buffer: the default recipe (what a caller gets from dfft_malloc(DFFT_CHUNK_DEFAULT) without a search)
-    int rc = dev_alloc_default(out_bytes, &o);
-    if (rc == 0 && back) rc = dev_alloc_default(in_bytes, &b);
-    float best = 0;
-    if (rc == 0) rc = placement_measure(p, in, o, b, 2, &best);
-    note(best);
-    // One buffer at a time (the passes' sensitivities to their buffers are independent): work area, out, back.  All candidates
-    // of a buffer are allocated BEFORE any is measured and the losers are freed afterwards: a freed candidate's physical pages
-    // would simply be handed out again to the next one, and it is the physical pages that differ.
-    for (int which = 0; which < 3 && rc == 0; which++) {
-        if (which == 0 && !own_work) continue;
-        if (which == 2 && !back) continue;
-        const size_t bytes = which == 0 ? work_bytes : which == 1 ? out_bytes : in_bytes;
-        std::vector<void *> cands;
-        for (int t = 1; t < tries; t++) {
-            void *cand = nullptr;
-            // (dev_alloc clamps a chunk larger than the buffer to the buffer's own size: still another physical allocation to try)
-            const size_t rec_chunk = std::min(kPlacementRecipes[(size_t)t % nrec] << 20, (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1));
-            const size_t rounded = rec_chunk ? (bytes + rec_chunk - 1) / rec_chunk * rec_chunk : bytes;
-            if (!room_for(rounded) || dev_alloc(bytes, kPlacementRecipes[(size_t)t % nrec], &cand) != 0) break;      // out of memory: fewer candidates
-            cands.push_back(cand);
-        }
-        void *keep = which == 0 ? p->work_d : which == 1 ? o : b;
-        for (void *cand : cands) {
-            if (rc != 0) { (void)dev_free(cand); continue; }
-            if (which == 0) p->work_d = cand;
-            float ms = 0;
-            rc = placement_measure(p, in, which == 1 ? cand : o, which == 2 ? cand : b, 2, &ms);
-            note(ms);
-            if (rc == 0 && ms < best) {
-                best = ms;
-                (void)dev_free(keep);
-                keep = cand;
-            } else {
-                (void)dev_free(cand);
-            }
-            if (which == 0) p->work_d = keep;
-        }
-        if (which == 1) o = keep; else if (which == 2) b = keep;
-    }
-    if (rc == 0) rc = tune_variants(p, in, o, b, best, note);
-    p->timing = was_timing;
-    graphs_clear(p);
-    if (rc != 0) { (void)dev_free(o); (void)dev_free(b); return rc; }
-    *out = o;
-    if (back) *back = b;
-    if (n_report) *n_report = nrep < max_report ? nrep : max_report;
-    return 0;
 }
 
 }  // extern "C"
