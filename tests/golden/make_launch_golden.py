@@ -29,6 +29,7 @@ def commands():
     launch = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(launch)
     seen = []
+    real_check_output = launch.subprocess.check_output      # (launch.subprocess IS the subprocess module: put it back afterwards)
     launch.subprocess.check_output = lambda command, shell=True: (seen.append(command), b"")[1]      # the ONE call that would execute it
     cwd, argv = os.getcwd(), sys.argv
     try:
@@ -40,6 +41,7 @@ def commands():
                 with contextlib.redirect_stdout(io.StringIO()):
                     launch.main()
     finally:
+        launch.subprocess.check_output = real_check_output
         os.chdir(cwd)
         sys.argv = argv
     return seen
