@@ -847,7 +847,28 @@ def main():
                              "kernel configurations, no tuner -- what a caller that follows the reference's ownership contract to the letter gets",
                      "ms_per_step": round(dtp / ksteps * 1e3, 3), "steps": ksteps, "round_trip_rel_linf": rt_p,
                      "value_GFLOPs": round(2 * flops_per_direction(N) * ksteps / dtp / 1e9, 1), "per_pass": per_pass(php, ksteps)}
-        del pp, p_work, p_out, p_back
+        del pp, p_work
+        # ... and what an UNMODIFIED reference call site gets: its own cudaMalloc'd in / out / back, and a work
+        # area the library owns (initFFT(..., allocate = true), placed by the library's allocator); no tuner call
+        unmodified = None
+        try:
+            pu = dfft.MPIcuFFT_Pencil_Opt1(dfft.Configurations(), None, precision=prec, rank=0)
+            pu.initFFT(dfft.GlobalSize(N, N, N), dfft.Partition(1, 1), allocate=False, c2c=True)
+            pu.setStream(stream)
+            pu.setWorkArea(None)
+            run_steps(pu, 2, p_out, p_back)
+            rt_u = round_trip_error(p_back)
+            pu.enablePhaseTiming(True)
+            dtu, phu, _ = run_steps(pu, ksteps, p_out, p_back, collect=True)
+            unmodified = {"what": "an unmodified reference call site: out / back from the caller's plain allocator (hipMalloc), the work area owned and "
+                                  "placed by the library (allocate = true), rule-based kernel configurations, no tuner call",
+                          "ms_per_step": round(dtu / ksteps * 1e3, 3), "steps": ksteps, "round_trip_rel_linf": rt_u,
+                          "value_GFLOPs": round(2 * flops_per_direction(N) * ksteps / dtu / 1e9, 1), "per_pass": per_pass(phu, ksteps)}
+            del pu
+        except Exception as e:   # noqa: BLE001
+            unmodified = {"error": str(e)}
+        plain_leg["unmodified_caller"] = unmodified
+        del p_out, p_back
         torch.cuda.empty_cache()
 
     # N > 1, pencil grids: the same plan with the two-hop relay on its group exchanges (every rank sets the option; collective)
@@ -1005,6 +1026,8 @@ def main():
         if plain_leg is not None:
             out["config"]["plain_buffers"] = plain_leg
             out["config"]["plain_buffers_ms_per_step"] = plain_leg["ms_per_step"]
+            if isinstance(plain_leg.get("unmodified_caller"), dict) and "ms_per_step" in plain_leg["unmodified_caller"]:
+                out["config"]["unmodified_caller_ms_per_step"] = plain_leg["unmodified_caller"]["ms_per_step"]
         if relay_leg is not None:
             out["config"]["relay"] = relay_leg
         if multi_rank_path is not None:
